@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""
+bench.py - headline benchmark of the hot path (BASELINE.json): tri-view 32x32 patches/s.
+
+  python bench.py --gpus N --steps K --warmup W [--mode forward|train] [--batch B]
+
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
+  forward (default; BASELINE configs[1]): deterministic forward of B = 100 000 tri-view patches through
+      scs_forward (probabilities + labels), shipped miccai2012_v1 weights.
+  train   (BASELINE configs[2]/[3]):     one scs_train_step + gradient all-reduce (RCCL, N > 1) + scs_adam_apply
+      on B = 256 samples per GPU.
+N > 1: launched by torchrun, one rank per GPU; ranks process independent batches (weak scaling), the forward
+path has no collective, the training path exactly one (the gradient arena).  Timing = K steps between
+barrier + synchronize brackets, max over ranks; rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel (fused conv1+conv2+pool1, 50.6 % of the net's MACs) is timed live with HIP events
+on the launch stream (scs_forward_profiled); achieved = algorithmic FLOP per launch / mean launch duration against
+the 157.3 TFLOP/s fp32 matrix/vector peak of gfx950.  cpu_baseline: the float32 torch-CPU port of the same net
+(oracle/torch_ref.py, all host threads) on a bounded sample - a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'sub-cortical_segmentation_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# MACs per tri-view patch and stage (nets.py:170-231), all three towers
+STAGE_NAMES = ['conv1+conv2+pool1', 'conv3', 'conv4+pool2', 'conv5', 'd1x3', 'FC1', 'fc_2', 'out+softmax']
+STAGE_MACS = [3 * (162000 + 2822400), 3 * 1036800, 3 * 1440000, 3 * 194400, 3 * 97200, 291600, 149850, 4050]
+FWD_FLOP = 2 * sum(STAGE_MACS)                 # 35 407 800
+TRAIN_FLOP = 3 * FWD_FLOP                      # fwd + dgrad + wgrad
+PEAK_F32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+ALGO_BYTES_FWD = 3 * 4096 + 60 + 60            # patches + atlas in, probs out
+
+
+def synth_on_device(torch, n, seed, dev):
+    g = torch.Generator(device=dev)
+    views = []
+    for i in range(3):
+        g.manual_seed(seed + i)
+        views.append(torch.randn((n, 1, 32, 32), generator=g, device=dev, dtype=torch.float32))
+    g.manual_seed(seed + 3)
+    e = -torch.log(torch.rand((n, 15), generator=g, device=dev, dtype=torch.float32).clamp_min(1e-12))
+    atlas = (e / e.sum(1, keepdim=True)).contiguous()                 # Dirichlet(1_15)
+    return views[0], views[1], views[2], atlas
+
+
+def cpu_baseline(weights, budget_s=12.0, batch=128):
+    """float32 torch-CPU port on the host cores, bounded sample (kind 'port': the reference's Theano CPU path
+    cannot run here - BASELINE.md section 3)."""
+    import torch
+    from oracle import torch_ref as T
+    from cnn_cort import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    net = T.FoldedCPUNet(weights)
+    ax, co, sa, at = [torch.from_numpy(a) for a in synth.patch_batch(batch, seed=0)]
+    net.forward(ax, co, sa, at)                                        # warm-up
+    done, t0 = 0, time.time()
+    while time.time() - t0 < budget_s and done < 16384:
+        net.forward(ax, co, sa, at)
+        done += batch
+    dt = time.time() - t0
+    return {'value': done / dt, 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d N(0,1) tri-view patches in batches of %d (nolearn effective batch), float32 torch-CPU forward, %.1f s'
+                      % (done, batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
+    ap.add_argument('--batch', type=int, default=0)
+    ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    from cnn_cort import _hip, dist, params as P
+
+    rank, world, local = dist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device')
+    torch.cuda.set_device(local)
+    dev = 'cuda:%d' % local
+    weights = P.load_params(os.path.join(PKG, 'nets', 'miccai2012_v1', 'miccai2012_v1'))
+    h = _hip.Handle(local)
+    h.set_params(P.params_to_flat(weights))
+    if args.chunk:
+        h.set_chunk(args.chunk)
+    chunk = h.set_chunk(0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    if args.mode == 'forward':
+        B = args.batch or 100000
+        ax, co, sa, at = synth_on_device(torch, B, 1000 * rank, dev)
+        probs = torch.empty((B, 15), device=dev)
+        labels = torch.empty((B,), dtype=torch.int32, device=dev)
+
+        def step():
+            h.forward(ax, co, sa, at, B, probs, labels, st)
+        flop_per_patch = FWD_FLOP
+        workload = 'forward-only inference, synthetic 32x32x3-view float32 patches, batch %d per GPU (BASELINE configs[1])' % B
+    else:
+        B = args.batch or 256
+        ax, co, sa, at = synth_on_device(torch, B, 1000 * rank, dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(4 + rank)
+        y = torch.randint(0, 15, (B,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+        ctr = [0]
+
+        def step():
+            ctr[0] += 1
+            h.train_step(ax, co, sa, at, y, B, seed=5 + ctr[0], want_loss=False, stream=st)
+            scale = dist.allreduce_grads(h, True, st, n_active=world)
+            h.adam_apply(grad_scale=scale, stream=st)
+        flop_per_patch = TRAIN_FLOP
+        workload = 'training step (fwd+bwd+Adam), synthetic batch %d per GPU, 15 classes (BASELINE configs[2]/[3])' % B
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = dist.max_scalar(time.perf_counter() - t0)
+    value = world * B * args.steps / dt
+
+    out = {
+        'metric': 'tri-view 32x32 patches/s (%s)' % ('forward' if args.mode == 'forward' else 'train step'),
+        'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': workload, 'weights': 'miccai2012_v1 (shipped)', 'per_gpu_batch': B, 'chunk': chunk,
+                   'parallelism': 'independent patch shards, no data-path collective' if args.mode == 'forward'
+                   else 'dp%d, one RCCL all-reduce of the 3.5 MB gradient arena per step' % world},
+        'net_tflops': value * flop_per_patch / 1e12,
+        'net_frac_of_f32_peak': value * flop_per_patch / 1e12 / (PEAK_F32_TFLOPS * world),
+    }
+
+    if rank == 0 and args.mode == 'forward':
+        # dominant kernel, timed with HIP events on the launch stream (untimed region)
+        ms, launches = h.forward_profiled(ax, co, sa, at, B, probs, labels, st)
+        ms2, _ = h.forward_profiled(ax, co, sa, at, B, probs, labels, st)
+        ms = np.minimum(ms, ms2)
+        dom = int(np.argmax(ms))
+        per_launch_patches = B / launches
+        flop_launch = 2.0 * STAGE_MACS[dom] * per_launch_patches
+        dur = ms[dom] / launches * 1e-3
+        achieved = flop_launch / dur / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')           # filled from rocprofv3 --pmc passes
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(STAGE_NAMES[dom])
+            except Exception:
+                traffic = None
+        out['roofline'] = {'bound': 'mfma', 'kernel': STAGE_NAMES[dom], 'achieved': achieved, 'peak': PEAK_F32_TFLOPS,
+                           'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic,
+                           'launch_ms': dur * 1e3, 'patches_per_launch': per_launch_patches}
+        out['stages'] = {STAGE_NAMES[i]: {'ms_per_step': float(ms[i]),
+                                          'tflops': 2.0 * STAGE_MACS[i] * B / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None}
+                         for i in range(8)}
+        out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out['cpu_baseline'] = cpu_baseline(weights)
+    if rank == 0:
+        print(json.dumps(out))
+    h.close()
+
+
+if __name__ == '__main__':
+    main()

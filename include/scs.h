@@ -1,0 +1,133 @@
+/*
+ * scs.h - C ABI of libscs.so, the MI355X (gfx950) implementation of the tri-planar voxelwise CNN of
+ * sergivalverde/sub-cortical_segmentation.
+ *
+ * The reference has no C/FFI boundary: its boundary is the Python object protocol of the nolearn `net`
+ * object plus three functions of cnn_cort/base.py.  This library is what the py3
+ * `cnn_cort` package in this repo binds (ctypes) to provide that protocol; each entry point names the
+ * reference call it replaces.  Plain pointers and sizes only - no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative scs_status on failure; scs_last_error() gives text.
+ *   - "dev" pointers are HIP device pointers on the handle's device; "host" pointers are ordinary memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only enqueue work;
+ *     the caller synchronises the stream (the *_host variants synchronise before returning).
+ *   - tensors are C-contiguous float32: views [n,1,32,32], atlas [n,15], probs [n,15]; labels int32 [n].
+ *   - parameters travel as ONE flat float32 arena in the reference's own order ("Lasagne layout"): the 88
+ *     layers of nets.py:170-231 in graph order, per layer the arrays of get_params() (conv W; BN beta,
+ *     gamma, mean, inv_std; PReLU alpha; dense W (in,out), b) - 883 455 floats.  Nothing is flipped or
+ *     folded in the arena; the library derives its packed MFMA operand layouts from it on the device.
+ */
+#ifndef SCS_H
+#define SCS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCS_N_PARAMS 883455          /* floats in the Lasagne-layout arena (the shipped miccai2012_v1 weights) */
+#define SCS_N_CLASSES 15
+#define SCS_PATCH 32
+
+typedef struct scs_ctx* scs_handle;
+
+typedef enum {
+    SCS_OK = 0,
+    SCS_ERR_ARG = -1,        /* bad argument (null pointer, wrong size, n < 0 ...) */
+    SCS_ERR_HIP = -2,        /* a HIP runtime call failed (no device, launch failure, out of memory) */
+    SCS_ERR_STATE = -3       /* call order (e.g. forward before scs_set_params) */
+} scs_status;
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* scs_last_error(void);
+
+/* Library/ABI version, and the gfx target the kernels were compiled for ("gfx950"). */
+int scs_abi_version(void);
+const char* scs_target_arch(void);
+
+/* Create / destroy a net instance bound to HIP device `device`.
+ * Replaces: nolearn NeuralNet(...) construction in build_model (nets.py:233-246). */
+int scs_create(int device, scs_handle* out);
+int scs_destroy(scs_handle h);
+
+/* Upload / download all parameters (host pointers, Lasagne-layout arena, n must be SCS_N_PARAMS).
+ * Replaces: net.load_params_from / net.save_params_to (nets.py:251, SaveWeights at nets.py:155).
+ * scs_set_params also (re)builds the inference operands (BN folded into the conv weights, filters flipped
+ * to correlation form, MFMA fragment order) and resets the Adam state. */
+int scs_set_params(scs_handle h, const float* host_arena, size_t n);
+int scs_get_params(scs_handle h, float* host_arena, size_t n);
+
+/* Batch-chunk size used internally by the forward entry points (default 4096 patches; workspace is
+ * allocated for one chunk).  Returns the value in effect. */
+int scs_set_chunk(scs_handle h, int patches_per_chunk);
+
+/* Deterministic forward on n patches (device pointers).  probs and/or labels may be NULL.
+ * labels[i] = argmax_c probs[i][c] (first maximum), i.e. nolearn's predict = argmax(predict_proba).
+ * Replaces: net.predict / net.predict_proba (base.py:425-428, 435-438) - one pass yields both. */
+int scs_forward(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,
+                const float* atlas_dev, int64_t n, float* probs_dev, int32_t* labels_dev, void* stream);
+
+/* Same, host pointers: uploads chunk by chunk, synchronises before returning. */
+int scs_forward_host(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas,
+                     int64_t n, float* probs, int32_t* labels);
+
+/* Gather-fused inference: patches are cut on the fly from a z-scored volume resident on the device.
+ *   vol_dev     float32 [X][Y][Z] (C order), already normalised (base.py:358)
+ *   centers_dev int32 [n][3] voxel coordinates (x,y,z); patches are zero padded outside the volume and the
+ *               centre lands at patch index [16][16] (base.py:293-306)
+ *   atlas4d_dev float32 [X][Y][Z][15]; rows that sum to 0 become background, channel 14 = 1 (base.py:391-394)
+ * Replaces: the host loop load_patch_batch + get_patches (base.py:380-397, 272-308) feeding net.predict. */
+int scs_forward_volume(scs_handle h, const float* vol_dev, int dim_x, int dim_y, int dim_z,
+                       const int32_t* centers_dev, const float* atlas4d_dev, int64_t n,
+                       float* probs_dev, int32_t* labels_dev, void* stream);
+
+/* Measurement hook (bench.py): scs_forward with HIP events recorded on `stream` around each stage of every
+ * chunk; synchronises.  stage_ms[8] receives the summed elapsed milliseconds of
+ *   0 conv1+conv2+pool1, 1 conv3, 2 conv4+pool2, 3 conv5, 4 d1 x3, 5 FC1 (+atlas concat), 6 fc_2, 7 out+softmax
+ * and *launches the number of chunks (= launches per stage). */
+int scs_forward_profiled(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,
+                         const float* atlas_dev, int64_t n, float* probs_dev, int32_t* labels_dev, void* stream,
+                         float* stage_ms, int* launches);
+
+/* Test hook: copy an intermediate activation of the LAST chunk processed by scs_forward to the host.
+ * which: 0 pool1 [3][n][20][14][14], 1 conv3 [3][n][40][12][12], 2 pool2 [3][n][40][5][5],
+ *        3 conv5 [3][n][540], 4 d1 concat [n][540], 5 FC1+atlas [n][556], 6 fc_2 [n][272], 7 logits [n][16]
+ * n = patches in that chunk; count = floats the caller's buffer holds (must match). */
+int scs_get_activation(scs_handle h, int which, float* host_out, size_t count);
+
+/* ---- training (replaces net.fit's per-batch train_iter_/eval_iter_, nets.py:233-246 + train_model.py:57) -- */
+
+/* One forward+backward in training mode (BN batch statistics, dropout p=0.5, mean cross-entropy) on n
+ * samples (device pointers; y = uint8 class ids 0..14).  Gradients land in the gradient arena (Lasagne
+ * layout, zeros at BN mean/inv_std); BN running statistics in the parameter arena are updated with
+ * alpha = 0.1.  Dropout keep-masks come from `masks_dev` when non-NULL (uint8 0/1, laid out
+ * [3][n][540] tower masks in (c,h,w) order, then [n][540] f1_drop, then [n][540] f2_drop), else from a
+ * counter-based generator keyed by dropout_seed.  *loss_host receives the batch mean loss (the call
+ * synchronises the stream to return it) unless NULL. */
+int scs_train_step(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,
+                   const float* atlas_dev, const uint8_t* y_dev, int64_t n, uint64_t dropout_seed,
+                   const uint8_t* masks_dev, float* loss_host, void* stream);
+
+/* Device pointers to the parameter and gradient arenas (SCS_N_PARAMS floats each) - the gradient arena is
+ * what a data-parallel caller all-reduces (RCCL) between scs_train_step and scs_adam_apply. */
+int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n);
+int scs_grad_arena(scs_handle h, float** dev_ptr, size_t* n);
+
+/* lasagne.updates.adam over the whole arena (nets.py:236-237): t += 1, bias-corrected step size,
+ * p -= a_t * m / (sqrt(v) + eps).  grad_scale multiplies the gradient first (1/world_size after a
+ * sum all-reduce).  Then refreshes the inference operands. */
+int scs_adam_apply(scs_handle h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* Deterministic forward + summed cross-entropy + number of correct argmax predictions on n labelled
+ * samples (nolearn eval_iter_).  Synchronises. */
+int scs_eval_batch(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,
+                   const float* atlas_dev, const uint8_t* y_dev, int64_t n,
+                   double* loss_sum_host, int64_t* n_correct_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCS_H */

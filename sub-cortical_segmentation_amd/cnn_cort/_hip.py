@@ -1,0 +1,173 @@
+"""
+ctypes binding of libscs.so (include/scs.h) - the only route from the Python surface to the HIP kernels.
+
+There is deliberately no CPU fallback: if the library is missing, or no MI355X-class device is visible,
+every compute entry point raises.  (The oracle under /oracle is test infrastructure and is never imported
+from here.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libscs.so')
+N_PARAMS = 883455
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/scs.h one to one
+_c = ctypes
+_f32p = _c.POINTER(_c.c_float)
+_vp = _c.c_void_p
+SIGNATURES = {
+    'scs_last_error': (_c.c_char_p, []),
+    'scs_abi_version': (_c.c_int, []),
+    'scs_target_arch': (_c.c_char_p, []),
+    'scs_create': (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
+    'scs_destroy': (_c.c_int, [_vp]),
+    'scs_set_params': (_c.c_int, [_vp, _vp, _c.c_size_t]),
+    'scs_get_params': (_c.c_int, [_vp, _vp, _c.c_size_t]),
+    'scs_set_chunk': (_c.c_int, [_vp, _c.c_int]),
+    'scs_forward': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
+    'scs_forward_host': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
+    'scs_forward_volume': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
+    'scs_forward_profiled': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _c.POINTER(_c.c_int)]),
+    'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
+    'scs_train_step': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
+    'scs_param_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
+    'scs_grad_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
+    'scs_adam_apply': (_c.c_int, [_vp, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
+    'scs_eval_batch': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.POINTER(_c.c_double),
+                                  _c.POINTER(_c.c_int64), _vp]),
+}
+
+
+class ScsError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libscs.so and attach the prototypes.  Raises ScsError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScsError('HIP extension missing: %s (build it with __graft_entry__.build() or '
+                       '`make -C sub-cortical_segmentation_amd/csrc`)' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().scs_last_error()
+        raise ScsError('%s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def _ptr(x):
+    """Device/host pointer of a torch tensor, numpy array or None as an integer."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()
+
+
+class Handle:
+    """Owns one scs_handle on one device."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check(self.lib.scs_create(int(device), ctypes.byref(h)), 'scs_create')
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.scs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        if flat.size != N_PARAMS:
+            raise ValueError('parameter arena has %d floats, expected %d' % (flat.size, N_PARAMS))
+        _check(self.lib.scs_set_params(self.h, flat.ctypes.data, flat.size), 'scs_set_params')
+
+    def get_params(self):
+        out = np.empty(N_PARAMS, np.float32)
+        _check(self.lib.scs_get_params(self.h, out.ctypes.data, out.size), 'scs_get_params')
+        return out
+
+    def set_chunk(self, n):
+        return self.lib.scs_set_chunk(self.h, int(n))
+
+    # ---- inference
+    def forward(self, ax, co, sa, atlas, n, probs=None, labels=None, stream=0):
+        _check(self.lib.scs_forward(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), int(n), _ptr(probs),
+                                    _ptr(labels), stream or None), 'scs_forward')
+
+    def forward_host(self, ax, co, sa, atlas, n, probs=None, labels=None):
+        _check(self.lib.scs_forward_host(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), int(n), _ptr(probs),
+                                         _ptr(labels)), 'scs_forward_host')
+
+    def forward_volume(self, vol, dims, centers, atlas4d, n, probs=None, labels=None, stream=0):
+        _check(self.lib.scs_forward_volume(self.h, _ptr(vol), int(dims[0]), int(dims[1]), int(dims[2]), _ptr(centers),
+                                           _ptr(atlas4d), int(n), _ptr(probs), _ptr(labels), stream or None),
+               'scs_forward_volume')
+
+    def forward_profiled(self, ax, co, sa, atlas, n, probs=None, labels=None, stream=0):
+        """-> (stage_ms float32[8], launches) measured with HIP events on `stream`."""
+        ms = np.zeros(8, np.float32)
+        k = ctypes.c_int(0)
+        _check(self.lib.scs_forward_profiled(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), int(n), _ptr(probs),
+                                             _ptr(labels), stream or None, ms.ctypes.data, ctypes.byref(k)),
+               'scs_forward_profiled')
+        return ms, int(k.value)
+
+    def get_activation(self, which, count):
+        out = np.empty(count, np.float32)
+        _check(self.lib.scs_get_activation(self.h, int(which), out.ctypes.data, out.size), 'scs_get_activation')
+        return out
+
+    # ---- training
+    def train_step(self, ax, co, sa, atlas, y, n, seed=0, masks=None, want_loss=True, stream=0):
+        loss = ctypes.c_float(0.0)
+        _check(self.lib.scs_train_step(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), _ptr(y), int(n),
+                                       ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
+                                       ctypes.addressof(loss) if want_loss else None, stream or None),
+               'scs_train_step')
+        return float(loss.value) if want_loss else None
+
+    def adam_apply(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0, stream=0):
+        _check(self.lib.scs_adam_apply(self.h, lr, b1, b2, eps, grad_scale, stream or None), 'scs_adam_apply')
+
+    def eval_batch(self, ax, co, sa, atlas, y, n, stream=0):
+        ls, nc = ctypes.c_double(0.0), ctypes.c_int64(0)
+        _check(self.lib.scs_eval_batch(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), _ptr(y), int(n),
+                                       ctypes.byref(ls), ctypes.byref(nc), stream or None), 'scs_eval_batch')
+        return float(ls.value), int(nc.value)
+
+    def _arena(self, fn):
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(fn(self.h, ctypes.byref(p), ctypes.byref(n)), 'arena query')
+        return p.value, n.value
+
+    def grad_arena(self):
+        return self._arena(self.lib.scs_grad_arena)
+
+    def param_arena(self):
+        return self._arena(self.lib.scs_param_arena)

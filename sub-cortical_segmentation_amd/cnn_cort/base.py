@@ -1,0 +1,289 @@
+"""
+Data assembly and the inference driver of the reference, for the HIP net.
+
+Mirrors /root/reference/cnn_cort/base.py (load_data :11-37, load_test_names :41-50, generate_training_set
+:53-117, load_patch_vectors :120-184, get_atlas_vectors :187-218, load_patches :221-256, get_patches
+:272-308, get_mask_voxels :310-331, load_patch_batch :335-397, test_scan :401-458, post_process_segmentation
+:460-480).  Same function names, argument meaning and outputs; what changed is how the work is done:
+
+  * get_patches is one strided-view gather instead of a Python list of per-voxel slices; centre lists are
+    int ndarrays [N,3] instead of lists of tuples (len(), slicing and np.stack(centers, axis=1) behave alike).
+  * test_scan never materialises patches on the host: the z-scored volume, the ROI centre list and the
+    4-D atlas go to the GPU once and libscs cuts the tri-planar patches inside the first conv kernel
+    (scs_forward_volume).  Labels and probabilities come from ONE forward pass (the reference runs the net
+    twice when out_probabilities is set, base.py:425,435).
+  * registration (register_masks, base.py:483-551: NiftyReg binaries + atlases that do not ship,
+    .MISSING_LARGE_BLOBS) is out of scope: tmp/MNI_sub_probabilities.nii.gz and tmp/MNI_subcortical_mask.nii.gz
+    must exist (FileNotFoundError otherwise).
+
+Reference quirks and what this module does about them:
+  * predict only under debug == 'True' (base.py:422): FIXED - always predicts.
+  * `crop` is a string and always truthy (base.py:367): reproduced for strings ('False' still crops), real
+    booleans are honoured.
+  * training-path atlas fix-up is dead code (base.py:213-216): reproduced (rows returned as they are).
+  * post_process_segmentation's empty-class behaviour (base.py:469-478): reproduced.
+  * unseeded negative sampling / permutation: seedable through options['seed'] (default: unseeded, as the
+    reference).
+"""
+import os
+import random
+import time
+
+import numpy as np
+from numpy.lib.stride_tricks import sliding_window_view
+from scipy import ndimage
+
+from . import nifti
+from .load_options import is_true
+
+_MODES = ('axial', 'coronal', 'saggital')
+
+
+# --------------------------------------------------------------------------------------------- names
+def load_test_names(options):
+    """Subject folders of the inference set -> (T1 paths, folder names) (base.py:41-50)."""
+    dir_name = options['test_folder']
+    t1_name = options['t1_name']
+    subjects = [f for f in sorted(os.listdir(dir_name)) if os.path.isdir(os.path.join(dir_name, f))]
+    return [os.path.join(dir_name, s, t1_name) for s in subjects], subjects
+
+
+def load_only_names(dir_name, mask_name, t1_name, use_t1, size):
+    """base.py:259-269."""
+    subjects = [f for f in sorted(os.listdir(dir_name)) if os.path.isdir(os.path.join(dir_name, f))]
+    return [os.path.join(dir_name, s, t1_name) for s in subjects] if use_t1 else None
+
+
+# --------------------------------------------------------------------------------------------- patches
+def get_patches(image, centers, patch_size=(32, 32), mode='axial'):
+    """2-D patches of one view around each centre, zero padded outside the volume (base.py:272-308).
+    axial = image[x-h:x+h, y-h:y+h, z], coronal = image[x-h:x+h, y, z-h:z+h], saggital = image[x, y-h:y+h, z-h:z+h]
+    (h = patch/2; the centre voxel lands at patch index [h][h]).  Returns ndarray [N, p1, p2] in image's dtype."""
+    if mode not in _MODES:
+        raise ValueError("mode must be 'axial', 'coronal' or 'saggital'")
+    image = np.asarray(image)
+    c = np.asarray(centers, dtype=np.int64).reshape(-1, 3)
+    p1, p2 = int(patch_size[0]), int(patch_size[1])
+    if c.shape[0] == 0:
+        return np.zeros((0, p1, p2), dtype=image.dtype)
+    ax = {'axial': (0, 1), 'coronal': (0, 2), 'saggital': (1, 2)}[mode]
+    h1, h2 = p1 // 2, p2 // 2
+    pad = [(0, 0)] * 3
+    pad[ax[0]] = (h1, p1 - h1)
+    pad[ax[1]] = (h2, p2 - h2)
+    padded = np.pad(image, pad, mode='constant', constant_values=0)
+    win = sliding_window_view(padded, (p1, p2), axis=ax)         # [..., p1, p2]; window origin = padded index
+    # after padding, the window that starts at the unpadded centre coordinate is the centred patch
+    return np.ascontiguousarray(win[c[:, 0], c[:, 1], c[:, 2]])
+
+
+def get_mask_voxels(mask, size=None, rng=None):
+    """Coordinates of the non-zero voxels in C order as int64 [N,3] (base.py:310-331).  With `size` the list is
+    shuffled (stdlib `random`, or the random.Random given as `rng`) and truncated, as the reference does."""
+    indices = np.stack(np.nonzero(mask), axis=1).astype(np.int64)
+    if size is not None:
+        perm = list(range(indices.shape[0]))
+        (rng or random).shuffle(perm)
+        indices = indices[np.asarray(perm[:size], dtype=np.int64)]
+    return indices
+
+
+def _zscore(image, as_float32):
+    """(image - mean) / std over the non-zero voxels, population std (base.py:146 training, :358 inference)."""
+    nz = image[np.nonzero(image)]
+    if as_float32:
+        return (image.astype(np.float32) - nz.mean()) / nz.std()
+    return (image - nz.mean()) / nz.std()
+
+
+# --------------------------------------------------------------------------------------------- training data
+def _subjects(dir_name):
+    return [f for f in sorted(os.listdir(dir_name)) if os.path.isdir(os.path.join(dir_name, f))]
+
+
+def load_patch_vectors(name, label_name, dir_name, size, random_state=42, balance_neg=True, rng=None):
+    """Per-subject training patches of all three views (base.py:120-184): every voxel with label 1..14, then an
+    equal number of randomly chosen label-15 (boundary) voxels; image AND label patches."""
+    subjects = _subjects(dir_name)
+    image_names = [os.path.join(dir_name, s, name) for s in subjects]
+    images = [nifti.load(n).get_data() for n in image_names]
+    images_norm = [_zscore(im, True) for im in images]
+    labels = [nifti.load(os.path.join(dir_name, s, label_name)).get_data() for s in subjects]
+
+    pos = [get_mask_voxels(np.logical_and(m > 0, m < 15)) for m in labels]
+    if balance_neg:
+        neg = [get_mask_voxels(m == 15, size=len(p), rng=rng) for m, p in zip(labels, pos)]
+    else:
+        neg = [get_mask_voxels(m == 15) for m in labels]
+    out = {}
+    for mode in _MODES:
+        out['x_' + mode] = [np.concatenate([get_patches(im, p, size, mode), get_patches(im, n, size, mode)])
+                            for im, p, n in zip(images_norm, pos, neg)]
+        out['y_' + mode] = [np.concatenate([get_patches(lb, p, size, mode), get_patches(lb, n, size, mode)])
+                            for lb, p, n in zip(labels, pos, neg)]
+    vox_positions = [np.concatenate([p, n]) for p, n in zip(pos, neg)]
+    return (out['x_axial'], out['y_axial'], out['x_coronal'], out['y_coronal'], out['x_saggital'], out['y_saggital'],
+            vox_positions, image_names)
+
+
+def get_atlas_vectors(dir_name, centers, t1_names):
+    """15-vector of the registered atlas at each patch centre (base.py:187-218)."""
+    subjects = _subjects(dir_name)
+    vectors = []
+    for subject, c in zip(subjects, centers):
+        atlas_path = os.path.join(dir_name, subject, 'tmp', 'MNI_sub_probabilities.nii.gz')
+        if not os.path.exists(atlas_path):
+            raise FileNotFoundError('%s is missing: run the NiftyReg registration of the reference first '
+                                    '(register_masks, base.py:483-551, is out of scope here)' % atlas_path)
+        a = nifti.load(atlas_path).get_data()
+        c = np.asarray(c, dtype=np.int64)
+        vectors.append(a[c[:, 0], c[:, 1], c[:, 2]])
+    return vectors
+
+
+def load_patches(dir_name, mask_name, t1_name, size, seeds=None, balance_neg=True, rng=None):
+    """base.py:221-256."""
+    print('    --> Loading ' + t1_name + ' images')
+    x_axial, y_axial, x_cor, y_cor, x_sag, y_sag, centers, t1_names = load_patch_vectors(
+        t1_name, mask_name, dir_name, size, 0, balance_neg, rng)
+    x_atlas = get_atlas_vectors(dir_name, centers, t1_names)
+    return x_axial, y_axial, x_cor, y_cor, x_sag, y_sag, x_atlas, t1_names
+
+
+def load_data(options):
+    """Patches of every training subject, all views (base.py:11-37).
+    Returns (x_axial, x_cor, x_sag, y_axial, x_atlas, names): lists indexed by subject."""
+    rng = random.Random(options['seed']) if options.get('seed') is not None else None
+    (x_axial, y_axial, x_cor, y_cor, x_sag, y_sag, x_atlas, names) = load_patches(
+        dir_name=options['train_folder'], t1_name=options['t1_name'], mask_name=options['roi_name'],
+        size=tuple(options['patch_size']), rng=rng)
+    return x_axial, x_cor, x_sag, y_axial, x_atlas, names
+
+
+def generate_training_set(x_axial, x_coronal, x_saggital, x_atlas, y, options, randomize=True):
+    """Concatenate subjects, take the centre label, map 15 -> 0, apply ONE permutation to all five arrays, add
+    the channel axis (base.py:53-117).  Returns (x_axial [N,1,p,p], x_cor, x_sag, x_atlas [N,15], y [N] uint8)."""
+    x_train_axial = np.concatenate(x_axial, axis=0).astype('float32')
+    x_train_cor = np.concatenate(x_coronal, axis=0).astype('float32')
+    x_train_sag = np.concatenate(x_saggital, axis=0).astype('float32')
+    x_train_atlas = np.concatenate(x_atlas, axis=0).astype('float32')
+    y_train = np.concatenate(y, axis=0).astype('uint8')
+    y_train = y_train[:, y_train.shape[1] // 2, y_train.shape[2] // 2]
+    y_train = np.squeeze(y_train)
+    y_train[y_train == 15] = 0
+    if randomize:
+        seed = options.get('seed')
+        if seed is None:
+            seed = np.random.randint(np.iinfo(np.int32).max)
+        # the reference re-seeds before each of the five permutations, i.e. applies one permutation five times
+        np.random.seed(seed)
+        perm = np.random.permutation(x_train_axial.shape[0])
+        x_train_axial, x_train_cor, x_train_sag = x_train_axial[perm], x_train_cor[perm], x_train_sag[perm]
+        y_train, x_train_atlas = y_train[perm], x_train_atlas[perm]
+    x_train_axial = np.expand_dims(x_train_axial, axis=1)
+    x_train_cor = np.expand_dims(x_train_cor, axis=1)
+    x_train_sag = np.expand_dims(x_train_sag, axis=1)
+    if is_true(options.get('debug')):
+        print("    --> X_TRAIN: ", x_train_axial.shape[0], x_train_axial.shape)
+        print("    --> Y_TRAIN POS: ", y_train[y_train > 0].shape[0])
+        print("    --> Y_TRAIN NEG: ", y_train[y_train == 0].shape[0])
+    return x_train_axial, x_train_cor, x_train_sag, x_train_atlas, y_train
+
+
+# --------------------------------------------------------------------------------------------- inference
+def _crop_enabled(options):
+    v = options.get('crop', 'True')
+    return bool(v)          # the reference tests the config STRING (base.py:367): any non-empty string crops
+
+
+def _scan_inputs(scan_name, options):
+    """Everything test_scan / load_patch_batch need from disk: normalised volume, ROI centres, atlas."""
+    dir_name = os.path.dirname(scan_name)
+    t1 = nifti.load(scan_name)
+    image = t1.get_data()
+    image_norm = _zscore(image, False)
+    atlas_name = os.path.join(dir_name, 'tmp', 'MNI_sub_probabilities.nii.gz')
+    mask_name = os.path.join(dir_name, 'tmp', 'MNI_subcortical_mask.nii.gz')
+    if not os.path.exists(atlas_name):
+        raise FileNotFoundError('%s is missing: run the NiftyReg registration of the reference first '
+                                '(register_masks, base.py:483-551, is out of scope here)' % atlas_name)
+    if _crop_enabled(options):
+        mask_atlas = nifti.load(mask_name).get_data()
+        b_mask = ndimage.binary_dilation(mask_atlas, iterations=10)
+        centers = get_mask_voxels(b_mask.astype(bool))
+    else:
+        centers = get_mask_voxels(image.astype(bool))
+    if is_true(options.get('debug')):
+        print("    -->  num of samples to test:", len(centers))
+    atlas_image = nifti.load(atlas_name).get_data()
+    return t1, image, image_norm, centers, atlas_image
+
+
+def atlas_vectors_at(atlas_image, centers):
+    """[N,15] float32 prior rows with the inference-path background rule (base.py:388-394)."""
+    c = np.asarray(centers, dtype=np.int64).reshape(-1, 3)
+    v = np.asarray(atlas_image[c[:, 0], c[:, 1], c[:, 2]]).astype(np.float32)
+    zero = v.sum(axis=1) == 0
+    v[zero, 14] = 1
+    return v
+
+
+def load_patch_batch(scan_name, options, datatype=np.float32):
+    """Generator over host-side test batches, as the reference yields them (base.py:335-397):
+    (axial [B,1,p,p], coronal, saggital, atlas [B,15], centers).  Kept for API compatibility and for tests;
+    test_scan itself uses the gather-fused GPU path instead."""
+    _, _, image_norm, centers_all, atlas_image = _scan_inputs(scan_name, options)
+    bs = options['test_batch_size']
+    for i in range(0, len(centers_all), bs):
+        centers = centers_all[i:i + bs]
+        views = [np.stack([get_patches(image_norm, centers, options['patch_size'], mode=m).astype(datatype)], axis=1)
+                 for m in _MODES]
+        yield views[0], views[1], views[2], atlas_vectors_at(atlas_image, centers), centers
+
+
+def test_scan(net, test_scan, options):
+    """Segment one T1 volume; writes out_subcortical_{prob,seg_prec,rawseg}.nii.gz next to it and returns the
+    elapsed minutes (base.py:401-458)."""
+    s_time = time.time()
+    image_path = os.path.dirname(test_scan)
+    t1, raw, image_norm, centers, atlas_image = _scan_inputs(test_scan, options)
+    want_probs = is_true(options.get('out_probabilities'))
+    image = np.zeros_like(raw)
+    image_proba = np.zeros(tuple(raw.shape) + (15,)) if want_probs else None
+
+    labels, probs = net.predict_volume(np.ascontiguousarray(image_norm, dtype=np.float32), centers,
+                                       np.ascontiguousarray(atlas_image, dtype=np.float32), want_probs=want_probs,
+                                       batch=options['test_batch_size'])
+    x, y, z = centers[:, 0], centers[:, 1], centers[:, 2]
+    image[x, y, z] = labels
+    if want_probs:
+        image_proba[x, y, z, :] = probs
+        nifti.save(image_proba, os.path.join(image_path, 'out_subcortical_prob.nii.gz'), like=t1)
+    if is_true(options.get('post_process')):
+        nifti.save(post_process_segmentation(image_path, image), os.path.join(image_path, 'out_subcortical_seg_prec.nii.gz'), like=t1)
+    else:
+        nifti.save(image, os.path.join(image_path, 'out_subcortical_rawseg.nii.gz'), like=t1)
+    return (time.time() - s_time) / 60.0
+
+
+def post_process_mask(input_mask, atlas):
+    """Array-level body of post_process_segmentation (base.py:464-480): per class 1..14 keep the connected
+    component with the largest overlap with the atlas mask.  np.unique(labels) includes the background
+    component 0 and the argmax INDEX is used as the component label, exactly as the reference does (so a
+    class without any atlas overlap paints its complement)."""
+    filtered_mask = np.zeros_like(input_mask)
+    for l in range(1, 15):
+        th_label = input_mask == l
+        labels, num_labels = ndimage.label(th_label)
+        label_list = np.unique(labels)
+        num_elements_by_lesion = ndimage.labeled_comprehension(np.logical_and(th_label, atlas), labels, label_list,
+                                                               np.sum, float, 0)
+        argmax = np.argmax(num_elements_by_lesion)
+        filtered_mask[labels == argmax] = l
+    return filtered_mask
+
+
+def post_process_segmentation(image_folder, input_mask):
+    """base.py:460-480."""
+    atlas = nifti.load(os.path.join(image_folder, 'tmp', 'MNI_subcortical_mask.nii.gz')).get_data()
+    return post_process_mask(input_mask, atlas)

@@ -1,0 +1,196 @@
+"""
+Multi-GPU plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) on xGMI.
+
+The reference is single-process / single-device ("Parallelism strategies: none"), so this
+layer is new.  What shards, and how:
+  * inference: patches / subjects are independent -> contiguous slices of the centre list (shard_range) or
+    whole subjects (shard_list) per rank, NO collective on the data path.
+  * training: pure data parallelism, identical replicas; per step each rank runs one mini-batch and ONE
+    exchange happens - a sum all-reduce of the contiguous float32 gradient arena (883 455 floats, 3.5 MB),
+    scaled by 1/active_ranks inside the Adam kernel.  Ranks without a batch at the tail of an epoch
+    contribute zeros.  BN running statistics are local per step and reconciled by an arena average once per
+    epoch (sync_params).
+All functions degrade to no-ops when torch.distributed is not initialised (world size 1).
+"""
+import os
+
+import numpy as np
+
+
+def _td():
+    import torch.distributed as td
+    return td
+
+
+def is_dist():
+    try:
+        td = _td()
+        return td.is_available() and td.is_initialized()
+    except Exception:
+        return False
+
+
+def world_size():
+    return _td().get_world_size() if is_dist() else 1
+
+
+def rank():
+    return _td().get_rank() if is_dist() else 0
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (RANK, WORLD_SIZE, MASTER_*).
+    backend defaults to 'nccl' (= RCCL) when a GPU is visible, else 'gloo'.  Returns (rank, world, local_rank)."""
+    import torch
+    td = _td()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not td.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        td.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=world)
+    return rank(), world_size(), local
+
+
+# ----------------------------------------------------------------------------------- sharding (no comms)
+def shard_range(n, world=None, r=None):
+    """Contiguous [lo, hi) slice of n independent units for rank r (sizes differ by at most 1)."""
+    world = world_size() if world is None else world
+    r = rank() if r is None else r
+    base, rem = divmod(int(n), world)
+    lo = r * base + min(r, rem)
+    return lo, lo + base + (1 if r < rem else 0)
+
+
+def shard_list(items, world=None, r=None):
+    """Round-robin assignment of whole items (subjects) to ranks: items[r::world]."""
+    world = world_size() if world is None else world
+    r = rank() if r is None else r
+    return list(items)[r::world]
+
+
+def shard_steps(starts, world=None, r=None):
+    """Lock-step schedule of mini-batches: step s gives rank r the batch starts[s*world + r].
+    Yields (start_or_None, active) for every step so that all ranks run the same number of collectives."""
+    world = world_size() if world is None else world
+    r = rank() if r is None else r
+    nb = len(starts)
+    for s in range((nb + world - 1) // world):
+        i = s * world + r
+        yield (starts[i], True) if i < nb else (None, False)
+
+
+def active_ranks(n_batches, step, world=None):
+    world = world_size() if world is None else world
+    return max(0, min(world, n_batches - step * world))
+
+
+# ----------------------------------------------------------------------------------- collectives
+class _DevArray:
+    """Zero-copy view of a raw device pointer for torch (CUDA array interface v2)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
+
+
+def wrap_device_floats(ptr, n, device):
+    import torch
+    return torch.as_tensor(_DevArray(ptr, n), device='cuda:%d' % device)
+
+
+def allreduce_flat(t, n_active):
+    """Sum all-reduce of a flat tensor (any backend); returns the scale that turns the sum into the mean over
+    the ranks that contributed."""
+    if is_dist() and world_size() > 1:
+        td = _td()
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return 1.0 / max(1, n_active)
+
+
+_step_state = {'n_active': None}
+
+
+def allreduce_grads(handle, active, stream=0, n_active=None):
+    """All-reduce the gradient arena of a libscs handle across ranks (RCCL); returns grad_scale for Adam.
+    `active` False = this rank had no batch this step: its arena is zeroed first."""
+    if world_size() == 1:
+        return 1.0
+    import torch
+    ptr, n = handle.grad_arena()
+    g = wrap_device_floats(ptr, n, handle.device)
+    if not active:
+        g.zero_()
+    td = _td()
+    flag = torch.tensor([1.0 if active else 0.0], device=g.device)
+    td.all_reduce(g, op=td.ReduceOp.SUM)
+    if n_active is None:
+        td.all_reduce(flag, op=td.ReduceOp.SUM)
+        n_active = int(flag.item())
+    return 1.0 / max(1, n_active)
+
+
+def sync_params(handle):
+    """Average the parameter arena across ranks (reconciles the per-rank BN running statistics; the trainable
+    entries are already identical)."""
+    if world_size() == 1:
+        return
+    ptr, n = handle.param_arena()
+    p = wrap_device_floats(ptr, n, handle.device)
+    td = _td()
+    td.all_reduce(p, op=td.ReduceOp.SUM)
+    p.mul_(1.0 / world_size())
+
+
+def mean_scalar(value, count):
+    """Count-weighted mean of a per-rank scalar (epoch train loss)."""
+    if world_size() == 1:
+        return float(value)
+    import torch
+    td = _td()
+    dev = 'cuda' if td.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([float(value) * count, float(count)], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t[0] / t[1]) if float(t[1]) > 0 else 0.0
+
+
+def max_scalar(value):
+    """Max over ranks (bench timing)."""
+    if world_size() == 1:
+        return float(value)
+    import torch
+    td = _td()
+    dev = 'cuda' if td.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t[0])
+
+
+def sum_scalar(value):
+    if world_size() == 1:
+        return float(value)
+    import torch
+    td = _td()
+    dev = 'cuda' if td.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t[0])
+
+
+def barrier():
+    if is_dist() and world_size() > 1:
+        _td().barrier()
+
+
+def gather_concat(arr, world=None):
+    """All-gather variable-length numpy arrays (labels of a sharded centre list) and concatenate in rank order.
+    Only needed when ONE rank must own the whole output; the compute path itself has no collective."""
+    if world_size() == 1:
+        return arr
+    td = _td()
+    out = [None] * world_size()
+    td.all_gather_object(out, np.asarray(arr))
+    return np.concatenate(out, axis=0)

@@ -1,0 +1,378 @@
+"""
+build_model() and the `net` object protocol of the reference, on libscs (HIP, gfx950).
+
+Mirrors /root/reference/cnn_cort/nets.py:127-255.  The reference returns a nolearn ``NeuralNet`` wrapping a
+Lasagne graph; both are external packages.  ``Net`` below reproduces the part of that object the reference
+uses: fit / predict / predict_proba / load_params_from / save_params_to / train_history_ (call sites
+nets.py:154-156,233-251, base.py:425,435, train_model.py:57-60), with the training-loop semantics of
+nolearn 0.6.0 + nolearn_utils 0.2.2 restated here:
+
+  * TrainSplit(eval_size): first fold of a non-shuffled stratified K-fold with K = round(1/eval_size) is the
+    validation set (old sklearn.cross_validation.StratifiedKFold semantics, restated in `stratified_first_fold`).
+  * BatchIterator: consecutive mini-batches, no shuffling.  The reference never passes a batch iterator, so
+    nolearn's default of 128 applies and options['batch_size'] is ignored.  Here options['batch_size']
+    is honoured when present (documented deviation); absent -> 128.
+  * per epoch: train on all training batches (dropout on, BN batch statistics), then evaluate deterministically
+    on the validation batches; history row {'epoch','train_loss','train_loss_best','valid_loss',
+    'valid_loss_best','valid_accuracy','dur'} (schema pinned by nets/miccai2012_v1/*_history.pkl).
+  * on_epoch_finished = [SaveWeights(only_best), SaveTrainingHistory, EarlyStopping(patience)] (nets.py:238-242);
+    early stopping fires when epoch - best_epoch >= patience (pinned by the shipped history: best 42, stop 62)
+    and restores the best weights.
+  * optimiser Adam(lr 1e-3) on mean categorical cross-entropy (nets.py:235-237).
+
+Deviations (documented in DESIGN.md): weights that fail to load raise instead of silently leaving a random
+net (nets.py:249-253 swallows every exception); files are a float32 blob + JSON manifest instead of pickles
+(the reference's own .pkl is still readable).
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+from . import params as P
+from .load_options import is_true
+
+__all__ = ['build_model', 'Net', 'stratified_first_fold', 'EarlyStopping']
+
+_SUPER = 16384      # patches moved to the device per slice when the caller hands over host arrays
+
+
+def stratified_first_fold(y, n_folds):
+    """Validation indices = fold 0 of sklearn<=0.17's StratifiedKFold(y, n_folds) (no shuffle), which is what
+    nolearn's TrainSplit takes: per class, the first ceil-share of that class's samples in order of appearance."""
+    y = np.asarray(y)
+    n = y.shape[0]
+    uniq, y_inv = np.unique(y, return_inverse=True)
+    test_folds = np.zeros(n, dtype=np.int64)
+    per_label = []
+    for c in np.bincount(y_inv):
+        m = max(int(c), n_folds)
+        sizes = np.full(n_folds, m // n_folds, dtype=np.int64)
+        sizes[:m % n_folds] += 1
+        bounds = np.concatenate([[0], np.cumsum(sizes)])
+        per_label.append([np.arange(bounds[i], bounds[i + 1]) for i in range(n_folds)])
+    for fold in range(n_folds):
+        for li in range(len(uniq)):
+            idx = np.nonzero(y_inv == li)[0]
+            split = per_label[li][fold]
+            split = split[split < idx.size]
+            test_folds[idx[split]] = fold
+    valid = np.nonzero(test_folds == 0)[0]
+    train = np.nonzero(test_folds != 0)[0]
+    return train, valid
+
+
+class EarlyStopping:
+    """nolearn_utils.hooks.EarlyStopping with the stop rule the shipped history pins (see module docstring)."""
+
+    def __init__(self, patience=20):
+        self.patience = patience
+        self.best_valid = np.inf
+        self.best_valid_epoch = 0
+        self.best_weights = None
+
+    def __call__(self, net, train_history):
+        cur = train_history[-1]['valid_loss']
+        epoch = train_history[-1]['epoch']
+        if cur < self.best_valid:
+            self.best_valid = cur
+            self.best_valid_epoch = epoch
+            self.best_weights = net.get_all_params_values()
+        elif epoch - self.best_valid_epoch >= self.patience:
+            if net.verbose:
+                print('Early stopping.')
+                print('Best valid loss was {:.6f} at epoch {}.'.format(self.best_valid, self.best_valid_epoch))
+            net.load_params_from(self.best_weights)
+            raise StopIteration()
+
+
+class Net:
+    """Drop-in for the nolearn NeuralNet the reference builds at nets.py:233-246."""
+
+    def __init__(self, weights_file=None, history_file=None, max_epochs=100, patience=20, eval_size=0.25,
+                 batch_size=128, verbose=0, device=None, update_learning_rate=0.001, seed=0):
+        self.weights_file = weights_file
+        self.history_file = history_file
+        self.max_epochs = int(max_epochs)
+        self.patience = int(patience)
+        self.eval_size = float(eval_size)
+        self.batch_size = int(batch_size)
+        self.verbose = int(verbose)
+        self.update_learning_rate = float(update_learning_rate)
+        self.seed = int(seed)
+        self.device = device
+        self.train_history_ = []
+        self._params = None          # host copy, Lasagne layout (OrderedDict)
+        self._handle = None          # libscs handle (created lazily on the device)
+        self._dirty = True           # host params newer than device
+        self._dev_newer = False      # device params newer than host (after training steps)
+        self._step = 0
+
+    # ------------------------------------------------------------------ device plumbing
+    def _torch(self):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('cnn_cort requires a HIP device (MI355X); torch.cuda.is_available() is False')
+        return torch
+
+    def _dev(self):
+        if self.device is None:
+            self.device = int(os.environ.get('LOCAL_RANK', '0'))
+        return int(self.device)
+
+    def _ensure_handle(self):
+        from . import _hip
+        torch = self._torch()
+        if self._handle is None:
+            torch.cuda.set_device(self._dev())
+            self._handle = _hip.Handle(self._dev())
+        if self._params is None:
+            self._params = P.init_params(self.seed)       # Lasagne default initialisers (training from scratch)
+            self._dirty = True
+        if self._dirty:
+            self._handle.set_params(P.params_to_flat(self._params))
+            self._dirty = False
+            self._dev_newer = False
+        return self._handle
+
+    def _sync_host(self):
+        if self._dev_newer and self._handle is not None:
+            self._params = P.flat_to_params(self._handle.get_params())
+            self._dev_newer = False
+
+    # ------------------------------------------------------------------ parameters
+    def get_all_params_values(self):
+        self._sync_host()
+        if self._params is None:
+            self._params = P.init_params(self.seed)
+        return {k: [a.copy() for a in v] for k, v in self._params.items()}
+
+    def load_params_from(self, source):
+        """nolearn load_params_from: a path (our .f32/.json pair or a reference .pkl) or a dict of arrays."""
+        if isinstance(source, (str, os.PathLike)):
+            params = P.load_params(str(source))
+        else:
+            params = P.check_params({k: [np.asarray(a, np.float32) for a in v] for k, v in source.items()})
+        self._params = params
+        self._dirty = True
+        self._dev_newer = False
+        return self
+
+    def save_params_to(self, path):
+        self._sync_host()
+        if self._params is None:
+            self._params = P.init_params(self.seed)
+        return P.save_params(str(path), self._params)
+
+    # ------------------------------------------------------------------ inference
+    def _as_device_inputs(self, X, lo, hi):
+        torch = self._torch()
+        out = []
+        for key in ('in1', 'in2', 'in3', 'in4'):
+            a = X[key]
+            if isinstance(a, np.ndarray):
+                t = torch.from_numpy(np.ascontiguousarray(a[lo:hi], dtype=np.float32)).to('cuda:%d' % self._dev())
+            else:
+                t = a[lo:hi].to(device='cuda:%d' % self._dev(), dtype=torch.float32).contiguous()
+            out.append(t)
+        return out
+
+    @staticmethod
+    def _check_X(X):
+        n = None
+        for key, tail in (('in1', (1, 32, 32)), ('in2', (1, 32, 32)), ('in3', (1, 32, 32)), ('in4', (15,))):
+            if key not in X:
+                raise ValueError("input dict lacks '%s'" % key)
+            shp = tuple(X[key].shape)
+            if shp[1:] != tail:
+                raise ValueError("'%s' has shape %r, expected [N,%s]" % (key, shp, ','.join(map(str, tail))))
+            if n is None:
+                n = shp[0]
+            elif shp[0] != n:
+                raise ValueError('inputs disagree on the number of samples')
+        return n
+
+    def _forward(self, X, want_probs):
+        torch = self._torch()
+        n = self._check_X(X)
+        h = self._ensure_handle()
+        dev = 'cuda:%d' % self._dev()
+        probs = np.empty((n, 15), np.float32) if want_probs else None
+        labels = np.empty((n,), np.int64)
+        stream = torch.cuda.current_stream(self._dev()).cuda_stream
+        for lo in range(0, n, _SUPER):
+            hi = min(n, lo + _SUPER)
+            ax, co, sa, at = self._as_device_inputs(X, lo, hi)
+            d_probs = torch.empty((hi - lo, 15), dtype=torch.float32, device=dev) if want_probs else None
+            d_lab = torch.empty((hi - lo,), dtype=torch.int32, device=dev)
+            h.forward(ax, co, sa, at, hi - lo, d_probs, d_lab, stream)
+            if want_probs:
+                probs[lo:hi] = d_probs.cpu().numpy()
+            labels[lo:hi] = d_lab.cpu().numpy()
+        return probs, labels
+
+    def predict_proba(self, X):
+        """float32 [N,15] softmax outputs (deterministic forward) - base.py:435-438."""
+        return self._forward(X, True)[0]
+
+    def predict(self, X):
+        """int64 [N] = argmax(predict_proba) - base.py:425-428 (nolearn, use_label_encoder=False)."""
+        return self._forward(X, False)[1]
+
+    def predict_volume(self, volume, centers, atlas4d, want_probs=False, batch=100000):
+        """Gather-fused inference for test_scan: `volume` float32 [X,Y,Z] already z-scored, `centers` int [N,3],
+        `atlas4d` float32 [X,Y,Z,15].  Returns (labels int64 [N], probs float32 [N,15] or None).
+        Replaces load_patch_batch + net.predict/predict_proba (base.py:380-397, 425-438)."""
+        torch = self._torch()
+        volume = np.ascontiguousarray(volume, dtype=np.float32)
+        atlas4d = np.ascontiguousarray(atlas4d, dtype=np.float32)
+        centers = np.ascontiguousarray(np.asarray(centers).reshape(-1, 3), dtype=np.int32)
+        if volume.ndim != 3:
+            raise ValueError('volume must be 3-D, got shape %r' % (volume.shape,))
+        if tuple(atlas4d.shape) != tuple(volume.shape) + (15,):
+            raise ValueError('atlas4d shape %r does not match volume shape %r + (15,)' % (atlas4d.shape, volume.shape))
+        n = centers.shape[0]
+        if n and ((centers < 0).any() or (centers >= np.asarray(volume.shape, np.int32)).any()):
+            raise ValueError('patch centres outside the volume')
+        if n == 0:
+            return np.zeros((0,), np.int64), (np.zeros((0, 15), np.float32) if want_probs else None)
+        h = self._ensure_handle()
+        dev = 'cuda:%d' % self._dev()
+        stream = torch.cuda.current_stream(self._dev()).cuda_stream
+        d_vol = torch.from_numpy(volume).to(dev)
+        d_atl = torch.from_numpy(atlas4d).to(dev)
+        d_cen = torch.from_numpy(centers).to(dev)
+        d_lab = torch.empty((n,), dtype=torch.int32, device=dev)
+        d_pr = torch.empty((n, 15), dtype=torch.float32, device=dev) if want_probs else None
+        batch = max(1, int(batch))
+        for lo in range(0, n, batch):
+            hi = min(n, lo + batch)
+            h.forward_volume(d_vol, volume.shape, d_cen[lo:hi], d_atl, hi - lo,
+                             d_pr[lo:hi] if want_probs else None, d_lab[lo:hi], stream)
+        labels = d_lab.cpu().numpy().astype(np.int64)
+        return labels, (d_pr.cpu().numpy() if want_probs else None)
+
+    # ------------------------------------------------------------------ training
+    def fit(self, X, y, epochs=None):
+        """net.fit({'in1','in2','in3','in4'}, y) - train_model.py:57-60."""
+        from . import dist
+        torch = self._torch()
+        n = self._check_X(X)
+        y = np.asarray(y)
+        if y.shape[0] != n:
+            raise ValueError('y has %d labels for %d samples' % (y.shape[0], n))
+        if y.size and (y.min() < 0 or y.max() > 14):
+            raise ValueError('labels must lie in 0..14')
+        h = self._ensure_handle()
+        dev = 'cuda:%d' % self._dev()
+        stream = torch.cuda.current_stream(self._dev()).cuda_stream
+
+        if self.eval_size and self.eval_size > 0:
+            tr_idx, va_idx = stratified_first_fold(y, int(round(1.0 / self.eval_size)))
+        else:
+            tr_idx, va_idx = np.arange(n), np.arange(0)
+
+        def to_dev(idx):
+            arrs = []
+            for key in ('in1', 'in2', 'in3', 'in4'):
+                a = X[key]
+                if isinstance(a, np.ndarray):
+                    arrs.append(torch.from_numpy(np.ascontiguousarray(a[idx], dtype=np.float32)).to(dev))
+                else:
+                    arrs.append(a[torch.as_tensor(idx, device=a.device)].to(device=dev, dtype=torch.float32).contiguous())
+            arrs.append(torch.from_numpy(np.ascontiguousarray(y[idx], dtype=np.uint8)).to(dev))
+            return arrs
+
+        Xtr, Xva = to_dev(tr_idx), to_dev(va_idx)
+        ntr, nva = len(tr_idx), len(va_idx)
+        bs = self.batch_size
+        world, rank = dist.world_size(), dist.rank()
+        hooks = [self._hook_save_weights, self._hook_save_history, EarlyStopping(self.patience)]
+        best_train, best_valid = np.inf, np.inf
+        first_epoch = len(self.train_history_)
+        if self.verbose:
+            print('  epoch    trn loss    val loss    trn/val    valid acc  dur')
+            print('-------  ----------  ----------  ---------  -----------  -----')
+        try:
+            for ep in range(epochs or self.max_epochs):
+                t0 = time.time()
+                losses = []
+                starts = list(range(0, ntr, bs))
+                for step, (lo, active) in enumerate(dist.shard_steps(starts, world, rank)):
+                    loss = None
+                    if active:
+                        hi = min(ntr, lo + bs)
+                        self._step += 1
+                        loss = h.train_step(Xtr[0][lo:hi], Xtr[1][lo:hi], Xtr[2][lo:hi], Xtr[3][lo:hi], Xtr[4][lo:hi],
+                                            hi - lo, seed=(self.seed << 32) + self._step * 131 + rank, stream=stream)
+                    scale = dist.allreduce_grads(h, active, stream, n_active=dist.active_ranks(len(starts), step, world))
+                    h.adam_apply(lr=self.update_learning_rate, grad_scale=scale, stream=stream)
+                    if loss is not None:
+                        losses.append(loss)
+                self._dev_newer = True
+                dist.sync_params(h)            # reconcile per-rank BN running statistics (no-op on one GPU)
+                vloss, vcorrect = 0.0, 0
+                for lo in range(0, nva, bs):
+                    hi = min(nva, lo + bs)
+                    ls, nc = h.eval_batch(Xva[0][lo:hi], Xva[1][lo:hi], Xva[2][lo:hi], Xva[3][lo:hi], Xva[4][lo:hi],
+                                          hi - lo, stream=stream)
+                    vloss += ls
+                    vcorrect += nc
+                train_loss = dist.mean_scalar(float(np.mean(losses)) if losses else 0.0, len(losses))
+                valid_loss = vloss / nva if nva else 0.0
+                valid_acc = vcorrect / nva if nva else 0.0
+                best_train = min(best_train, train_loss)
+                best_valid = min(best_valid, valid_loss)
+                info = {'epoch': first_epoch + ep + 1, 'train_loss': train_loss, 'train_loss_best': best_train == train_loss,
+                        'valid_loss': valid_loss, 'valid_loss_best': best_valid == valid_loss,
+                        'valid_accuracy': valid_acc, 'dur': time.time() - t0}
+                self.train_history_.append(info)
+                if self.verbose:
+                    print('{:>7}  {:>10.5f}  {:>10.5f}  {:>9.5f}  {:>11.5f}  {:.2f}s'.format(
+                        info['epoch'], train_loss, valid_loss, train_loss / valid_loss if valid_loss else 0.0,
+                        valid_acc, info['dur']))
+                for hook in hooks:
+                    hook(self, self.train_history_)
+        except StopIteration:
+            pass
+        return self
+
+    # hooks (nets.py:154-156, 238-242)
+    def _hook_save_weights(self, net, history):
+        from . import dist
+        if self.weights_file and history[-1]['valid_loss_best'] and dist.rank() == 0:
+            self.save_params_to(self.weights_file)
+
+    def _hook_save_history(self, net, history):
+        from . import dist
+        if self.history_file and dist.rank() == 0:
+            base = self.history_file[:-4] if self.history_file.endswith('.pkl') else self.history_file
+            with open(base + '.json', 'w') as f:
+                json.dump([{k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in r.items()} for r in history], f, indent=0)
+
+
+def build_model(weights_path, options):
+    """
+    Build the CNN model and return the net object (nets.py:127-255).
+      weights_path: folder that holds <experiment>/<experiment>.{f32,json} (or the reference's .pkl)
+      options: experiment, net_verbose, train_split, max_epochs, patience, patch_size, load_weights
+               (+ batch_size, device - see module docstring)
+    """
+    name = options['experiment']
+    folder = os.path.join(weights_path, name)
+    os.makedirs(folder, exist_ok=True)                       # nets.py:140-143
+    net_weights = os.path.join(folder, name + '.pkl')        # same stem as the reference; extension is replaced
+    net_history = os.path.join(folder, name + '_history.pkl')
+    ps = options['patch_size'][0] if isinstance(options['patch_size'], (list, tuple)) else int(options['patch_size'])
+    if ps != 32:
+        raise ValueError('the tri-planar net is built for 32x32 patches (patch_size=%r)' % (options['patch_size'],))
+    net = Net(weights_file=net_weights, history_file=net_history,
+              max_epochs=options['max_epochs'], patience=options['patience'], eval_size=options['train_split'],
+              batch_size=options.get('batch_size') or 128, verbose=options['net_verbose'],
+              device=options.get('device'))
+    if is_true(options['load_weights']):
+        if net.verbose:
+            print("    --> loading weights from ", net_weights)
+        net.load_params_from(net_weights)                    # raises IOError / ValueError (reference: silent)
+    return net

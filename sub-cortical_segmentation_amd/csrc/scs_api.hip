@@ -1,0 +1,553 @@
+// libscs - C ABI (include/scs.h) and the inference pipeline of the tri-planar CNN on gfx950.
+//
+// Inference per chunk of patches (all launches on the caller's stream):
+//   conv1+conv2+pool1 (fused, LDS-resident conv1 output)        nets.py:171-173
+//   conv3                                                         nets.py:174
+//   conv4+pool2                                                   nets.py:175-176
+//   conv5                                                         nets.py:177
+//   d1 x3 -> concat [n][540]                                      nets.py:179, 215
+//   FC1 -> [n][556] (+ atlas columns 540..554)                    nets.py:217, 222-224
+//   fc_2 -> [n][272]                                              nets.py:227
+//   out_layer + softmax + argmax                                  nets.py:231; base.py:425-438
+// Dropout layers are identity at inference, PReLU after ReLU is the identity for any alpha.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "conv_mfma.h"
+#include "gemm_mfma.h"
+#include "scs_ctx.h"
+
+namespace scs {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ----------------------------------------------------------------------------- layer configurations
+using CfgConv12 = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 912>;
+using CfgConv12V = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_VOLUME, 912>;
+using CfgConv3 = ConvCfg<20, 40, 14, 4, EPI_BIAS_RELU, SRC_NCHW, 208>;
+using CfgConv4 = ConvCfg<40, 40, 12, 4, EPI_BIAS_RELU_POOL, SRC_NCHW, 144>;
+using CfgConv5 = ConvCfg<40, 60, 5, 16, EPI_BIAS_RELU, SRC_NCHW, 27>;
+
+// ----------------------------------------------------------------------------- packing kernels
+// conv i (Cin >= 4): Wp[c4][tap][kk][n] = W[n][4*c4+kk][2-dy][2-dx] * scale[n]  (true conv -> correlation)
+__global__ void pack_conv_kernel(const float* __restrict__ W, const float* __restrict__ bn, int cin, int cout,
+                                 int ns, int fold, float* __restrict__ wp, float* __restrict__ bias) {
+    const int total = (cin / 4) * 36 * ns;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int n = e % ns;
+        int r = e / ns;
+        const int kk = r & 3; r >>= 2;
+        const int tap = r % 9, c4 = r / 9;
+        float v = 0.f;
+        if (n < cout) {
+            const int c = c4 * 4 + kk, dy = tap / 3, dx = tap % 3;
+            v = W[((n * cin + c) * 3 + (2 - dy)) * 3 + (2 - dx)];
+            if (fold) v *= bn[cout + n] * bn[3 * cout + n];          // gamma * inv_std
+        }
+        wp[e] = v;
+    }
+    const int nb = n_tiles(cout) * 16;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < nb; n += gridDim.x * blockDim.x) {
+        float b = 0.f;
+        if (fold && n < cout) b = bn[n] - bn[2 * cout + n] * bn[cout + n] * bn[3 * cout + n];   // beta - mean*scale
+        bias[n] = b;
+    }
+}
+
+// conv1: w1[tap][c] (20 channels), b1[32]
+__global__ void pack_conv1_kernel(const float* __restrict__ W, const float* __restrict__ bn, int fold,
+                                  float* __restrict__ w1, float* __restrict__ b1) {
+    const int t = threadIdx.x;
+    if (t < 180) {
+        const int tap = t / 20, c = t % 20, dy = tap / 3, dx = tap % 3;
+        float v = W[(c * 3 + (2 - dy)) * 3 + (2 - dx)];
+        if (fold) v *= bn[20 + c] * bn[60 + c];
+        w1[t] = v;
+    }
+    if (t < 32) {
+        float b = 0.f;
+        if (fold && t < 20) b = bn[t] - bn[40 + t] * bn[20 + t] * bn[60 + t];
+        b1[t] = b;
+    }
+}
+
+// dense: Wp[k][n] over [K4][NS] zero padded, bias padded to NS
+__global__ void pack_dense_kernel(const float* __restrict__ W, const float* __restrict__ b, int K, int N, int K4,
+                                  int NS, float* __restrict__ wp, float* __restrict__ bp) {
+    const int total = K4 * NS;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int n = e % NS, k = e / NS;
+        wp[e] = (k < K && n < N) ? W[(size_t)k * N + n] : 0.f;
+    }
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < NS; n += gridDim.x * blockDim.x) bp[n] = n < N ? b[n] : 0.f;
+}
+
+// ----------------------------------------------------------------------------- small kernels of the head
+// atlas -> columns 540..554 of the FC1 output rows (ConcatLayer elem_channels2, nets.py:224); column 555 = 0
+__global__ void atlas_concat_kernel(const float* __restrict__ atlas, float* __restrict__ fc1, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * 16) return;
+    const int row = e >> 4, c = e & 15;
+    fc1[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? atlas[(size_t)row * 15 + c] : 0.f;
+}
+
+// same from the 4-D prior volume at the patch centres, with the zero-row -> background rule (base.py:388-394)
+__global__ void atlas_gather_kernel(const float* __restrict__ atlas4d, const int32_t* __restrict__ centers,
+                                    int dx, int dy, int dz, float* __restrict__ fc1, int n) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int x = centers[row * 3], y = centers[row * 3 + 1], z = centers[row * 3 + 2];
+    const float* src = atlas4d + (((size_t)x * dy + y) * dz + z) * 15;
+    float v[15], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) { v[c] = src[c]; s += v[c]; }
+    if (s == 0.f) v[14] = 1.f;
+    float* dst = fc1 + (size_t)row * kFC1ld + kFC1;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) dst[c] = v[c];
+    dst[15] = 0.f;
+}
+
+// out_layer (270 -> 15) + softmax + argmax, one lane per patch row (4 050 MACs per row: 0.02 % of the net).
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ fc2, const float* __restrict__ wout /*[270][16]*/,
+                                                      const float* __restrict__ bout /*[16]*/, int n,
+                                                      float* __restrict__ logits /*[n][16] or null*/,
+                                                      float* __restrict__ probs /*[n][15] or null*/,
+                                                      int32_t* __restrict__ labels /*[n] or null*/) {
+    __shared__ __attribute__((aligned(16))) float s_w[kFC2 * 16 + 16];
+    for (int e = threadIdx.x; e < kFC2 * 16; e += blockDim.x) s_w[e] = wout[e];
+    if (threadIdx.x < 16) s_w[kFC2 * 16 + threadIdx.x] = bout[threadIdx.x];
+    __syncthreads();
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    float z[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) z[c] = s_w[kFC2 * 16 + c];
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(fc2 + (size_t)row * kFC2ld);
+    for (int k4 = 0; k4 < kFC2ld / 4; ++k4) {
+        const float4 xv = x4[k4];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k4 * 4 + u;
+            if (k < kFC2) {
+#pragma unroll
+                for (int c = 0; c < 15; ++c) z[c] = fmaf(xs[u], s_w[k * 16 + c], z[c]);
+            }
+        }
+    }
+    float mx = z[0];
+#pragma unroll
+    for (int c = 1; c < 15; ++c) mx = fmaxf(mx, z[c]);
+    float p[15], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) { p[c] = expf(z[c] - mx); s += p[c]; }
+    const float inv = 1.f / s;
+    int best = 0;
+    float bp = -1.f;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        p[c] *= inv;
+        if (p[c] > bp) { bp = p[c]; best = c; }       // strict '>' keeps the first maximum (np.argmax)
+    }
+    if (logits) {
+#pragma unroll
+        for (int c = 0; c < 15; ++c) logits[(size_t)row * 16 + c] = z[c];
+        logits[(size_t)row * 16 + 15] = 0.f;
+    }
+    if (probs) {
+#pragma unroll
+        for (int c = 0; c < 15; ++c) probs[(size_t)row * 15 + c] = p[c];
+    }
+    if (labels) labels[row] = best;
+}
+
+// ----------------------------------------------------------------------------- packed-weights arena
+static size_t align64(size_t f) { return (f + 63) / 64 * 64; }
+
+static int alloc_packed(scs_ctx* h) {
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += align64(floats); return o; };
+    size_t o_c1w[kTowers], o_c1b[kTowers], o_cw[kTowers][kConvs], o_cb[kTowers][kConvs], o_d1w[kTowers], o_d1b[kTowers];
+    for (int t = 0; t < kTowers; ++t) {
+        o_c1w[t] = take(180); o_c1b[t] = take(32);
+        for (int i = 1; i < kConvs; ++i) { o_cw[t][i] = take(conv_pack_floats(i)); o_cb[t][i] = take(n_tiles(kCout[i]) * 16); }
+        o_d1w[t] = take((size_t)kFlat * gemm_ns(kD1)); o_d1b[t] = take(gemm_ns(kD1));
+    }
+    const size_t o_f1w = take((size_t)kFC1 * gemm_ns(kFC1)), o_f1b = take(gemm_ns(kFC1));
+    const size_t o_f2w = take((size_t)kFC1ld * gemm_ns(kFC2)), o_f2b = take(gemm_ns(kFC2));
+    const size_t o_ow = take(kFC2 * 16), o_ob = take(16);
+    h->packed_floats = off;
+    SCS_HIP(hipMalloc(&h->packed, off * sizeof(float)));
+    float* b = h->packed;
+    for (int t = 0; t < kTowers; ++t) {
+        h->pk.conv1w[t] = b + o_c1w[t]; h->pk.conv1b[t] = b + o_c1b[t];
+        for (int i = 1; i < kConvs; ++i) { h->pk.convw[t][i] = b + o_cw[t][i]; h->pk.convb[t][i] = b + o_cb[t][i]; }
+        h->pk.d1w[t] = b + o_d1w[t]; h->pk.d1b[t] = b + o_d1b[t];
+    }
+    h->pk.fc1w = b + o_f1w; h->pk.fc1b = b + o_f1b;
+    h->pk.fc2w = b + o_f2w; h->pk.fc2b = b + o_f2b;
+    h->pk.outw = b + o_ow; h->pk.outb = b + o_ob;
+    return SCS_OK;
+}
+
+// rebuild the inference operands from the parameter arena (BN folded, flipped, fragment order)
+int repack_inference(scs_ctx* h, hipStream_t st) {
+    const float* P = h->params;
+    constexpr HeadOff H = head_off();
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        hipLaunchKernelGGL(pack_conv1_kernel, dim3(1), dim3(256), 0, st, P + T.convW[0], P + T.bn[0], 1,
+                           h->pk.conv1w[t], h->pk.conv1b[t]);
+        for (int i = 1; i < kConvs; ++i)
+            hipLaunchKernelGGL(pack_conv_kernel, dim3(32), dim3(256), 0, st, P + T.convW[i], P + T.bn[i], kCin[i],
+                               kCout[i], n_stride(kCout[i]), 1, h->pk.convw[t][i], h->pk.convb[t][i]);
+        hipLaunchKernelGGL(pack_dense_kernel, dim3(64), dim3(256), 0, st, P + T.d1W, P + T.d1b, kFlat, kD1, kFlat,
+                           gemm_ns(kD1), h->pk.d1w[t], h->pk.d1b[t]);
+    }
+    hipLaunchKernelGGL(pack_dense_kernel, dim3(128), dim3(256), 0, st, P + H.fc1W, P + H.fc1b, kFC1, kFC1, kFC1,
+                       gemm_ns(kFC1), h->pk.fc1w, h->pk.fc1b);
+    hipLaunchKernelGGL(pack_dense_kernel, dim3(128), dim3(256), 0, st, P + H.fc2W, P + H.fc2b, kFC1 + kAtlas, kFC2,
+                       kFC1ld, gemm_ns(kFC2), h->pk.fc2w, h->pk.fc2b);
+    hipLaunchKernelGGL(pack_dense_kernel, dim3(8), dim3(256), 0, st, P + H.outW, P + H.outb, kFC2, kClasses, kFC2, 16,
+                       h->pk.outw, h->pk.outb);
+    SCS_HIP(hipGetLastError());
+    return SCS_OK;
+}
+
+// ----------------------------------------------------------------------------- workspace
+int ensure_workspace(scs_ctx* h) {
+    if (h->ws && h->ws_chunk == h->chunk) return SCS_OK;
+    if (h->ws) { SCS_HIP(hipFree(h->ws)); h->ws = nullptr; }
+    if (h->stage_dev) { SCS_HIP(hipFree(h->stage_dev)); h->stage_dev = nullptr; }
+    const size_t c = (size_t)h->chunk;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += align64(floats); return o; };
+    size_t o1[kTowers], o3[kTowers], o2[kTowers], o5[kTowers];
+    for (int t = 0; t < kTowers; ++t) {
+        o1[t] = take(c * 20 * 196); o3[t] = take(c * 40 * 144); o2[t] = take(c * 40 * 25); o5[t] = take(c * kFlat);
+    }
+    const size_t of = take(c * kFlat), o_fc1 = take(c * kFC1ld), o_fc2 = take(c * kFC2ld), o_lg = take(c * 16);
+    SCS_HIP(hipMalloc(&h->ws, off * sizeof(float)));
+    for (int t = 0; t < kTowers; ++t) {
+        h->a_pool1[t] = h->ws + o1[t]; h->a_conv3[t] = h->ws + o3[t];
+        h->a_pool2[t] = h->ws + o2[t]; h->a_conv5[t] = h->ws + o5[t];
+    }
+    h->a_feat = h->ws + of; h->a_fc1 = h->ws + o_fc1; h->a_fc2 = h->ws + o_fc2; h->a_logits = h->ws + o_lg;
+    h->ws_chunk = h->chunk;
+    h->last_n = 0;
+    return SCS_OK;
+}
+
+// ----------------------------------------------------------------------------- one chunk of the forward
+int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
+                  const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
+                  int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev) {
+    const PackedNet& pk = h->pk;
+    auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
+    mark(0);
+    ConvArgs a{};
+    a.n = n;
+    // conv1 + conv2 + pool1
+    for (int t = 0; t < kTowers; ++t) {
+        a.w[t] = pk.convw[t][1]; a.bias[t] = pk.convb[t][1]; a.out[t] = h->a_pool1[t];
+        a.w1[t] = pk.conv1w[t]; a.b1[t] = pk.conv1b[t];
+    }
+    if (vol) {
+        a.in[0] = a.in[1] = a.in[2] = vol;
+        a.centers = centers; a.dimx = dx; a.dimy = dy; a.dimz = dz;
+        conv_launch<CfgConv12V>(a, st);
+    } else {
+        a.in[0] = ax; a.in[1] = co; a.in[2] = sa;
+        conv_launch<CfgConv12>(a, st);
+    }
+    mark(1);
+    // conv3
+    for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_pool1[t]; a.w[t] = pk.convw[t][2]; a.bias[t] = pk.convb[t][2]; a.out[t] = h->a_conv3[t]; }
+    conv_launch<CfgConv3>(a, st);
+    mark(2);
+    // conv4 + pool2
+    for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_conv3[t]; a.w[t] = pk.convw[t][3]; a.bias[t] = pk.convb[t][3]; a.out[t] = h->a_pool2[t]; }
+    conv_launch<CfgConv4>(a, st);
+    mark(3);
+    // conv5
+    for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_pool2[t]; a.w[t] = pk.convw[t][4]; a.bias[t] = pk.convb[t][4]; a.out[t] = h->a_conv5[t]; }
+    conv_launch<CfgConv5>(a, st);
+    mark(4);
+    // d1 x3 -> feat[:, 180 t : 180 t + 180]
+    GemmArgs g{};
+    g.M = n; g.K4 = kFlat; g.N = kD1; g.relu = 1;
+    for (int t = 0; t < kTowers; ++t) g.p[t] = GemmProblem{h->a_conv5[t], kFlat, pk.d1w[t], gemm_ns(kD1), pk.d1b[t], h->a_feat + t * kD1, kFlat};
+    gemm_launch(g, kTowers, st);
+    mark(5);
+    // FC1 -> fc1[:, 0:540]; atlas -> fc1[:, 540:556]
+    g.K4 = kFC1; g.N = kFC1;
+    g.p[0] = GemmProblem{h->a_feat, kFlat, pk.fc1w, gemm_ns(kFC1), pk.fc1b, h->a_fc1, kFC1ld};
+    gemm_launch(g, 1, st);
+    if (vol)
+        hipLaunchKernelGGL(atlas_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->a_fc1, n);
+    else
+        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, h->a_fc1, n);
+    mark(6);
+    // fc_2
+    g.K4 = kFC1ld; g.N = kFC2;
+    g.p[0] = GemmProblem{h->a_fc1, kFC1ld, pk.fc2w, gemm_ns(kFC2), pk.fc2b, h->a_fc2, kFC2ld};
+    gemm_launch(g, 1, st);
+    mark(7);
+    // out + softmax + argmax
+    hipLaunchKernelGGL(head_out_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->a_fc2, pk.outw, pk.outb, n,
+                       h->a_logits, probs, labels);
+    mark(8);
+    SCS_HIP(hipGetLastError());
+    h->last_n = n;
+    return SCS_OK;
+}
+
+static int set_kernel_attrs() {
+    SCS_HIP(conv_set_attr<CfgConv12>());
+    SCS_HIP(conv_set_attr<CfgConv12V>());
+    SCS_HIP(conv_set_attr<CfgConv3>());
+    SCS_HIP(conv_set_attr<CfgConv4>());
+    SCS_HIP(conv_set_attr<CfgConv5>());
+    SCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+    return SCS_OK;
+}
+
+}  // namespace scs
+
+using namespace scs;
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* scs_last_error(void) { return g_err; }
+int scs_abi_version(void) { return 1; }
+const char* scs_target_arch(void) { return "gfx950"; }
+
+int scs_create(int device, scs_handle* out) {
+    SCS_ARG(out != nullptr, "out handle is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    SCS_HIP(hipGetDeviceCount(&ndev));
+    SCS_ARG(device >= 0 && device < ndev, "device index out of range");
+    SCS_HIP(hipSetDevice(device));
+    scs_ctx* h = new (std::nothrow) scs_ctx();
+    SCS_ARG(h != nullptr, "out of host memory");
+    h->device = device;
+    int rc = set_kernel_attrs();
+    if (rc != SCS_OK) { delete h; return rc; }
+    const size_t bytes = (size_t)SCS_N_PARAMS * sizeof(float);
+    hipError_t e = hipMalloc(&h->params, bytes);
+    if (e == hipSuccess) e = hipMalloc(&h->grads, bytes);
+    if (e == hipSuccess) e = hipMalloc(&h->adam_m, bytes);
+    if (e == hipSuccess) e = hipMalloc(&h->adam_v, bytes);
+    if (e != hipSuccess) { set_error("hipMalloc of the arenas failed: %s", hipGetErrorString(e)); scs_destroy(h); return SCS_ERR_HIP; }
+    (void)hipMemset(h->grads, 0, bytes);
+    (void)hipMemset(h->adam_m, 0, bytes);
+    (void)hipMemset(h->adam_v, 0, bytes);
+    rc = alloc_packed(h);
+    if (rc != SCS_OK) { scs_destroy(h); return rc; }
+    *out = h;
+    return SCS_OK;
+}
+
+int scs_destroy(scs_handle h) {
+    if (!h) return SCS_OK;
+    (void)hipSetDevice(h->device);
+    train_free(h);
+    if (h->params) (void)hipFree(h->params);
+    if (h->grads) (void)hipFree(h->grads);
+    if (h->adam_m) (void)hipFree(h->adam_m);
+    if (h->adam_v) (void)hipFree(h->adam_v);
+    if (h->packed) (void)hipFree(h->packed);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->stage_dev) (void)hipFree(h->stage_dev);
+    delete h;
+    return SCS_OK;
+}
+
+int scs_set_params(scs_handle h, const float* host_arena, size_t n) {
+    SCS_ARG(h && host_arena, "null handle or arena");
+    SCS_ARG(n == (size_t)SCS_N_PARAMS, "arena must hold SCS_N_PARAMS floats");
+    SCS_HIP(hipSetDevice(h->device));
+    SCS_HIP(hipMemcpy(h->params, host_arena, n * sizeof(float), hipMemcpyHostToDevice));
+    SCS_HIP(hipMemset(h->adam_m, 0, n * sizeof(float)));
+    SCS_HIP(hipMemset(h->adam_v, 0, n * sizeof(float)));
+    h->adam_t = 0;
+    int rc = repack_inference(h, nullptr);
+    if (rc != SCS_OK) return rc;
+    SCS_HIP(hipDeviceSynchronize());
+    h->has_params = true;
+    return SCS_OK;
+}
+
+int scs_get_params(scs_handle h, float* host_arena, size_t n) {
+    SCS_ARG(h && host_arena, "null handle or arena");
+    SCS_ARG(n == (size_t)SCS_N_PARAMS, "arena must hold SCS_N_PARAMS floats");
+    if (!h->has_params) { set_error("no parameters loaded"); return SCS_ERR_STATE; }
+    SCS_HIP(hipSetDevice(h->device));
+    SCS_HIP(hipDeviceSynchronize());
+    SCS_HIP(hipMemcpy(host_arena, h->params, n * sizeof(float), hipMemcpyDeviceToHost));
+    return SCS_OK;
+}
+
+int scs_set_chunk(scs_handle h, int patches_per_chunk) {
+    if (!h) return SCS_ERR_ARG;
+    if (patches_per_chunk >= 16 && patches_per_chunk <= (1 << 20)) h->chunk = (patches_per_chunk + 15) / 16 * 16;
+    return h->chunk;
+}
+
+static int forward_common(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas,
+                          const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
+                          int64_t n, float* probs, int32_t* labels, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(n >= 0, "n < 0");
+    if (!h->has_params) { set_error("scs_forward before scs_set_params"); return SCS_ERR_STATE; }
+    if (n == 0) return SCS_OK;
+    SCS_HIP(hipSetDevice(h->device));
+    int rc = ensure_workspace(h);
+    if (rc != SCS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t s = 0; s < n; s += h->chunk) {
+        const int m = (int)((n - s < h->chunk) ? (n - s) : h->chunk);
+        rc = forward_chunk(h, ax ? ax + s * 1024 : nullptr, co ? co + s * 1024 : nullptr, sa ? sa + s * 1024 : nullptr,
+                           atlas ? atlas + s * 15 : nullptr, vol, dx, dy, dz, centers ? centers + s * 3 : nullptr, atlas4d,
+                           m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, nullptr);
+        if (rc != SCS_OK) return rc;
+    }
+    return SCS_OK;
+}
+
+int scs_forward(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, int64_t n,
+                float* probs, int32_t* labels, void* stream) {
+    SCS_ARG(n == 0 || (ax && co && sa && atlas), "null input pointer");
+    return forward_common(h, ax, co, sa, atlas, nullptr, 0, 0, 0, nullptr, nullptr, n, probs, labels, stream);
+}
+
+int scs_forward_volume(scs_handle h, const float* vol, int dx, int dy, int dz, const int32_t* centers,
+                       const float* atlas4d, int64_t n, float* probs, int32_t* labels, void* stream) {
+    SCS_ARG(n == 0 || (vol && centers && atlas4d), "null input pointer");
+    SCS_ARG(dx > 0 && dy > 0 && dz > 0, "volume dims must be positive");
+    return forward_common(h, nullptr, nullptr, nullptr, nullptr, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, stream);
+}
+
+int scs_forward_host(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, int64_t n,
+                     float* probs, int32_t* labels) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(n >= 0, "n < 0");
+    SCS_ARG(n == 0 || (ax && co && sa && atlas), "null input pointer");
+    if (!h->has_params) { set_error("scs_forward_host before scs_set_params"); return SCS_ERR_STATE; }
+    if (n == 0) return SCS_OK;
+    SCS_HIP(hipSetDevice(h->device));
+    int rc = ensure_workspace(h);
+    if (rc != SCS_OK) return rc;
+    const size_t c = (size_t)h->chunk;
+    const size_t per = 3 * 1024 + 15 + 15 + 1;                  // views, atlas, probs, label
+    if (!h->stage_dev || h->stage_floats < c * per) {
+        if (h->stage_dev) SCS_HIP(hipFree(h->stage_dev));
+        SCS_HIP(hipMalloc(&h->stage_dev, c * per * sizeof(float)));
+        h->stage_floats = c * per;
+    }
+    float* d_ax = h->stage_dev; float* d_co = d_ax + c * 1024; float* d_sa = d_co + c * 1024;
+    float* d_at = d_sa + c * 1024; float* d_pr = d_at + c * 15; int32_t* d_lb = reinterpret_cast<int32_t*>(d_pr + c * 15);
+    for (int64_t s = 0; s < n; s += h->chunk) {
+        const size_t m = (size_t)((n - s < h->chunk) ? (n - s) : h->chunk);
+        SCS_HIP(hipMemcpyAsync(d_ax, ax + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
+        SCS_HIP(hipMemcpyAsync(d_co, co + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
+        SCS_HIP(hipMemcpyAsync(d_sa, sa + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
+        SCS_HIP(hipMemcpyAsync(d_at, atlas + s * 15, m * 60, hipMemcpyHostToDevice, nullptr));
+        rc = forward_chunk(h, d_ax, d_co, d_sa, d_at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d_pr, d_lb, nullptr, nullptr);
+        if (rc != SCS_OK) return rc;
+        if (probs) SCS_HIP(hipMemcpyAsync(probs + s * 15, d_pr, m * 60, hipMemcpyDeviceToHost, nullptr));
+        if (labels) SCS_HIP(hipMemcpyAsync(labels + s, d_lb, m * 4, hipMemcpyDeviceToHost, nullptr));
+        SCS_HIP(hipStreamSynchronize(nullptr));
+    }
+    return SCS_OK;
+}
+
+int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas,
+                         int64_t n, float* probs, int32_t* labels, void* stream, float* stage_ms, int* launches) {
+    SCS_ARG(h && stage_ms && launches, "null pointer");
+    SCS_ARG(n > 0 && ax && co && sa && atlas, "null input pointer or n <= 0");
+    if (!h->has_params) { set_error("scs_forward_profiled before scs_set_params"); return SCS_ERR_STATE; }
+    SCS_HIP(hipSetDevice(h->device));
+    int rc = ensure_workspace(h);
+    if (rc != SCS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunks = (int)((n + h->chunk - 1) / h->chunk);
+    std::vector<hipEvent_t> ev((size_t)nchunks * 9);
+    for (auto& e : ev) SCS_HIP(hipEventCreate(&e));
+    int c = 0;
+    for (int64_t s = 0; s < n; s += h->chunk, ++c) {
+        const int m = (int)((n - s < h->chunk) ? (n - s) : h->chunk);
+        rc = forward_chunk(h, ax + s * 1024, co + s * 1024, sa + s * 1024, atlas + s * 15, nullptr, 0, 0, 0, nullptr, nullptr,
+                           m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, &ev[(size_t)c * 9]);
+        if (rc != SCS_OK) break;
+    }
+    if (rc == SCS_OK) {
+        SCS_HIP(hipStreamSynchronize(st));
+        for (int i = 0; i < 8; ++i) stage_ms[i] = 0.f;
+        for (int k = 0; k < nchunks; ++k)
+            for (int i = 0; i < 8; ++i) {
+                float ms = 0.f;
+                SCS_HIP(hipEventElapsedTime(&ms, ev[(size_t)k * 9 + i], ev[(size_t)k * 9 + i + 1]));
+                stage_ms[i] += ms;
+            }
+        *launches = nchunks;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
+    SCS_ARG(h && host_out, "null pointer");
+    if (!h->ws || h->last_n <= 0) { set_error("no forward has run"); return SCS_ERR_STATE; }
+    SCS_HIP(hipSetDevice(h->device));
+    SCS_HIP(hipDeviceSynchronize());
+    const size_t n = (size_t)h->last_n;
+    size_t per = 0;
+    float* const* tow = nullptr;
+    const float* single = nullptr;
+    switch (which) {
+        case 0: per = 20 * 196; tow = h->a_pool1; break;
+        case 1: per = 40 * 144; tow = h->a_conv3; break;
+        case 2: per = 40 * 25; tow = h->a_pool2; break;
+        case 3: per = kFlat; tow = h->a_conv5; break;
+        case 4: per = kFlat; single = h->a_feat; break;
+        case 5: per = kFC1ld; single = h->a_fc1; break;
+        case 6: per = kFC2ld; single = h->a_fc2; break;
+        case 7: per = 16; single = h->a_logits; break;
+        default: SCS_ARG(false, "unknown activation id");
+    }
+    if (tow) {
+        SCS_ARG(count == 3 * n * per, "count does not match 3*n*per-patch size");
+        for (int t = 0; t < kTowers; ++t)
+            SCS_HIP(hipMemcpy(host_out + t * n * per, tow[t], n * per * sizeof(float), hipMemcpyDeviceToHost));
+    } else {
+        SCS_ARG(count == n * per, "count does not match n*row size");
+        SCS_HIP(hipMemcpy(host_out, single, n * per * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return SCS_OK;
+}
+
+int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n) {
+    SCS_ARG(h && dev_ptr && n, "null pointer");
+    *dev_ptr = h->params; *n = SCS_N_PARAMS;
+    return SCS_OK;
+}
+int scs_grad_arena(scs_handle h, float** dev_ptr, size_t* n) {
+    SCS_ARG(h && dev_ptr && n, "null pointer");
+    *dev_ptr = h->grads; *n = SCS_N_PARAMS;
+    return SCS_OK;
+}
+
+}  // extern "C"

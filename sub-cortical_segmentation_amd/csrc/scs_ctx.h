@@ -1,0 +1,50 @@
+// Per-instance state of libscs (opaque to callers: include/scs.h).
+#pragma once
+#include "scs_common.h"
+
+struct scs_ctx {
+    int device = 0;
+    bool has_params = false;
+
+    // Lasagne-layout arenas (SCS_N_PARAMS floats each)
+    float* params = nullptr;
+    float* grads = nullptr;
+    float* adam_m = nullptr;
+    float* adam_v = nullptr;
+    long adam_t = 0;
+
+    // packed inference operands
+    float* packed = nullptr;
+    size_t packed_floats = 0;
+    scs::PackedNet pk{};
+
+    // forward workspace (one chunk)
+    int chunk = 4096;
+    int ws_chunk = 0;              // chunk the workspace was allocated for
+    float* ws = nullptr;
+    float* a_pool1[scs::kTowers]{};   // [chunk][20][14][14]
+    float* a_conv3[scs::kTowers]{};   // [chunk][40][12][12]
+    float* a_pool2[scs::kTowers]{};   // [chunk][40][5][5]
+    float* a_conv5[scs::kTowers]{};   // [chunk][540]
+    float* a_feat = nullptr;          // [chunk][540]
+    float* a_fc1 = nullptr;           // [chunk][556]
+    float* a_fc2 = nullptr;           // [chunk][272]
+    float* a_logits = nullptr;        // [chunk][16]
+    int last_n = 0;
+
+    // host staging for the *_host entry points
+    float* stage_dev = nullptr;       // [chunk] x (3*1024 + 15 + 15) floats + labels
+    size_t stage_floats = 0;
+
+    // training state (scs_train.hip)
+    struct TrainWs* tws = nullptr;
+};
+
+namespace scs {
+int ensure_workspace(scs_ctx* h);
+int repack_inference(scs_ctx* h, hipStream_t st);
+int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
+                  const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
+                  int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev);
+void train_free(scs_ctx* h);
+}

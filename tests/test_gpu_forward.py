@@ -1,0 +1,170 @@
+"""Parity of the HIP forward path (through the C ABI) with the float64 oracle - needs an MI355X.
+
+Tolerances (BASELINE.json north_star): softmax probabilities within 1e-4 absolute of the oracle; argmax labels
+identical wherever the oracle's own top-2 margin exceeds float32 noise (1e-5) and, for closer calls, one of the
+oracle's top two classes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+PROB_TOL = 1e-4
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to('cuda:0', dtype=dtype)
+
+
+def run_forward(handle, ax, co, sa, at, want_probs=True):
+    n = ax.shape[0]
+    probs = torch.full((n, 15), -7.0, device='cuda:0') if want_probs else None
+    labels = torch.full((n,), -7, dtype=torch.int32, device='cuda:0')
+    handle.forward(dev(ax), dev(co), dev(sa), dev(at), n, probs, labels, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return (probs.cpu().numpy() if want_probs else None), labels.cpu().numpy()
+
+
+def check_labels(labels, ref_probs):
+    srt = np.sort(ref_probs, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    ref = ref_probs.argmax(1)
+    clear = margin > 1e-5
+    assert np.array_equal(labels[clear], ref[clear])
+    top2 = np.argsort(ref_probs, axis=1)[:, -2:]
+    assert all(l in t for l, t in zip(labels[~clear], top2[~clear]))
+
+
+@pytest.mark.parametrize('name', ['g1_random.npz', 'g2_volume.npz', 'g3_classes.npz', 'g4_ties.npz'])
+def test_golden_sets(handle, name):
+    g = gold(name)
+    probs, labels = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+    assert np.isfinite(probs).all()
+    err = np.abs(probs - g['probs']).max()
+    assert err < PROB_TOL, 'max |p - p_oracle| = %g' % err
+    assert np.abs(probs.sum(1) - 1).max() < 1e-5
+    check_labels(labels, g['probs'])
+    # labels are the argmax of the returned float32 probabilities (nolearn predict = argmax(predict_proba))
+    assert np.array_equal(labels, probs.argmax(1))
+
+
+def test_per_layer_activations(handle, weights):
+    g = gold('g2_volume.npz')
+    n = 24
+    args = [g[k][:n] for k in ('ax', 'co', 'sa', 'atlas')]
+    tr = {}
+    O.forward(weights, *args, trace=tr)
+    run_forward(handle, *args)
+    towers = ('axial', 'coronal', 'saggital')
+
+    def close(got, ref, what):
+        scale = max(1.0, np.abs(ref).max())
+        err = np.abs(got - ref).max()
+        assert err <= 2e-5 * scale, '%s: max err %g (scale %g)' % (what, err, scale)
+
+    for which, key, per in ((0, 'pool1', 20 * 196), (1, 'conv3', 40 * 144), (2, 'pool2', 40 * 25), (3, 'conv5', 540)):
+        got = handle.get_activation(which, 3 * n * per).reshape(3, n, -1)
+        for t, tn in enumerate(towers):
+            close(got[t], tr['%s_%s' % (tn, key)].reshape(n, -1), '%s_%s' % (tn, key))
+    feat = handle.get_activation(4, n * 540).reshape(n, 540)
+    close(feat, np.concatenate([tr['%s_d1' % t] for t in towers], axis=1), 'd1 concat')
+    fc1 = handle.get_activation(5, n * 556).reshape(n, 556)
+    close(fc1[:, :540], tr['FC1'], 'FC1')
+    assert np.array_equal(fc1[:, 540:555], args[3]) and np.all(fc1[:, 555] == 0)
+    fc2 = handle.get_activation(6, n * 272).reshape(n, 272)
+    close(fc2[:, :270], tr['fc_2'], 'fc_2')
+    logits = handle.get_activation(7, n * 16).reshape(n, 16)
+    close(logits[:, :15], tr['logits'], 'logits')
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 5, 15, 16, 17, 63, 130])
+def test_ragged_batch_sizes(handle, n):
+    """Partial patch groups (conv3/4: 4 per workgroup, conv5: 16, GEMM: 128 rows) must not leak or drop rows."""
+    g = gold('g2_volume.npz')
+    args = [g[k][:n] for k in ('ax', 'co', 'sa', 'atlas')]
+    probs, labels = run_forward(handle, *args)
+    assert np.abs(probs - g['probs'][:n]).max() < PROB_TOL
+    check_labels(labels, g['probs'][:n])
+
+
+def test_chunking_is_invisible(handle):
+    g = gold('g2_volume.npz')
+    args = [g[k] for k in ('ax', 'co', 'sa', 'atlas')]
+    full, lab_full = run_forward(handle, *args)
+    old = handle.set_chunk(0)
+    try:
+        assert handle.set_chunk(48) == 48
+        part, lab_part = run_forward(handle, *args)          # 256 patches -> 5 full chunks + 16
+    finally:
+        handle.set_chunk(old)
+    assert np.array_equal(full, part) and np.array_equal(lab_full, lab_part)
+
+
+def test_empty_and_optional_outputs(handle):
+    g = gold('g1_random.npz')
+    handle.forward(None, None, None, None, 0, None, None, 0)                      # n = 0 is a no-op
+    _, labels = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'], want_probs=False)
+    check_labels(labels, g['probs'])
+
+
+def test_host_pointer_entry_matches_device_entry(handle):
+    g = gold('g1_random.npz')
+    probs, labels = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+    n = g['ax'].shape[0]
+    hp = np.empty((n, 15), np.float32)
+    hl = np.empty((n,), np.int32)
+    handle.forward_host(g['ax'], g['co'], g['sa'], g['atlas'], n, hp, hl)
+    assert np.array_equal(hp, probs) and np.array_equal(hl, labels)
+
+
+def test_gather_fused_volume_path_equals_patch_path(handle):
+    """scs_forward_volume cuts the same patches the literal get_patches restatement produced for g2 (border
+    centres included) and applies the zero-row atlas rule: results must equal the patch entry bit for bit."""
+    g = gold('g2_volume.npz')
+    from oracle import patches_ref as R
+    vol = R.zscore_inference(g['volume']).astype(np.float32)
+    probs, labels = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+    n = g['centers'].shape[0]
+    d_pr = torch.empty((n, 15), device='cuda:0')
+    d_lb = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+    handle.forward_volume(dev(vol), vol.shape, dev(g['centers'], torch.int32), dev(g['atlas4d']), n, d_pr, d_lb,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pr.cpu().numpy(), probs)
+    assert np.array_equal(d_lb.cpu().numpy(), labels)
+
+
+def test_full_size_properties(handle):
+    """BASELINE config 2 size (100 000 patches): size-independent properties - rows sum to 1, permutation
+    equivariance (a shuffled batch gives the shuffled result bit for bit), determinism across calls."""
+    from cnn_cort import synth
+    n = 100000
+    ax, co, sa, at = synth.patch_batch(n, seed=0)
+    d = [dev(a) for a in (ax, co, sa, at)]
+    st = torch.cuda.current_stream().cuda_stream
+    p1 = torch.empty((n, 15), device='cuda:0')
+    l1 = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+    handle.forward(*d, n, p1, l1, st)
+    perm = torch.randperm(n, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(1))
+    d2 = [a[perm].contiguous() for a in d]
+    p2 = torch.empty_like(p1)
+    l2 = torch.empty_like(l1)
+    handle.forward(*d2, n, p2, l2, st)
+    p3 = torch.empty_like(p1)
+    handle.forward(*d, n, p3, None, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(p1).all()
+    assert (p1.sum(1) - 1).abs().max().item() < 1e-5
+    assert torch.equal(p1[perm], p2) and torch.equal(l1[perm], l2)
+    assert torch.equal(p1, p3)
+    assert torch.equal(l1.long(), p1.argmax(1))
+    # spot-check a slice against the oracle
+    from cnn_cort import params as P
+    from conftest import WEIGHTS
+    idx = np.arange(0, n, n // 16)[:16]
+    ref = O.forward(P.load_params(WEIGHTS), ax[idx], co[idx], sa[idx], at[idx])
+    assert np.abs(p1.cpu().numpy()[idx] - ref).max() < PROB_TOL

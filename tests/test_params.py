@@ -1,0 +1,71 @@
+"""Parameter store: layer inventory, file formats, arena layout (CPU)."""
+import io
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from cnn_cort import params as P
+from conftest import WEIGHTS
+
+
+def test_layer_inventory_matches_shipped_weights(weights):
+    assert len(P.LAYER_SPEC) == 88
+    assert sum(1 for _, s in P.LAYER_SPEC if s) == 56
+    assert P.N_STORED == 883455
+    n_train = sum(int(np.prod(s)) for n, shapes in P.LAYER_SPEC for i, s in enumerate(shapes) if P.is_trainable(n, i))
+    assert n_train == 882375
+    assert list(weights.keys()) == [n for n, _ in P.LAYER_SPEC]
+    # BN inv_std strictly positive, spelling 'saggital' preserved
+    assert all((weights['%s_ch_conv%d_bn' % (t, i)][3] > 0).all() for t in P.TOWERS for i in range(1, 6))
+    assert 'saggital_d1' in weights
+
+
+def test_blob_roundtrip(tmp_path, weights):
+    p = P.save_params(str(tmp_path / 'w.pkl'), weights)     # '.pkl' stem is accepted, pair is written
+    assert p.endswith('w.f32') and os.path.exists(str(tmp_path / 'w.json'))
+    back = P.load_params(str(tmp_path / 'w.pkl'))
+    for k in weights:
+        for a, b in zip(weights[k], back[k]):
+            assert a.dtype == np.float32 and np.array_equal(a, b)
+    flat = P.params_to_flat(weights)
+    again = P.flat_to_params(flat)
+    assert all(np.array_equal(a, b) for k in weights for a, b in zip(weights[k], again[k]))
+    offs = P.flat_offsets()
+    off, shape = offs[('fc_2', 0)]
+    assert shape == (555, 270) and np.array_equal(flat[off:off + 555 * 270].reshape(shape), weights['fc_2'][0])
+
+
+def test_missing_and_mismatched_files_raise(tmp_path, weights):
+    with pytest.raises(IOError):
+        P.load_params(str(tmp_path / 'nothing.pkl'))
+    bad = {k: [a.copy() for a in v] for k, v in weights.items()}
+    bad['FC1'][0] = bad['FC1'][0][:, :-1]
+    with pytest.raises(ValueError):
+        P.check_params(bad)
+    with pytest.raises(ValueError):
+        P.flat_to_params(np.zeros(10, np.float32))
+
+
+def test_reference_pickle_loader_is_data_only(tmp_path):
+    # a python-2 style pickle of OrderedDict/ndarray loads; anything else is refused
+    from collections import OrderedDict
+    ok = tmp_path / 'ok.pkl'
+    with open(ok, 'wb') as f:
+        pickle.dump(OrderedDict(a=[np.arange(3, dtype=np.float32)]), f, protocol=2)
+    assert np.array_equal(P.read_reference_pickle(str(ok))['a'][0], [0, 1, 2])
+    evil = tmp_path / 'evil.pkl'
+    with open(evil, 'wb') as f:
+        pickle.dump(os.getcwd, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError):
+        P.read_reference_pickle(str(evil))
+
+
+def test_init_params_follow_lasagne_defaults():
+    p = P.init_params(3)
+    P.check_params(p)
+    assert np.all(p['axial_ch_conv2_bn'][1] == 1) and np.all(p['axial_ch_conv2_bn'][3] == 1)
+    assert np.all(p['prelu_f1'][0] == 0.25) and np.all(p['FC1'][1] == 0)
+    lim = np.sqrt(6.0 / ((20 + 20) * 9))
+    assert np.abs(p['axial_ch_conv2'][0]).max() <= lim

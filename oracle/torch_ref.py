@@ -38,6 +38,18 @@ def _conv_true(x, W):
     return F.conv2d(x, torch.flip(W, dims=(2, 3)))
 
 
+def _maxpool2_theano(x):
+    """2x2/2 max pool whose backward sends the whole output gradient to EVERY element equal to the window
+    maximum (Theano MaxPoolGrad), unlike F.max_pool2d (first maximum only).  Matters for constant regions
+    (zero-padded border patches), where windows tie at a positive value."""
+    y = F.max_pool2d(x, 2)
+    up = y.detach().repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    mask = (x.detach() == up).to(x.dtype)
+    n, c, h, w = x.shape
+    routed = ((x - x.detach()) * mask).reshape(n, c, h // 2, 2, w // 2, 2).sum(dim=(3, 5))
+    return y.detach() + routed
+
+
 def forward(P, ax, co, sa, atlas, train=False, masks=None, bn_out=None):
     """P: dict of torch tensors (to_torch). Inputs torch tensors. Returns probs [N,15]."""
     feats = []
@@ -56,7 +68,7 @@ def forward(P, ax, co, sa, atlas, train=False, masks=None, bn_out=None):
             h = (z - mean.view(sh)) * (gamma * inv_std).view(sh) + beta.view(sh)
             h = _prelu(_relu(h), P['%s_ch_prelu%d' % (t, i)][0])
             if i in (2, 4):
-                h = F.max_pool2d(h, 2)
+                h = _maxpool2_theano(h) if train else F.max_pool2d(h, 2)
         if train:
             h = h / 0.5 * masks['%s_l1drop' % t]
         W, b = P['%s_d1' % t]

@@ -159,7 +159,8 @@ def main():
         dom = int(np.argmax(ms))
         per_launch_patches = B / launches
         flop_launch = 2.0 * STAGE_MACS[dom] * per_launch_patches
-        dur = ms[dom] / launches * 1e-3
+        ms = ms.astype(np.float64)
+        dur = float(ms[dom]) / launches * 1e-3
         achieved = flop_launch / dur / 1e12
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')           # filled from rocprofv3 --pmc passes
@@ -172,13 +173,13 @@ def main():
                            'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic,
                            'launch_ms': dur * 1e3, 'patches_per_launch': per_launch_patches}
         out['stages'] = {STAGE_NAMES[i]: {'ms_per_step': float(ms[i]),
-                                          'tflops': 2.0 * STAGE_MACS[i] * B / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else None}
+                                          'tflops': float(2.0 * STAGE_MACS[i] * B / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else None}
                          for i in range(8)}
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
     if rank == 0 and world == 1 and not args.no_cpu:
         out['cpu_baseline'] = cpu_baseline(weights)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out, default=float))
     h.close()
 
 

@@ -24,9 +24,9 @@ namespace scs {
 enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2 };
 enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3 };
 
-template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_>
+template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0>
 struct ConvCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_;
+    static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_;
     // SRC_NCHW_PAD2: the global input is (HIN_-4)^2 and is zero-padded by 2 on every side in LDS (dgrad)
     static constexpr int HIN = HIN_, WIN = HIN_;
     static constexpr int HSRC = (SRC_ == SRC_NCHW_PAD2) ? HIN_ - 4 : HIN_;
@@ -35,23 +35,37 @@ struct ConvCfg {
     static constexpr int HP = HO / 2;
     static constexpr int PIX = HO * HO;                 // conv outputs per patch
     static constexpr int OUTPIX = POOL ? HP * HP : PIX; // stored outputs per patch and channel
+    // a workgroup owns band `b` of NB horizontal bands of its G patches: HOB conv-output rows, HINB input rows
+    static constexpr int HOB = HO / NB_;
+    static constexpr int HINB = HOB + 2;
+    static constexpr int PIXB = HOB * HO;               // conv outputs per patch and band
+    static constexpr int WB = (HOB / 2) * HP;           // pooling windows per patch and band
+    static constexpr int OUTB = POOL ? WB : PIXB;       // stored outputs per patch, channel and band
+    static constexpr int XROWS = HINB + 2;              // rows of the raw 32x32 patch a fused-conv1 band needs
     static constexpr int PLANE = PLANE_;
     static constexpr int NT = n_tiles(COUT_);
     static constexpr int NS = n_stride(COUT_);
     static constexpr int NC4 = CIN_ / 4;
-    static constexpr int MTOT = G_ * PIX;
+    static constexpr int MTOT = G_ * PIXB;
     static constexpr int TILES = (MTOT + 15) / 16;
-    static constexpr int TPW = (TILES + 3) / 4;         // tiles per wave
+    static constexpr int TPW = (TILES + 3) / 4;         // tiles per wave (wave w owns tiles w, w+4, ...)
+    static constexpr bool LAST_RAGGED = (3 + 4 * (TPW - 1)) >= TILES;   // some waves lack their last tile
     static constexpr int WCHUNK = 36 * NS;              // floats per weight chunk
     static constexpr int WCHUNK4 = WCHUNK / 4;
     static constexpr int WPT = (WCHUNK4 + 255) / 256;   // float4 per thread per chunk
     static constexpr int IN_FLOATS = G_ * CIN_ * PLANE_;
     static constexpr int IN_FLOATS_AL = (IN_FLOATS + 3) / 4 * 4;
-    static constexpr int XS_FLOATS = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME) ? (32 * 32 + 9 * 20 + 32) : 0;
-    static constexpr size_t LDS_BYTES = (size_t)(IN_FLOATS_AL + 2 * WCHUNK + XS_FLOATS) * 4;
+    static constexpr int XS_FLOATS = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME) ? 32 * 32 : 0;
+    // the epilogue restages the outputs in LDS ([g][cout][OSTR], odd stride) and stores them as whole rows
+    static constexpr int OSTR = OUTB | 1;
+    static constexpr int OUT_FLOATS = G_ * COUT_ * OSTR;
+    static constexpr int MAIN_FLOATS = IN_FLOATS_AL + 2 * WCHUNK + XS_FLOATS;
+    static constexpr size_t LDS_BYTES = (size_t)(MAIN_FLOATS > OUT_FLOATS ? MAIN_FLOATS : OUT_FLOATS) * 4;
     static_assert(CIN_ % 4 == 0, "k-steps are groups of 4 input channels");
-    static_assert(!POOL || (HO % 2 == 0), "pooling needs an even conv output");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(HO % NB_ == 0 && (!POOL || (HOB % 2 == 0)), "bands must split the output rows (evenly for pooling)");
+    static_assert(NB_ == 1 || (G_ == 1 && SRC_ != SRC_NCHW_PAD2), "bands: one patch per workgroup");
+    static_assert(PLANE_ >= HINB * HIN_, "plane stride too small");
+    static_assert(LDS_BYTES * WPS_ <= 160 * 1024, "LDS budget (WPS workgroups of 4 waves per CU)");
 };
 
 struct ConvArgs {
@@ -59,11 +73,11 @@ struct ConvArgs {
     const float* w[kTowers];      // packed [CIN/4][9][4][NS]
     const float* bias[kTowers];   // [NT*16] (unused for EPI_RAW)
     float* out[kTowers];          // [n][COUT][OUTPIX]
-    const float* w1[kTowers];     // SRC_CONV1/VOLUME: conv1 weights [9][20] and bias [32]
-    const float* b1[kTowers];
+    const float* w1[kTowers];     // SRC_CONV1/VOLUME: conv1 weights+bias [20][10] (9 taps, then the bias)
     const int32_t* centers;       // SRC_VOLUME: [n][3]
     int dimx, dimy, dimz;
     int n;                        // patches
+    unsigned long long* stamps;   // diagnostic builds only (STAMP): [workgroup][8] s_memtime values
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -72,43 +86,76 @@ __device__ __forceinline__ T pick3(T const (&arr)[kTowers], int t) {
     return t == 0 ? arr[0] : (t == 1 ? arr[1] : arr[2]);
 }
 
-// conv1 (1 -> 20 channels, K = 9) on the vector ALU, 32x32 LDS tile -> 20 planes of 30x30 in LDS, bias + ReLU.
-// (nets.py:171; 2.8 % of a tower's MACs: not worth a K-padded MFMA pass.)
-template <int PLANE>
-__device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, const float* __restrict__ s_w1,
-                                             const float* __restrict__ s_b1, float* __restrict__ s_out, int tid) {
-    for (int p = tid; p < 900; p += 256) {
+// conv1 (1 -> 20 channels, K = 9) on the vector ALU: raw tile rows in LDS -> 20 planes of ROWS x 30 in LDS, bias + ReLU.
+// (nets.py:171; 2.8 % of a tower's MACs: not worth a K-padded MFMA pass.)  Each lane keeps the 3x3 neighbourhoods
+// of its pixels in registers; the 200 weights/biases are wave-uniform and arrive through scalar loads (SGPR
+// operands of v_fma), so the only LDS traffic is 9 reads and 20 writes per pixel.
+template <int PLANE, int ROWS>
+__device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, const float* __restrict__ w1g,
+                                             float* __restrict__ s_out, int tid) {
+    constexpr int NPIX = ROWS * 30, NR = (NPIX + 255) / 256;
+    float in[NR][9];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int p = min(tid + 256 * r, NPIX - 1);
         const int y = p / 30, x = p - y * 30;
-        float in[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) in[t] = s_x[(y + t / 3) * 32 + x + t % 3];
-        float o[20];
+        for (int t = 0; t < 9; ++t) in[r][t] = s_x[(y + t / 3) * 32 + x + t % 3];
+    }
 #pragma unroll
-        for (int c = 0; c < 20; ++c) o[c] = s_b1[c];
+    for (int c = 0; c < 20; ++c) {
+        const float* __restrict__ w = w1g + c * 10;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int r = 0; r < NR; ++r) {
+            float o = w[9];
 #pragma unroll
-            for (int c = 0; c < 20; ++c) o[c] = fmaf(in[t], s_w1[t * 20 + c], o[c]);
+            for (int t = 0; t < 9; ++t) o = fmaf(in[r][t], w[t], o);
+            const int p = tid + 256 * r;
+            if (p < NPIX) s_out[c * PLANE + p] = fmaxf(o, 0.f);
+        }
+    }
+}
+
+// batched copy helper: K independent loads in flight per thread before the LDS writes (a plain strided loop
+// serialises one global-load latency per iteration)
+template <int TOTAL, class V, class SrcF, class DstF>
+__device__ __forceinline__ void staged_copy(int tid, SrcF&& src_of, DstF&& dst_of) {
+    constexpr int ITER = (TOTAL + 255) / 256, K = 8;
 #pragma unroll
-        for (int c = 0; c < 20; ++c) s_out[c * PLANE + p] = fmaxf(o[c], 0.f);
+    for (int i0 = 0; i0 < ITER; i0 += K) {
+        V v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (i0 + k < ITER) { const int e = min(tid + 256 * (i0 + k), TOTAL - 1); v[k] = src_of(e); }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (i0 + k < ITER) { const int e = tid + 256 * (i0 + k); if (e < TOTAL) dst_of(e, v[k]); }
+        }
     }
 }
 
 template <class C>
-__global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + C::IN_FLOATS_AL;
-    float* s_x = s_w + 2 * C::WCHUNK;     // only when XS_FLOATS > 0: [1024] patch, [180] w1, [32] b1
+    float* s_x = s_w + 2 * C::WCHUNK;     // only when XS_FLOATS > 0: raw rows of the 32x32 patch
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
     const int tower = blockIdx.y;
-    const int g0 = blockIdx.x * C::G;
+    const int band = (C::NB > 1) ? (int)(blockIdx.x % C::NB) : 0;
+    const int g0 = (int)(blockIdx.x / C::NB) * C::G;
     const int ng = min(C::G, a.n - g0);
 
+    unsigned long long* stp = nullptr;
+    if constexpr (C::STAMP) {
+        stp = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        if (tid == 0) stp[0] = __builtin_amdgcn_s_memtime();
+    }
     const float* __restrict__ wsrc = pick3(a.w, tower);
     const float* __restrict__ insrc = pick3(a.in, tower);
 
@@ -121,14 +168,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
     if constexpr (C::WPT > 1) wr1 = reinterpret_cast<const float4*>(wsrc)[wi1];
     if constexpr (C::WPT > 2) wr2 = reinterpret_cast<const float4*>(wsrc)[wi2];
 
+    // per-lane epilogue bias, fetched now so its latency hides under the staging
+    float bvs[C::NT];
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+        bvs[nt] = 0.f;
+        if constexpr (C::EPI != EPI_RAW) bvs[nt] = pick3(a.bias, tower)[nt * 16 + lr];
+    }
+
     // ---- stage the input planes of this workgroup's patches
     if constexpr (C::SRC == SRC_NCHW) {
-        constexpr int HW = C::HSRC * C::HSRC;
-        const float* __restrict__ src = insrc + (size_t)g0 * C::CIN * HW;
-        const int total = ng * C::CIN * HW;
-        for (int e = tid; e < C::G * C::CIN * HW; e += 256) {
-            const int pl = e / HW, r = e - pl * HW;
-            s_in[pl * C::PLANE + r] = (e < total) ? src[e] : 0.f;
+        constexpr int HW = C::HSRC * C::HSRC, BW = C::HINB * C::WIN;      // full plane / band slice of it
+        const float* __restrict__ src = insrc + (size_t)g0 * C::CIN * HW + band * C::HOB * C::WIN;
+        const int planes = ng * C::CIN;
+        if constexpr (BW % 4 == 0 && HW % 4 == 0 && C::PLANE % 4 == 0 && (C::HOB * C::WIN) % 4 == 0) {
+            constexpr int BW4 = BW / 4;
+            const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
+            float4* dst4 = reinterpret_cast<float4*>(s_in);
+            staged_copy<C::G * C::CIN * BW4, float4>(
+                tid,
+                [&](int e) { const int pl = e / BW4, r = e - pl * BW4;
+                             return (pl < planes) ? src4[(size_t)pl * (HW / 4) + r] : float4{0.f, 0.f, 0.f, 0.f}; },
+                [&](int e, float4 v) { const int pl = e / BW4, r = e - pl * BW4; dst4[pl * (C::PLANE / 4) + r] = v; });
+        } else if constexpr (C::PLANE == HW && C::NB == 1 && (C::G * C::CIN * HW) % 4 == 0) {
+            // unpadded planes: the LDS image is the global block itself (16-byte aligned: g0 is a multiple of G)
+            const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
+            float4* dst4 = reinterpret_cast<float4*>(s_in);
+            const int tot4 = planes * HW / 4;      // ng*CIN*HW is a multiple of 4 whenever CIN*HW is
+            staged_copy<C::G * C::CIN * HW / 4, float4>(
+                tid, [&](int e) { return (e < tot4) ? src4[e] : float4{0.f, 0.f, 0.f, 0.f}; },
+                [&](int e, float4 v) { dst4[e] = v; });
+        } else {
+            staged_copy<C::G * C::CIN * BW, float>(
+                tid,
+                [&](int e) { const int pl = e / BW, r = e - pl * BW; return (pl < planes) ? src[(size_t)pl * HW + r] : 0.f; },
+                [&](int e, float v) { const int pl = e / BW, r = e - pl * BW; s_in[pl * C::PLANE + r] = v; });
         }
     } else if constexpr (C::SRC == SRC_NCHW_PAD2) {
         constexpr int HS = C::HSRC, HW = HS * HS;
@@ -143,20 +217,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
         }
     } else {
         static_assert(C::SRC == SRC_NCHW || C::SRC == SRC_NCHW_PAD2 || C::G == 1, "fused conv1 variants take one patch per workgroup");
-        float* s_w1 = s_x + 1024;
-        float* s_b1 = s_w1 + 180;
-        if (tid < 180) s_w1[tid] = pick3(a.w1, tower)[tid];
-        if (tid < 32) s_b1[tid] = pick3(a.b1, tower)[tid];
         if constexpr (C::SRC == SRC_CONV1) {
-            const float4* __restrict__ src = reinterpret_cast<const float4*>(insrc + (size_t)g0 * 1024);
-            reinterpret_cast<float4*>(s_x)[tid] = src[tid];
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(insrc + (size_t)g0 * 1024 + band * C::HOB * 32);
+            if (tid < C::XROWS * 8) reinterpret_cast<float4*>(s_x)[tid] = src[tid];
         } else {
             // tri-planar gather, zero padded (base.py:293-306): axial [x-16+i][y-16+j][z], coronal
             // [x-16+i][y][z-16+j], sagittal [x][y-16+i][z-16+j]
             const int cx = a.centers[(size_t)g0 * 3 + 0], cy = a.centers[(size_t)g0 * 3 + 1], cz = a.centers[(size_t)g0 * 3 + 2];
             const float* __restrict__ vol = insrc;
-            for (int e = tid; e < 1024; e += 256) {
-                const int i = e >> 5, j = e & 31;
+            for (int e = tid; e < C::XROWS * 32; e += 256) {
+                const int i = band * C::HOB + (e >> 5), j = e & 31;
                 int vx, vy, vz;
                 if (tower == 0) { vx = cx - 16 + i; vy = cy - 16 + j; vz = cz; }
                 else if (tower == 1) { vx = cx - 16 + i; vy = cy; vz = cz - 16 + j; }
@@ -166,9 +236,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
-        conv1_to_lds<C::PLANE>(s_x, s_w1, s_b1, s_in, tid);
+        conv1_to_lds<C::PLANE, C::HINB>(s_x, pick3(a.w1, tower), s_in, tid);
     }
 
+    if constexpr (C::STAMP) { if (tid == 0) stp[1] = __builtin_amdgcn_s_memtime(); }
     // ---- weight chunk 0 -> LDS
     {
         float4* dst = reinterpret_cast<float4*>(s_w);
@@ -184,17 +255,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
         int m = (wave + 4 * j) * 16 + lr;
         int g, y, x;
         if constexpr (C::POOL) {
-            int widx = min(m >> 2, C::G * C::HP * C::HP - 1);
+            int widx = min(m >> 2, C::G * C::WB - 1);
             const int q = m & 3;
-            g = widx / (C::HP * C::HP);
-            const int r = widx - g * (C::HP * C::HP);
+            g = widx / C::WB;
+            const int r = widx - g * C::WB;
             const int wy = r / C::HP, wx = r - wy * C::HP;
             y = 2 * wy + (q >> 1);
             x = 2 * wx + (q & 1);
         } else {
             m = min(m, C::MTOT - 1);
-            g = m / C::PIX;
-            const int r = m - g * C::PIX;
+            g = m / C::PIXB;
+            const int r = m - g * C::PIXB;
             y = r / C::HO;
             x = r - y * C::HO;
         }
@@ -208,8 +279,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
         for (int nt = 0; nt < C::NT; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __syncthreads();
+    if constexpr (C::STAMP) { if (tid == 0) stp[2] = __builtin_amdgcn_s_memtime(); }
 
     const int boff = kq * C::NS + lr;
+    const bool last_ok = (wave + 4 * (C::TPW - 1)) < C::TILES;
     for (int c4 = 0; c4 < C::NC4; ++c4) {
         if (c4 + 1 < C::NC4) {
             const float4* __restrict__ src = reinterpret_cast<const float4*>(wsrc + (size_t)(c4 + 1) * C::WCHUNK);
@@ -227,6 +300,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
             for (int nt = 0; nt < C::NT; ++nt) b[nt] = sw[tap * 4 * C::NS + nt * 16];
 #pragma unroll
             for (int j = 0; j < C::TPW; ++j) {
+                if (C::LAST_RAGGED && j == C::TPW - 1 && !last_ok) continue;   // wave-uniform: this wave has no such tile
                 const float av = sa[abase[j] + toff];
 #pragma unroll
                 for (int nt = 0; nt < C::NT; ++nt)
@@ -242,9 +316,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: D row = 4*kq + r (pixel / window position), column = lr (cout)
-    const float* __restrict__ biasp = pick3(a.bias, tower);
-    float* __restrict__ outp = pick3(a.out, tower) + (size_t)g0 * C::COUT * C::OUTPIX;
+    if constexpr (C::STAMP) { if (tid == 0) stp[3] = __builtin_amdgcn_s_memtime(); }
+    // ---- epilogue: D row = 4*kq + r (pixel / window position), column = lr (cout).  Results are restaged in
+    // LDS as [g][cout][OSTR] (every wave has passed the loop's last barrier, so the operand buffers are free) and
+    // leave as whole rows: 64 lanes -> 256 contiguous bytes, instead of 64 scattered dwords per store.
+    float* s_o = smem;
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
         const int t = wave + 4 * j;
@@ -253,36 +329,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_kernel(ConvArgs a) {
         for (int nt = 0; nt < C::NT; ++nt) {
             const int co = nt * 16 + lr;
             if (co >= C::COUT) continue;
-            float bv = 0.f;
-            if constexpr (C::EPI != EPI_RAW) bv = biasp[co];
+            const float bv = bvs[nt];
             if constexpr (C::POOL) {
                 const int widx = t * 4 + kq;
-                if (widx < C::G * C::HP * C::HP) {
-                    const int g = widx / (C::HP * C::HP);
-                    const int r = widx - g * (C::HP * C::HP);
-                    if (g < ng) {
-                        const f32x4 v = acc[j][nt];
-                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        outp[((size_t)g * C::COUT + co) * C::OUTPIX + r] = fmaxf(mx + bv, 0.f);
-                    }
+                if (widx < C::G * C::WB) {
+                    const int g = widx / C::WB;
+                    const int r = widx - g * C::WB;
+                    const f32x4 v = acc[j][nt];
+                    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    s_o[(g * C::COUT + co) * C::OSTR + r] = fmaxf(mx + bv, 0.f);
                 }
             } else {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int m = t * 16 + kq * 4 + r4;
                     if (m < C::MTOT) {
-                        const int g = m / C::PIX;
-                        const int r = m - g * C::PIX;
-                        if (g < ng) {
-                            float v = acc[j][nt][r4];
-                            if constexpr (C::EPI != EPI_RAW) v = fmaxf(v + bv, 0.f);
-                            outp[((size_t)g * C::COUT + co) * C::OUTPIX + r] = v;
-                        }
+                        const int g = m / C::PIXB;
+                        const int r = m - g * C::PIXB;
+                        float v = acc[j][nt][r4];
+                        if constexpr (C::EPI != EPI_RAW) v = fmaxf(v + bv, 0.f);
+                        s_o[(g * C::COUT + co) * C::OSTR + r] = v;
                     }
                 }
             }
         }
     }
+    __syncthreads();
+    {
+        float* __restrict__ outp = pick3(a.out, tower) + (size_t)g0 * C::COUT * C::OUTPIX + band * C::OUTB;
+        const int total = ng * C::COUT * C::OUTB;
+        for (int e = tid; e < total; e += 256) {
+            const int gc = e / C::OUTB, r = e - gc * C::OUTB;
+            outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
+        }
+    }
+    if constexpr (C::STAMP) { if (tid == 0) stp[4] = __builtin_amdgcn_s_memtime(); }
 }
 
 template <class C>
@@ -294,7 +375,7 @@ inline hipError_t conv_set_attr() {
 template <class C>
 inline void conv_launch(const ConvArgs& a, hipStream_t st) {
     if (a.n <= 0) return;
-    dim3 grid((a.n + C::G - 1) / C::G, kTowers);
+    dim3 grid(((a.n + C::G - 1) / C::G) * C::NB, kTowers);
     hipLaunchKernelGGL(conv3x3_mfma_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
 }
 

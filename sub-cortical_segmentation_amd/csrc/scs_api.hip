@@ -31,11 +31,12 @@ void set_error(const char* fmt, ...) {
 }
 
 // ----------------------------------------------------------------------------- layer configurations
-using CfgConv12 = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 912>;
-using CfgConv12V = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_VOLUME, 912>;
-using CfgConv3 = ConvCfg<20, 40, 14, 4, EPI_BIAS_RELU, SRC_NCHW, 208>;
-using CfgConv4 = ConvCfg<40, 40, 12, 4, EPI_BIAS_RELU_POOL, SRC_NCHW, 144>;
-using CfgConv5 = ConvCfg<40, 60, 5, 16, EPI_BIAS_RELU, SRC_NCHW, 27>;
+// <CIN, COUT, HIN, patches per workgroup, epilogue, source, LDS plane stride, bands, workgroups per CU>
+using CfgConv12 = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 2>;    // half a patch per workgroup
+using CfgConv12V = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_VOLUME, 496, 2, 2>;
+using CfgConv3 = ConvCfg<20, 40, 14, 2, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 3>;
+using CfgConv4 = ConvCfg<40, 40, 12, 2, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 2>;
+using CfgConv5 = ConvCfg<40, 60, 5, 16, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 1>;
 
 // ----------------------------------------------------------------------------- packing kernels
 // conv i (Cin >= 4): Wp[c4][tap][kk][n] = W[n][4*c4+kk][2-dy][2-dx] * scale[n]  (true conv -> correlation)
@@ -63,20 +64,21 @@ __global__ void pack_conv_kernel(const float* __restrict__ W, const float* __res
     }
 }
 
-// conv1: w1[tap][c] (20 channels), b1[32]
+// conv1: w1b[c][10] = 9 correlation taps (flipped, BN scale folded) then the folded bias
 __global__ void pack_conv1_kernel(const float* __restrict__ W, const float* __restrict__ bn, int fold,
-                                  float* __restrict__ w1, float* __restrict__ b1) {
+                                  float* __restrict__ w1b) {
     const int t = threadIdx.x;
-    if (t < 180) {
-        const int tap = t / 20, c = t % 20, dy = tap / 3, dx = tap % 3;
-        float v = W[(c * 3 + (2 - dy)) * 3 + (2 - dx)];
-        if (fold) v *= bn[20 + c] * bn[60 + c];
-        w1[t] = v;
-    }
-    if (t < 32) {
-        float b = 0.f;
-        if (fold && t < 20) b = bn[t] - bn[40 + t] * bn[20 + t] * bn[60 + t];
-        b1[t] = b;
+    if (t < 200) {
+        const int c = t / 10, k = t % 10;
+        float v;
+        if (k < 9) {
+            const int dy = k / 3, dx = k % 3;
+            v = W[(c * 3 + (2 - dy)) * 3 + (2 - dx)];
+            if (fold) v *= bn[20 + c] * bn[60 + c];                     // gamma * inv_std
+        } else {
+            v = fold ? bn[c] - bn[40 + c] * bn[20 + c] * bn[60 + c] : 0.f;   // beta - mean*scale
+        }
+        w1b[t] = v;
     }
 }
 
@@ -179,7 +181,7 @@ static int alloc_packed(scs_ctx* h) {
     auto take = [&](size_t floats) { size_t o = off; off += align64(floats); return o; };
     size_t o_c1w[kTowers], o_c1b[kTowers], o_cw[kTowers][kConvs], o_cb[kTowers][kConvs], o_d1w[kTowers], o_d1b[kTowers];
     for (int t = 0; t < kTowers; ++t) {
-        o_c1w[t] = take(180); o_c1b[t] = take(32);
+        o_c1w[t] = take(200); o_c1b[t] = take(1);
         for (int i = 1; i < kConvs; ++i) { o_cw[t][i] = take(conv_pack_floats(i)); o_cb[t][i] = take(n_tiles(kCout[i]) * 16); }
         o_d1w[t] = take((size_t)kFlat * gemm_ns(kD1)); o_d1b[t] = take(gemm_ns(kD1));
     }
@@ -206,8 +208,7 @@ int repack_inference(scs_ctx* h, hipStream_t st) {
     constexpr HeadOff H = head_off();
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
-        hipLaunchKernelGGL(pack_conv1_kernel, dim3(1), dim3(256), 0, st, P + T.convW[0], P + T.bn[0], 1,
-                           h->pk.conv1w[t], h->pk.conv1b[t]);
+        hipLaunchKernelGGL(pack_conv1_kernel, dim3(1), dim3(256), 0, st, P + T.convW[0], P + T.bn[0], 1, h->pk.conv1w[t]);
         for (int i = 1; i < kConvs; ++i)
             hipLaunchKernelGGL(pack_conv_kernel, dim3(32), dim3(256), 0, st, P + T.convW[i], P + T.bn[i], kCin[i],
                                kCout[i], n_stride(kCout[i]), 1, h->pk.convw[t][i], h->pk.convb[t][i]);
@@ -260,7 +261,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     // conv1 + conv2 + pool1
     for (int t = 0; t < kTowers; ++t) {
         a.w[t] = pk.convw[t][1]; a.bias[t] = pk.convb[t][1]; a.out[t] = h->a_pool1[t];
-        a.w1[t] = pk.conv1w[t]; a.b1[t] = pk.conv1b[t];
+        a.w1[t] = pk.conv1w[t];
     }
     if (vol) {
         a.in[0] = a.in[1] = a.in[2] = vol;

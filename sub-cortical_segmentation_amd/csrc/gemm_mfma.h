@@ -19,13 +19,15 @@ struct GemmProblem {
 };
 struct GemmArgs {
     GemmProblem p[kTowers];      // blockIdx.z selects
-    int M, K4, N;
+    int M, K4, N;                // K4 = reduction length walked (multiple of 4)
+    int K;                       // rows of W that exist (k >= K reads as zero); 0 = K4
     int relu;
 };
 
 constexpr int kGemmBM = 128, kGemmBN = 96, kGemmBK = 32, kGemmAS = 34, kGemmBS = 112;
 constexpr size_t kGemmLds = (size_t)(2 * kGemmBM * kGemmAS + 2 * kGemmBK * kGemmBS) * 4;
 
+template <int VARIANT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a = smem;                                  // [2][128][34]
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
     const int lr = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
 
+    const int kmax = g.K ? g.K : g.K4;
     float ra[16], rb[12];
     const int a_col = tid & 31, a_row = tid >> 5;       // A slab: rows a_row + 8*i, column a_col
     auto load_slab = [&](int k0) {
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
             const int e = tid + 256 * i;
             const int kr = e / kGemmBN, c = e - kr * kGemmBN;
             const int k = k0 + kr, n = n0 + c;
-            rb[i] = (k < g.K4 && n < P.NS) ? P.W[(size_t)k * P.NS + n] : 0.f;
+            rb[i] = (k < kmax && n < P.NS) ? P.W[(size_t)k * P.NS + n] : 0.f;
         }
     };
     auto store_slab = [&](int buf) {
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
 inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
     if (g.M <= 0) return;
     dim3 grid((g.M + kGemmBM - 1) / kGemmBM, (g.N + kGemmBN - 1) / kGemmBN, nproblems);
-    hipLaunchKernelGGL(gemm_mfma_kernel, grid, dim3(256), kGemmLds, st, g);
+    hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), kGemmLds, st, g);
 }
 
 }  // namespace scs

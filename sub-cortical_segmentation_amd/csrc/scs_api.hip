@@ -319,7 +319,7 @@ static int set_kernel_attrs() {
     SCS_HIP(conv_set_attr<CfgConv3>());
     SCS_HIP(conv_set_attr<CfgConv4>());
     SCS_HIP(conv_set_attr<CfgConv5>());
-    SCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+    SCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
     return SCS_OK;
 }
 
@@ -387,6 +387,7 @@ int scs_set_params(scs_handle h, const float* host_arena, size_t n) {
     int rc = repack_inference(h, nullptr);
     if (rc != SCS_OK) return rc;
     SCS_HIP(hipDeviceSynchronize());
+    h->packed_dirty = false;
     h->has_params = true;
     return SCS_OK;
 }
@@ -418,6 +419,7 @@ static int forward_common(scs_handle h, const float* ax, const float* co, const 
     int rc = ensure_workspace(h);
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
     for (int64_t s = 0; s < n; s += h->chunk) {
         const int m = (int)((n - s < h->chunk) ? (n - s) : h->chunk);
         rc = forward_chunk(h, ax ? ax + s * 1024 : nullptr, co ? co + s * 1024 : nullptr, sa ? sa + s * 1024 : nullptr,
@@ -451,6 +453,7 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
     SCS_HIP(hipSetDevice(h->device));
     int rc = ensure_workspace(h);
     if (rc != SCS_OK) return rc;
+    if (h->packed_dirty) { rc = repack_inference(h, nullptr); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
     const size_t c = (size_t)h->chunk;
     const size_t per = 3 * 1024 + 15 + 15 + 1;                  // views, atlas, probs, label
     if (!h->stage_dev || h->stage_floats < c * per) {
@@ -484,6 +487,7 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
     int rc = ensure_workspace(h);
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
     const int nchunks = (int)((n + h->chunk - 1) / h->chunk);
     std::vector<hipEvent_t> ev((size_t)nchunks * 9);
     for (auto& e : ev) SCS_HIP(hipEventCreate(&e));

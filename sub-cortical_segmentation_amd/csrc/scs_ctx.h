@@ -2,9 +2,12 @@
 #pragma once
 #include "scs_common.h"
 
+struct TrainWs;
+
 struct scs_ctx {
     int device = 0;
     bool has_params = false;
+    bool packed_dirty = false;     // parameter arena changed since the inference operands were packed
 
     // Lasagne-layout arenas (SCS_N_PARAMS floats each)
     float* params = nullptr;
@@ -37,7 +40,7 @@ struct scs_ctx {
     size_t stage_floats = 0;
 
     // training state (scs_train.hip)
-    struct TrainWs* tws = nullptr;
+    TrainWs* tws = nullptr;
 };
 
 namespace scs {

@@ -1,23 +1,776 @@
-// Training entry points of libscs (include/scs.h) - placeholder until the training kernels land.
+// libscs - training step (forward in training mode, backward, Adam) and labelled evaluation.
+//
+// Replaces what nolearn's train_iter_/eval_iter_ compile out of the Lasagne graph of
+// /root/reference/cnn_cort/nets.py:170-246: conv -> BatchNorm (batch statistics, eps 1e-4, running averages
+// alpha 0.1) -> ReLU -> PReLU (identity on ReLU output, zero alpha gradient: SURVEY F2) -> max-pool, dropout 0.5,
+// dense layers, softmax + mean categorical cross-entropy (nets.py:235), Adam (nets.py:236-237).
+//
+// Forward convolutions (raw, unfolded weights) and the data gradients (correlation of the zero-padded output
+// gradient with the channel-transposed filters) run on the same fp32 MFMA kernel as inference (conv_mfma.h);
+// BN statistics/gradients are per-channel reductions with double accumulators; weight gradients and the
+// dense-layer backward GEMMs are plain LDS-tiled vector-ALU kernels in this round.
+#include <cmath>
+#include <vector>
+
+#include "conv_mfma.h"
+#include "gemm_mfma.h"
 #include "scs_ctx.h"
 
 namespace scs {
-void train_free(scs_ctx*) {}
+
+// ------------------------------------------------------------------------------------------- configurations
+using TF2 = ConvCfg<20, 20, 30, 1, EPI_RAW, SRC_NCHW, 496, 2, 2>;
+using TF3 = ConvCfg<20, 40, 14, 2, EPI_RAW, SRC_NCHW, 208, 1, 2>;
+using TF4 = ConvCfg<40, 40, 12, 2, EPI_RAW, SRC_NCHW, 144, 1, 2>;
+using TF5 = ConvCfg<40, 60, 5, 16, EPI_RAW, SRC_NCHW, 27, 1, 1>;
+// data gradients: input = dZ_i zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i
+using DG5 = ConvCfg<60, 40, 7, 8, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 1>;
+using DG4 = ConvCfg<40, 40, 14, 2, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 2>;
+using DG3 = ConvCfg<40, 20, 16, 2, EPI_RAW, SRC_NCHW_PAD2, 272, 1, 1>;
+using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 1040, 1, 1>;
+
+constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
+constexpr bool kPool[kConvs] = {false, true, false, true, false};
+
+}  // namespace scs
+
+struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
+    static constexpr int kTowers = scs::kTowers, kConvs = scs::kConvs;
+    int cap = 0;                               // samples the buffers hold
+    float* base = nullptr;
+    float* Z[kTowers][kConvs]{};               // raw conv outputs
+    float* X[kTowers][kConvs]{};               // conv inputs (X[0] = caller's patches; X[i] = block i-1 output)
+    float* H5[kTowers]{};                      // block-5 output after dropout [n][540]
+    float* dZ[kTowers]{};                      // gradient wrt the current Z (max size)
+    float* dX[kTowers][2]{};                   // gradient wrt block outputs, ping-pong (max size)
+    float *feat = nullptr, *featd = nullptr, *R1 = nullptr, *cat2 = nullptr, *R2 = nullptr;
+    float *probs = nullptr, *dlog = nullptr, *dR2 = nullptr, *dcat = nullptr, *dfeat = nullptr;
+    float *loss_rows = nullptr, *loss_dev = nullptr;
+    float* stats = nullptr;                    // [3][5][4][64]: mean, inv_std, dbeta, dgamma
+    uint8_t* masks = nullptr;                  // [3][n][540] + [n][540] + [n][540]
+    float* wpk[kTowers][kConvs]{};             // unfolded forward packs (i >= 1), conv1 [20][10] at i = 0
+    float* wdg[kTowers][kConvs]{};             // data-gradient packs (i >= 1)
+    float* pack_base = nullptr;
+    double* eval_acc = nullptr;                // [2]: loss sum, correct count
+};
+
+namespace scs {
+
+static size_t al64(size_t f) { return (f + 63) / 64 * 64; }
+
+void train_free(scs_ctx* h) {
+    if (!h->tws) return;
+    TrainWs* w = h->tws;
+    if (w->base) (void)hipFree(w->base);
+    if (w->masks) (void)hipFree(w->masks);
+    if (w->pack_base) (void)hipFree(w->pack_base);
+    if (w->eval_acc) (void)hipFree(w->eval_acc);
+    delete w;
+    h->tws = nullptr;
 }
 
+static int train_ensure(scs_ctx* h, int n) {
+    if (!h->tws) h->tws = new TrainWs();
+    TrainWs* w = h->tws;
+    if (!w->pack_base) {
+        size_t off = 0;
+        size_t of[kTowers][kConvs], og[kTowers][kConvs];
+        for (int t = 0; t < kTowers; ++t)
+            for (int i = 0; i < kConvs; ++i) {
+                of[t][i] = off; off += al64(i == 0 ? 200 : conv_pack_floats(i));
+                og[t][i] = off; off += al64(i == 0 ? 0 : (size_t)(kCout[i] / 4) * 36 * n_stride(kCin[i]));
+            }
+        SCS_HIP(hipMalloc(&w->pack_base, off * sizeof(float)));
+        for (int t = 0; t < kTowers; ++t)
+            for (int i = 0; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
+        SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
+    }
+    if (n <= w->cap) return SCS_OK;
+    if (w->base) { SCS_HIP(hipFree(w->base)); w->base = nullptr; }
+    if (w->masks) { SCS_HIP(hipFree(w->masks)); w->masks = nullptr; }
+    const size_t c = (size_t)((n + 63) / 64 * 64);
+    size_t off = 0;
+    auto take = [&](size_t f) { size_t o = off; off += al64(f); return o; };
+    size_t oZ[kTowers][kConvs], oX[kTowers][kConvs], oH[kTowers], odZ[kTowers], odX[kTowers][2];
+    for (int t = 0; t < kTowers; ++t) {
+        for (int i = 0; i < kConvs; ++i) {
+            oZ[t][i] = take(c * kCout[i] * kHout[i] * kHout[i]);
+            oX[t][i] = (i == 0) ? 0 : take(c * kCin[i] * kHin[i] * kHin[i]);
+        }
+        oH[t] = take(c * kFlat);
+        odZ[t] = take(c * 20 * 900);
+        odX[t][0] = take(c * 20 * 900);
+        odX[t][1] = take(c * 20 * 900);
+    }
+    const size_t o_feat = take(c * kFlat), o_featd = take(c * kFlat), o_R1 = take(c * kFC1), o_cat2 = take(c * kFC1ld),
+                 o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
+                 o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
+                 o_st = take((size_t)kTowers * kConvs * 4 * 64);
+    SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
+    SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
+    for (int t = 0; t < kTowers; ++t) {
+        for (int i = 0; i < kConvs; ++i) { w->Z[t][i] = w->base + oZ[t][i]; w->X[t][i] = (i == 0) ? nullptr : w->base + oX[t][i]; }
+        w->H5[t] = w->base + oH[t]; w->dZ[t] = w->base + odZ[t];
+        w->dX[t][0] = w->base + odX[t][0]; w->dX[t][1] = w->base + odX[t][1];
+    }
+    w->feat = w->base + o_feat; w->featd = w->base + o_featd; w->R1 = w->base + o_R1; w->cat2 = w->base + o_cat2;
+    w->R2 = w->base + o_R2; w->probs = w->base + o_probs; w->dlog = w->base + o_dlog; w->dR2 = w->base + o_dR2;
+    w->dcat = w->base + o_dcat; w->dfeat = w->base + o_dfeat; w->loss_rows = w->base + o_lr; w->loss_dev = w->base + o_ld;
+    w->stats = w->base + o_st;
+    SCS_HIP(hipMalloc(&w->masks, c * kFlat * 5));
+    w->cap = (int)c;
+    return SCS_OK;
+}
+
+// ------------------------------------------------------------------------------------------- packing (per step)
+struct PackJob { const float* W; float* fwd; float* dg; int cin, cout; };
+struct PackJobs { PackJob j[kTowers * kConvs]; };
+
+// fwd (i >= 1): Wp[c4][tap][kk][n] = W[n][4c4+kk][2-dy][2-dx];  conv1: w1b[c][10] = flipped taps, bias 0
+// dg  (i >= 1): Kp[o4][tap][kk][c] = W[4o4+kk][c][a][b]   (tap = 3a+b, no flip, channels transposed)
+__global__ void pack_train_kernel(PackJobs jobs) {
+    const PackJob J = jobs.j[blockIdx.y];
+    const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (J.cin == 1) {
+        for (int e = t0; e < 200; e += stride) {
+            const int c = e / 10, k = e % 10;
+            J.fwd[e] = k < 9 ? J.W[(c * 3 + (2 - k / 3)) * 3 + (2 - k % 3)] : 0.f;
+        }
+        return;
+    }
+    const int ns = n_stride(J.cout), tot = (J.cin / 4) * 36 * ns;
+    for (int e = t0; e < tot; e += stride) {
+        const int n = e % ns;
+        int r = e / ns;
+        const int kk = r & 3; r >>= 2;
+        const int tap = r % 9, c4 = r / 9;
+        float v = 0.f;
+        if (n < J.cout) v = J.W[((n * J.cin + c4 * 4 + kk) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)];
+        J.fwd[e] = v;
+    }
+    const int nsd = n_stride(J.cin), totd = (J.cout / 4) * 36 * nsd;
+    for (int e = t0; e < totd; e += stride) {
+        const int c = e % nsd;
+        int r = e / nsd;
+        const int kk = r & 3; r >>= 2;
+        const int tap = r % 9, o4 = r / 9;
+        float v = 0.f;
+        if (c < J.cin) v = J.W[(((o4 * 4 + kk) * J.cin + c) * 3 + tap / 3) * 3 + tap % 3];
+        J.dg[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- small kernels
+struct Ptr3 { float* p[kTowers]; };
+struct CPtr3 { const float* p[kTowers]; };
+template <class T> __device__ __forceinline__ T sel3(const T (&a)[kTowers], int t) { return t == 0 ? a[0] : (t == 1 ? a[1] : a[2]); }
+
+// counter-based dropout keep-mask: one hash per element (splitmix64 finaliser), keep when the top bit is set
+__global__ void dropout_mask_kernel(uint8_t* m, size_t total, uint64_t seed) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (e + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        m[e] = (uint8_t)(z >> 63);
+    }
+}
+
+// conv1, raw (no BN): [n][32][32] -> Z1 [n][20][30][30]; weights [20][10] (bias slot 0) via scalar loads
+__global__ __launch_bounds__(256) void conv1_raw_kernel(CPtr3 in, CPtr3 w, Ptr3 out) {
+    __shared__ __attribute__((aligned(16))) float s_x[1024];
+    const int t = blockIdx.y, tid = threadIdx.x;
+    const float* __restrict__ src = sel3(in.p, t) + (size_t)blockIdx.x * 1024;
+    reinterpret_cast<float4*>(s_x)[tid] = reinterpret_cast<const float4*>(src)[tid];
+    __syncthreads();
+    const float* __restrict__ w1 = sel3(w.p, t);
+    float* __restrict__ o = sel3(out.p, t) + (size_t)blockIdx.x * 20 * 900;
+    float inr[4][9];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int p = min(tid + 256 * r, 899), y = p / 30, x = p - y * 30;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) inr[r][k] = s_x[(y + k / 3) * 32 + x + k % 3];
+    }
+#pragma unroll
+    for (int c = 0; c < 20; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(inr[r][k], w1[c * 10 + k], acc);
+            const int p = tid + 256 * r;
+            if (p < 900) o[c * 900 + p] = acc;
+        }
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wv] = v;
+    __syncthreads();
+    double r = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += s_red[i];
+    return r;
+}
+
+// BN batch statistics of one channel: mean, inv_std = 1/sqrt(var + eps); running averages updated in the arena
+__global__ __launch_bounds__(256) void bn_stats_kernel(CPtr3 Z, int n, int C, int pix, float* stats /*[3][..]*/, int layer,
+                                                      float* params, int bn_off0, int tower_stride) {
+    __shared__ double s_red[4];
+    const int c = blockIdx.x, t = blockIdx.y;
+    const float* __restrict__ z = sel3(Z.p, t);
+    double s = 0, q = 0;
+    const long total = (long)n * pix;
+    for (long e = threadIdx.x; e < total; e += blockDim.x) {
+        const long ni = e / pix, p = e - ni * pix;
+        const double v = z[(ni * C + c) * pix + p];
+        s += v; q += v * v;
+    }
+    s = block_sum(s, s_red);
+    q = block_sum(q, s_red);
+    if (threadIdx.x == 0) {
+        const double mean = s / total, var = fmax(q / total - mean * mean, 0.0);
+        const double inv = 1.0 / sqrt(var + (double)kBnEps);
+        float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+        st[c] = (float)mean; st[64 + c] = (float)inv;
+        float* bn = params + bn_off0 + t * tower_stride;       // beta, gamma, mean, inv_std
+        bn[2 * C + c] = (1.f - kBnAlpha) * bn[2 * C + c] + kBnAlpha * (float)mean;
+        bn[3 * C + c] = (1.f - kBnAlpha) * bn[3 * C + c] + kBnAlpha * (float)inv;
+    }
+}
+
+// y = gamma*(z-mean)*inv_std + beta; ReLU; optional 2x2 max-pool; optional dropout (x * mask * 2) -> next input
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_kernel(CPtr3 Z, Ptr3 out, int n, int C, int H, const float* stats, int layer,
+                                                     const float* params, int bn_off0, int tower_stride, const uint8_t* mask) {
+    const int t = blockIdx.y;
+    const float* __restrict__ z = sel3(Z.p, t);
+    float* __restrict__ o = sel3(out.p, t);
+    const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+    const float* bn = params + bn_off0 + t * tower_stride;
+    const int HO = POOL ? H / 2 : H, opix = HO * HO, pix = H * H;
+    const long total = (long)n * C * opix;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long nc = e / opix;
+        const int r = (int)(e - nc * opix), c = (int)(nc % C);
+        const float sc = bn[C + c] * st[64 + c], sh = bn[c] - st[c] * sc;
+        float v;
+        if (POOL) {
+            const int wy = r / HO, wx = r - wy * HO;
+            const float* zp = z + nc * pix + (2 * wy) * H + 2 * wx;
+            v = fmaxf(fmaxf(fmaf(zp[0], sc, sh), fmaf(zp[1], sc, sh)), fmaxf(fmaf(zp[H], sc, sh), fmaf(zp[H + 1], sc, sh)));
+        } else {
+            v = fmaf(z[nc * pix + r], sc, sh);
+        }
+        v = fmaxf(v, 0.f);
+        if (mask) v = mask[(size_t)t * n * kFlat + e] ? v * 2.f : 0.f;
+        o[e] = v;
+    }
+}
+
+// atlas -> columns 540..554 of the fc_2 input rows (ConcatLayer elem_channels2, nets.py:224); column 555 = 0
+__global__ void atlas_cols_kernel(const float* __restrict__ atlas, float* __restrict__ cat2, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * 16) return;
+    const int row = e >> 4, c = e & 15;
+    cat2[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? atlas[(size_t)row * 15 + c] : 0.f;
+}
+
+// out[n][ldo] (cols 0..cols-1) = in[n][ldi] * mask * 2
+__global__ void dropout_apply_kernel(const float* in, int ldi, float* out, int ldo, const uint8_t* mask, int n, int cols) {
+    const long total = (long)n * cols;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / cols; const int c = (int)(e - r * cols);
+        out[r * ldo + c] = mask[e] ? in[r * ldi + c] * 2.f : 0.f;
+    }
+}
+
+// out_layer + softmax + cross-entropy on unpacked arena weights W[270][15], b[15]
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ R2, const float* __restrict__ W,
+                                                        const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
+                                                        float* probs /*[n][16]*/, float* dlog /*[n][16] or null*/,
+                                                        float* loss_rows /*[n] or null*/, double* eval_acc /*null or [2]*/) {
+    __shared__ float s_w[kFC2 * 15 + 16];
+    for (int e = threadIdx.x; e < kFC2 * 15; e += blockDim.x) s_w[e] = W[e];
+    if (threadIdx.x < 15) s_w[kFC2 * 15 + threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    float z[15];
+#pragma unroll
+    for (int c = 0; c < 15; ++c) z[c] = s_w[kFC2 * 15 + c];
+    const float* x = R2 + (size_t)row * kFC2ld;
+    for (int k = 0; k < kFC2; ++k) {
+        const float xv = x[k];
+#pragma unroll
+        for (int c = 0; c < 15; ++c) z[c] = fmaf(xv, s_w[k * 15 + c], z[c]);
+    }
+    float mx = z[0];
+#pragma unroll
+    for (int c = 1; c < 15; ++c) mx = fmaxf(mx, z[c]);
+    float p[15], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) { p[c] = expf(z[c] - mx); s += p[c]; }
+    const float inv = 1.f / s;
+    const int yi = y[row];
+    int best = 0; float bp = -1.f, py = 0.f, zy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        p[c] *= inv;
+        if (p[c] > bp) { bp = p[c]; best = c; }
+        if (c == yi) { py = p[c]; zy = z[c]; }
+        probs[(size_t)row * 16 + c] = p[c];
+    }
+    const float loss = -(zy - mx - logf(s));                       // -log softmax, stable
+    if (loss_rows) loss_rows[row] = loss;
+    if (dlog) {
+        const float in = 1.f / (float)n;
+#pragma unroll
+        for (int c = 0; c < 15; ++c) dlog[(size_t)row * 16 + c] = (p[c] - (c == yi ? 1.f : 0.f)) * in;
+        dlog[(size_t)row * 16 + 15] = 0.f;
+    }
+    if (eval_acc) {
+        atomicAdd(&eval_acc[0], (double)loss);
+        if (best == yi) atomicAdd(&eval_acc[1], 1.0);
+    }
+    (void)py;
+}
+
+__global__ void mean_kernel(const float* v, int n, float* out) {
+    __shared__ double s_red[4];
+    double s = 0;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) s += v[e];
+    s = block_sum(s, s_red);
+    if (threadIdx.x == 0) out[0] = (float)(s / n);
+}
+
+// g[n][ldg] *= (act[n][lda] > 0) [* mask*2]   (ReLU backward, optionally through a dropout in front of it)
+__global__ void relu_mask_kernel(float* g, int ldg, const float* act, int lda, const uint8_t* mask, int n, int cols) {
+    const long total = (long)n * cols;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / cols; const int c = (int)(e - r * cols);
+        float v = g[r * ldg + c];
+        if (mask) v = mask[e] ? v * 2.f : 0.f;
+        g[r * ldg + c] = act[r * lda + c] > 0.f ? v : 0.f;
+    }
+}
+
+// g[t][n][540] = g * mask5[t] * 2 (dropout in front of d1), all towers
+__global__ void dropout_bwd_kernel(Ptr3 g, const uint8_t* mask, int n) {
+    const int t = blockIdx.y;
+    float* p = sel3(g.p, t);
+    const long total = (long)n * kFlat;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+        p[e] = mask[(size_t)t * total + e] ? p[e] * 2.f : 0.f;
+}
+
+// out[j] = sum_r g[r][ldg + j]
+__global__ void colsum_kernel(const float* g, int ldg, int n, int cols, float* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    double s = 0;
+    for (int r = 0; r < n; ++r) s += g[(size_t)r * ldg + j];
+    out[j] = (float)s;
+}
+
+// ---- generic strided SGEMM on the vector ALU: C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
+struct SgemmProblem { const float* A; long sam, sak; const float* B; long sbk, sbn; float* C; long ldc; };
+struct SgemmArgs { SgemmProblem p[kTowers]; int M, N, K; };
+
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
+    __shared__ float sA[16][65], sB[16][65];
+    const int z = blockIdx.z;
+    const SgemmProblem P = z == 0 ? g.p[0] : (z == 1 ? g.p[1] : g.p[2]);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int kk = e & 15, mm = e >> 4;               // consecutive threads walk k (fast when sak == 1) ...
+            const int m = m0 + mm, k = k0 + kk;
+            sA[kk][mm] = (m < g.M && k < g.K) ? P.A[m * P.sam + k * P.sak] : 0.f;
+            const int nn = e & 63, kb = e >> 6;               // ... and n for B (fast when sbn == 1)
+            const int n = n0 + nn, k2 = k0 + kb;
+            sB[kb][nn] = (n < g.N && k2 < g.K) ? P.B[k2 * P.sbk + n * P.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty * 4 + i]; b[i] = sB[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < g.M && n < g.N) P.C[m * P.ldc + n] = acc[i][j];
+        }
+}
+
+static void sgemm(const SgemmArgs& g, int nprob, hipStream_t st) {
+    dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, nprob);
+    hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, st, g);
+}
+
+// ---- BN backward.  dy(n,c,y,x) = dOut routed through max-pool (every tied maximum receives it, as Theano's
+// MaxPoolGrad does) and ReLU.
+template <bool POOL>
+__device__ __forceinline__ float bn_dy(const float* __restrict__ z, const float* __restrict__ dout, long nc, int H, int y, int x,
+                                      float sc, float sh, float* xhat_out, float mean, float inv) {
+    const float zv = z[nc * H * H + y * H + x];
+    const float yv = fmaf(zv, sc, sh);
+    *xhat_out = (zv - mean) * inv;
+    if (POOL) {
+        const int HO = H / 2, wy = y >> 1, wx = x >> 1;
+        const float* zp = z + nc * H * H + (2 * wy) * H + 2 * wx;
+        const float m = fmaxf(fmaxf(fmaf(zp[0], sc, sh), fmaf(zp[1], sc, sh)), fmaxf(fmaf(zp[H], sc, sh), fmaf(zp[H + 1], sc, sh)));
+        return (yv == m && m > 0.f) ? dout[nc * HO * HO + wy * HO + wx] : 0.f;
+    }
+    return yv > 0.f ? dout[nc * H * H + y * H + x] : 0.f;
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(CPtr3 Z, CPtr3 dOut, int n, int C, int H, float* stats, int layer,
+                                                           const float* params, float* grads, int bn_off0, int tower_stride) {
+    __shared__ double s_red[4];
+    const int c = blockIdx.x, t = blockIdx.y;
+    const float* __restrict__ z = sel3(Z.p, t);
+    const float* __restrict__ d = sel3(dOut.p, t);
+    float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+    const float* bn = params + bn_off0 + t * tower_stride;
+    const float mean = st[c], inv = st[64 + c], sc = bn[C + c] * inv, sh = bn[c] - mean * sc;
+    const int pix = H * H;
+    double sb = 0, sg = 0;
+    const long total = (long)n * pix;
+    for (long e = threadIdx.x; e < total; e += blockDim.x) {
+        const long ni = e / pix; const int p = (int)(e - ni * pix);
+        float xh;
+        const float dy = bn_dy<POOL>(z, d, ni * C + c, H, p / H, p % H, sc, sh, &xh, mean, inv);
+        sb += dy; sg += (double)dy * xh;
+    }
+    sb = block_sum(sb, s_red);
+    sg = block_sum(sg, s_red);
+    if (threadIdx.x == 0) {
+        st[128 + c] = (float)sb; st[192 + c] = (float)sg;
+        float* gb = grads + bn_off0 + t * tower_stride;
+        gb[c] = (float)sb; gb[C + c] = (float)sg;             // d beta, d gamma (mean / inv_std stay 0)
+    }
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, Ptr3 dZ, int n, int C, int H, const float* stats,
+                                                          int layer, const float* params, int bn_off0, int tower_stride) {
+    const int t = blockIdx.y;
+    const float* __restrict__ z = sel3(Z.p, t);
+    const float* __restrict__ d = sel3(dOut.p, t);
+    float* __restrict__ dz = sel3(dZ.p, t);
+    const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+    const float* bn = params + bn_off0 + t * tower_stride;
+    const int pix = H * H;
+    const float invM = 1.f / ((float)n * pix);
+    const long total = (long)n * C * pix;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long nc = e / pix; const int p = (int)(e - nc * pix), c = (int)(nc % C);
+        const float mean = st[c], inv = st[64 + c], sc = bn[C + c] * inv, sh = bn[c] - mean * sc;
+        float xh;
+        const float dy = bn_dy<POOL>(z, d, nc, H, p / H, p % H, sc, sh, &xh, mean, inv);
+        dz[e] = sc * (dy - st[128 + c] * invM - xh * st[192 + c] * invM);
+    }
+}
+
+// weight gradient of a true convolution: dW[o][c][2-dy][2-dx] = sum_{n,y,x} dz[n][o][y][x] * X[n][c][y+dy][x+dx]
+// one workgroup per (c, o, tower); the (n, pixel) sum is spread over the threads (L1/L2 serve the 9-tap re-reads)
+__global__ __launch_bounds__(256) void wgrad_kernel(CPtr3 X, CPtr3 dZ, int n, int Cin, int Cout, int HIN, float* grads, int w_off0,
+                                                   int tower_stride) {
+    __shared__ double s_red[4];
+    const int c = blockIdx.x, o = blockIdx.y, t = blockIdx.z;
+    const float* __restrict__ x = sel3(X.p, t);
+    const float* __restrict__ dz = sel3(dZ.p, t);
+    const int HO = HIN - 2, pix = HO * HO;
+    float acc[9] = {};
+    const long total = (long)n * pix;
+    for (long e = threadIdx.x; e < total; e += blockDim.x) {
+        const long ni = e / pix; const int p = (int)(e - ni * pix), y = p / HO, xx = p - y * HO;
+        const float d = dz[(ni * Cout + o) * pix + p];
+        const float* xb = x + ((ni * Cin + c) * HIN + y) * HIN + xx;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = fmaf(d, xb[(k / 3) * HIN + k % 3], acc[k]);
+    }
+    float* gw = grads + w_off0 + t * tower_stride + (o * Cin + c) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double s = block_sum((double)acc[k], s_red);
+        if (threadIdx.x == 0) gw[(2 - k / 3) * 3 + (2 - k % 3)] = (float)s;
+    }
+}
+
+// lasagne.updates.adam over the arena
+__global__ void adam_kernel(float* p, float* g, float* m, float* v, int n, float a_t, float b1, float b2, float eps, float gscale) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const float gr = g[e] * gscale;
+        const float mn = b1 * m[e] + (1.f - b1) * gr;
+        const float vn = b2 * v[e] + (1.f - b2) * gr * gr;
+        m[e] = mn; v[e] = vn;
+        p[e] -= a_t * mn / (sqrtf(vn) + eps);
+    }
+}
+
+static int set_train_attrs() {
+    static bool done = false;
+    if (done) return SCS_OK;
+    SCS_HIP(conv_set_attr<TF2>()); SCS_HIP(conv_set_attr<TF3>()); SCS_HIP(conv_set_attr<TF4>()); SCS_HIP(conv_set_attr<TF5>());
+    SCS_HIP(conv_set_attr<DG5>()); SCS_HIP(conv_set_attr<DG4>()); SCS_HIP(conv_set_attr<DG3>()); SCS_HIP(conv_set_attr<DG2>());
+    done = true;
+    return SCS_OK;
+}
+
+static inline dim3 ew_grid(long total) { long b = (total + 255) / 256; return dim3((unsigned)(b < 4096 ? (b > 0 ? b : 1) : 4096)); }
+
+}  // namespace scs
+
+using namespace scs;
+
 extern "C" {
-int scs_train_step(scs_handle, const float*, const float*, const float*, const float*, const uint8_t*, int64_t,
-                   uint64_t, const uint8_t*, float*, void*) {
-    scs::set_error("scs_train_step: not built yet");
-    return SCS_ERR_STATE;
+
+int scs_train_step(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, const uint8_t* y,
+                   int64_t n64, uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(n64 > 0 && n64 <= (1 << 20), "n out of range");
+    SCS_ARG(ax && co && sa && atlas && y, "null input pointer");
+    if (!h->has_params) { set_error("scs_train_step before scs_set_params"); return SCS_ERR_STATE; }
+    SCS_HIP(hipSetDevice(h->device));
+    int rc = set_train_attrs();
+    if (rc != SCS_OK) return rc;
+    const int n = (int)n64;
+    rc = train_ensure(h, n);
+    if (rc != SCS_OK) return rc;
+    TrainWs* w = h->tws;
+    hipStream_t st = (hipStream_t)stream;
+    float* P = h->params;
+    float* G = h->grads;
+    constexpr HeadOff H = head_off();
+    constexpr TowerOff T0 = tower_off(0);
+    const float* xin[kTowers] = {ax, co, sa};
+
+    SCS_HIP(hipMemsetAsync(G, 0, (size_t)SCS_N_PARAMS * sizeof(float), st));
+
+    // ---- masks
+    const uint8_t* masks = masks_dev;
+    if (!masks) {
+        const size_t total = (size_t)n * kFlat * 5;
+        hipLaunchKernelGGL(dropout_mask_kernel, ew_grid((long)total), dim3(256), 0, st, w->masks, total, dropout_seed);
+        masks = w->masks;
+    }
+    const uint8_t* mask5 = masks;                                  // [3][n][540]
+    const uint8_t* mask1 = masks + (size_t)3 * n * kFlat;          // f1_drop [n][540]
+    const uint8_t* mask2 = mask1 + (size_t)n * kFlat;              // f2_drop [n][540]
+
+    // ---- per-step operand packs (unfolded)
+    PackJobs jobs;
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        for (int i = 0; i < kConvs; ++i) jobs.j[t * kConvs + i] = PackJob{P + T.convW[i], w->wpk[t][i], w->wdg[t][i], kCin[i], kCout[i]};
+    }
+    hipLaunchKernelGGL(pack_train_kernel, dim3(8, kTowers * kConvs), dim3(256), 0, st, jobs);
+
+    // ---- forward, training mode
+    auto c3 = [&](auto& a, int i) { CPtr3 r; for (int t = 0; t < kTowers; ++t) r.p[t] = a[t][i]; return r; };
+    auto p3 = [&](auto& a, int i) { Ptr3 r; for (int t = 0; t < kTowers; ++t) r.p[t] = a[t][i]; return r; };
+    for (int i = 0; i < kConvs; ++i) {
+        if (i == 0) {
+            CPtr3 in{{ax, co, sa}}, wp{{w->wpk[0][0], w->wpk[1][0], w->wpk[2][0]}};
+            hipLaunchKernelGGL(conv1_raw_kernel, dim3(n, kTowers), dim3(256), 0, st, in, wp, p3(w->Z, 0));
+        } else {
+            ConvArgs a{};
+            a.n = n;
+            for (int t = 0; t < kTowers; ++t) { a.in[t] = w->X[t][i]; a.w[t] = w->wpk[t][i]; a.bias[t] = nullptr; a.out[t] = w->Z[t][i]; }
+            if (i == 1) conv_launch<TF2>(a, st);
+            else if (i == 2) conv_launch<TF3>(a, st);
+            else if (i == 3) conv_launch<TF4>(a, st);
+            else conv_launch<TF5>(a, st);
+        }
+        const int C = kCout[i], Hh = kHout[i];
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, kTowers), dim3(256), 0, st, c3(w->Z, i), n, C, Hh * Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
+        Ptr3 out;
+        for (int t = 0; t < kTowers; ++t) out.p[t] = (i == kConvs - 1) ? w->H5[t] : w->X[t][i + 1];
+        const long tot = (long)n * C * (kPool[i] ? (Hh / 2) * (Hh / 2) : Hh * Hh);
+        dim3 g(ew_grid(tot).x, kTowers);
+        if (kPool[i])
+            hipLaunchKernelGGL(bn_relu_kernel<true>, g, dim3(256), 0, st, c3(w->Z, i), out, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats, (const uint8_t*)nullptr);
+        else
+            hipLaunchKernelGGL(bn_relu_kernel<false>, g, dim3(256), 0, st, c3(w->Z, i), out, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats,
+                               (i == kConvs - 1) ? mask5 : (const uint8_t*)nullptr);
+    }
+    // dense head (weights straight from the arena: [K][N] row-major)
+    GemmArgs g{};
+    g.M = n; g.K4 = kFlat; g.K = kFlat; g.N = kD1; g.relu = 1;
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        g.p[t] = GemmProblem{w->H5[t], kFlat, P + T.d1W, kD1, P + T.d1b, w->feat + t * kD1, kFlat};
+    }
+    gemm_launch(g, kTowers, st);
+    hipLaunchKernelGGL(dropout_apply_kernel, ew_grid((long)n * kFlat), dim3(256), 0, st, w->feat, kFlat, w->featd, kFlat, mask1, n, kFlat);
+    g.K4 = kFC1; g.K = kFC1; g.N = kFC1;
+    g.p[0] = GemmProblem{w->featd, kFlat, P + H.fc1W, kFC1, P + H.fc1b, w->R1, kFC1};
+    gemm_launch(g, 1, st);
+    hipLaunchKernelGGL(dropout_apply_kernel, ew_grid((long)n * kFC1), dim3(256), 0, st, w->R1, kFC1, w->cat2, kFC1ld, mask2, n, kFC1);
+    hipLaunchKernelGGL(atlas_cols_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, w->cat2, n);   // cols 540..555
+    g.K4 = kFC1ld; g.K = kFC1 + kAtlas; g.N = kFC2;
+    g.p[0] = GemmProblem{w->cat2, kFC1ld, P + H.fc2W, kFC2, P + H.fc2b, w->R2, kFC2ld};
+    gemm_launch(g, 1, st);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, y, n, w->probs,
+                       w->dlog, w->loss_rows, (double*)nullptr);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, w->loss_rows, n, w->loss_dev);
+
+    // ---- backward: dense head
+    SgemmArgs s{};
+    // out_layer
+    s.M = kFC2; s.N = kClasses; s.K = n;
+    s.p[0] = SgemmProblem{w->R2, 1, kFC2ld, w->dlog, 16, 1, G + H.outW, kClasses};
+    sgemm(s, 1, st);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, st, w->dlog, 16, n, kClasses, G + H.outb);
+    s.M = n; s.N = kFC2; s.K = kClasses;
+    s.p[0] = SgemmProblem{w->dlog, 16, 1, P + H.outW, 1, kClasses, w->dR2, kFC2ld};
+    sgemm(s, 1, st);
+    hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC2), dim3(256), 0, st, w->dR2, kFC2ld, w->R2, kFC2ld, (const uint8_t*)nullptr, n, kFC2);
+    // fc_2
+    s.M = kFC1 + kAtlas; s.N = kFC2; s.K = n;
+    s.p[0] = SgemmProblem{w->cat2, 1, kFC1ld, w->dR2, kFC2ld, 1, G + H.fc2W, kFC2};
+    sgemm(s, 1, st);
+    hipLaunchKernelGGL(colsum_kernel, dim3((kFC2 + 63) / 64), dim3(64), 0, st, w->dR2, kFC2ld, n, kFC2, G + H.fc2b);
+    s.M = n; s.N = kFC1; s.K = kFC2;
+    s.p[0] = SgemmProblem{w->dR2, kFC2ld, 1, P + H.fc2W, 1, kFC2, w->dcat, kFC1};
+    sgemm(s, 1, st);
+    hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC1), dim3(256), 0, st, w->dcat, kFC1, w->R1, kFC1, mask2, n, kFC1);
+    // FC1
+    s.M = kFlat; s.N = kFC1; s.K = n;
+    s.p[0] = SgemmProblem{w->featd, 1, kFlat, w->dcat, kFC1, 1, G + H.fc1W, kFC1};
+    sgemm(s, 1, st);
+    hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64), dim3(64), 0, st, w->dcat, kFC1, n, kFC1, G + H.fc1b);
+    s.M = n; s.N = kFlat; s.K = kFC1;
+    s.p[0] = SgemmProblem{w->dcat, kFC1, 1, P + H.fc1W, 1, kFC1, w->dfeat, kFlat};
+    sgemm(s, 1, st);
+    hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFlat), dim3(256), 0, st, w->dfeat, kFlat, w->feat, kFlat, mask1, n, kFlat);
+    // d1 x3
+    s.M = kFlat; s.N = kD1; s.K = n;
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        s.p[t] = SgemmProblem{w->H5[t], 1, kFlat, w->dfeat + t * kD1, kFlat, 1, G + T.d1W, kD1};
+    }
+    sgemm(s, kTowers, st);
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        hipLaunchKernelGGL(colsum_kernel, dim3((kD1 + 63) / 64), dim3(64), 0, st, w->dfeat + t * kD1, kFlat, n, kD1, G + T.d1b);
+    }
+    s.M = n; s.N = kFlat; s.K = kD1;
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        s.p[t] = SgemmProblem{w->dfeat + t * kD1, kFlat, 1, P + T.d1W, 1, kD1, w->dX[t][0], kFlat};
+    }
+    sgemm(s, kTowers, st);
+    {
+        Ptr3 gp{{w->dX[0][0], w->dX[1][0], w->dX[2][0]}};
+        hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid((long)n * kFlat).x, kTowers), dim3(256), 0, st, gp, mask5, n);
+    }
+
+    // ---- backward: conv blocks 5..1 (dX ping-pongs between the two buffers)
+    int cur = 0;
+    for (int i = kConvs - 1; i >= 0; --i) {
+        const int C = kCout[i], Hh = kHout[i];
+        CPtr3 Zi = c3(w->Z, i), dOut{{w->dX[0][cur], w->dX[1][cur], w->dX[2][cur]}};
+        Ptr3 dZ{{w->dZ[0], w->dZ[1], w->dZ[2]}};
+        const long tot = (long)n * C * Hh * Hh;
+        if (kPool[i]) {
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(C, kTowers), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, G, T0.bn[i], kTowerFloats);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(C, kTowers), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, G, T0.bn[i], kTowerFloats);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
+        }
+        CPtr3 Xi;
+        for (int t = 0; t < kTowers; ++t) Xi.p[t] = (i == 0) ? xin[t] : w->X[t][i];
+        CPtr3 dZc{{w->dZ[0], w->dZ[1], w->dZ[2]}};
+        hipLaunchKernelGGL(wgrad_kernel, dim3(kCin[i], C, kTowers), dim3(256), 0, st, Xi, dZc, n, kCin[i], C, kHin[i], G, T0.convW[i], kTowerFloats);
+        if (i > 0) {
+            ConvArgs a{};
+            a.n = n;
+            for (int t = 0; t < kTowers; ++t) { a.in[t] = w->dZ[t]; a.w[t] = w->wdg[t][i]; a.bias[t] = nullptr; a.out[t] = w->dX[t][cur ^ 1]; }
+            if (i == 4) conv_launch<DG5>(a, st);
+            else if (i == 3) conv_launch<DG4>(a, st);
+            else if (i == 2) conv_launch<DG3>(a, st);
+            else conv_launch<DG2>(a, st);
+            cur ^= 1;
+        }
+    }
+    SCS_HIP(hipGetLastError());
+    h->packed_dirty = true;          // BN running statistics moved
+    if (loss_host) {
+        SCS_HIP(hipMemcpyAsync(loss_host, w->loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
+        SCS_HIP(hipStreamSynchronize(st));
+    }
+    return SCS_OK;
 }
-int scs_adam_apply(scs_handle, float, float, float, float, float, void*) {
-    scs::set_error("scs_adam_apply: not built yet");
-    return SCS_ERR_STATE;
+
+int scs_adam_apply(scs_handle h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    if (!h->has_params) { set_error("scs_adam_apply before scs_set_params"); return SCS_ERR_STATE; }
+    SCS_HIP(hipSetDevice(h->device));
+    h->adam_t += 1;
+    const double t = (double)h->adam_t;
+    const float a_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+    hipLaunchKernelGGL(adam_kernel, dim3(864), dim3(256), 0, (hipStream_t)stream, h->params, h->grads, h->adam_m, h->adam_v,
+                       SCS_N_PARAMS, a_t, beta1, beta2, eps, grad_scale);
+    SCS_HIP(hipGetLastError());
+    h->packed_dirty = true;
+    return SCS_OK;
 }
-int scs_eval_batch(scs_handle, const float*, const float*, const float*, const float*, const uint8_t*, int64_t,
-                   double*, int64_t*, void*) {
-    scs::set_error("scs_eval_batch: not built yet");
-    return SCS_ERR_STATE;
+
+int scs_eval_batch(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, const uint8_t* y,
+                   int64_t n, double* loss_sum_host, int64_t* n_correct_host, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(n >= 0, "n < 0");
+    SCS_ARG(loss_sum_host && n_correct_host, "null output pointer");
+    *loss_sum_host = 0.0; *n_correct_host = 0;
+    if (n == 0) return SCS_OK;
+    SCS_ARG(ax && co && sa && atlas && y, "null input pointer");
+    if (!h->has_params) { set_error("scs_eval_batch before scs_set_params"); return SCS_ERR_STATE; }
+    SCS_HIP(hipSetDevice(h->device));
+    int rc = train_ensure(h, 1);
+    if (rc != SCS_OK) return rc;
+    rc = ensure_workspace(h);
+    if (rc != SCS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
+    TrainWs* w = h->tws;
+    SCS_HIP(hipMemsetAsync(w->eval_acc, 0, 2 * sizeof(double), st));
+    constexpr HeadOff H = head_off();
+    for (int64_t s = 0; s < n; s += h->chunk) {
+        const int m = (int)((n - s < h->chunk) ? (n - s) : h->chunk);
+        rc = forward_chunk(h, ax + s * 1024, co + s * 1024, sa + s * 1024, atlas + s * 15, nullptr, 0, 0, 0, nullptr, nullptr, m,
+                           nullptr, nullptr, st, nullptr);
+        if (rc != SCS_OK) return rc;
+        // loss / accuracy from the fc_2 activations of this chunk (probs scratch = logits buffer)
+        hipLaunchKernelGGL(softmax_ce_kernel, dim3((m + 255) / 256), dim3(256), 0, st, h->a_fc2, h->params + H.outW, h->params + H.outb,
+                           y + s, m, h->a_logits, (float*)nullptr, (float*)nullptr, w->eval_acc);
+    }
+    double acc[2];
+    SCS_HIP(hipMemcpyAsync(acc, w->eval_acc, sizeof(acc), hipMemcpyDeviceToHost, st));
+    SCS_HIP(hipStreamSynchronize(st));
+    *loss_sum_host = acc[0];
+    *n_correct_host = (int64_t)(acc[1] + 0.5);
+    return SCS_OK;
 }
-}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""Training path on the MI355X against the float64 oracle: one step (loss, every gradient, BN running
+statistics, Adam update), labelled evaluation, and the fit() loop.  float32 kernels vs float64 oracle:
+gradients agree to a few 1e-4 of each array's scale (tolerance 3e-3 written below)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold
+from cnn_cort import dist, params as P
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+GRAD_RTOL = 3e-3
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to('cuda:0', dtype=dtype)
+
+
+def arena(handle, which):
+    ptr, n = handle.grad_arena() if which == 'grad' else handle.param_arena()
+    torch.cuda.synchronize()
+    return dist.wrap_device_floats(ptr, n, 0).cpu().numpy().copy()
+
+
+def pack_masks(masks):
+    m5 = np.stack([masks['%s_l1drop' % t].reshape(masks['f1_drop'].shape[0], 540) for t in P.TOWERS])
+    return np.concatenate([m5.ravel(), masks['f1_drop'].ravel(), masks['f2_drop'].ravel()]).astype(np.uint8)
+
+
+@pytest.fixture()
+def fresh(weights):
+    from cnn_cort import _hip
+    h = _hip.Handle(0)
+    h.set_params(P.params_to_flat(weights))
+    yield h
+    h.close()
+
+
+def test_one_training_step_matches_oracle(fresh, weights):
+    g = gold('g5_train.npz')
+    n = g['ax'].shape[0]
+    masks = {k[5:]: g[k] for k in g.files if k.startswith('mask_')}
+    loss_ref, grads_ref, bn_ref, probs_ref = O.train_forward_backward(weights, g['ax'], g['co'], g['sa'], g['atlas'], g['y'], masks)
+    st = torch.cuda.current_stream().cuda_stream
+    loss = fresh.train_step(dev(g['ax']), dev(g['co']), dev(g['sa']), dev(g['atlas']), dev(g['y'], torch.uint8), n,
+                            masks=dev(pack_masks(masks), torch.uint8), stream=st)
+    assert abs(loss - loss_ref) <= 2e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    got = P.flat_to_params(arena(fresh, 'grad'))
+    worst = 0.0
+    for name, shapes in P.LAYER_SPEC:
+        for i, _ in enumerate(shapes):
+            ref = np.asarray(grads_ref[name][i])
+            scale = max(np.abs(ref).max(), 1e-6)
+            err = np.abs(got[name][i] - ref).max() / scale
+            worst = max(worst, err)
+            assert err <= GRAD_RTOL, '%s[%d]: rel err %g (scale %g)' % (name, i, err, scale)
+    print('worst relative gradient error', worst)
+    # BN running statistics after the step (alpha = 0.1)
+    newp = P.flat_to_params(arena(fresh, 'param'))
+    run = O.bn_running_update(weights, bn_ref)
+    for name in bn_ref:
+        assert np.abs(newp[name][2] - run[name][2]).max() <= 1e-4 * max(1.0, np.abs(run[name][2]).max()), name
+        assert np.abs(newp[name][3] - run[name][3]).max() <= 1e-4 * max(1.0, np.abs(run[name][3]).max()), name
+    # Adam (first step: |delta| ~ lr for every parameter with a gradient)
+    fresh.adam_apply(stream=st)
+    after = P.flat_to_params(arena(fresh, 'param'))
+    ref_after = O.bn_running_update(O.adam_step(weights, grads_ref, {}, trainable=P.is_trainable), bn_ref)
+    for name, shapes in P.LAYER_SPEC:
+        for i, _ in enumerate(shapes):
+            d_ref = np.asarray(ref_after[name][i]) - np.asarray(weights[name][i], np.float64)
+            d_got = after[name][i].astype(np.float64) - np.asarray(weights[name][i], np.float64)
+            big = np.abs(np.asarray(grads_ref[name][i])) > 1e-6 * max(np.abs(np.asarray(grads_ref[name][i])).max(), 1e-12)
+            if P.is_trainable(name, i) and big.any():
+                assert np.abs(d_got[big] - d_ref[big]).max() <= 5e-5, name      # steps are ~1e-3
+    assert all(np.array_equal(after[k][0], weights[k][0]) for k, s in P.LAYER_SPEC if 'prelu' in k)   # zero gradient
+
+
+def test_eval_batch_and_generated_masks(fresh, weights):
+    g = gold('g3_classes.npz')
+    n = g['ax'].shape[0]
+    y = g['probs'].argmax(1).astype(np.uint8)
+    y[::5] = (y[::5] + 1) % 15                                                   # some wrong labels
+    ref = O.forward(weights, g['ax'], g['co'], g['sa'], g['atlas'])
+    ref_loss = float(-np.log(ref[np.arange(n), y]).sum())
+    ref_correct = int((ref.argmax(1) == y).sum())
+    st = torch.cuda.current_stream().cuda_stream
+    args = [dev(g['ax']), dev(g['co']), dev(g['sa']), dev(g['atlas']), dev(y, torch.uint8)]
+    ls, nc = fresh.eval_batch(*args, n, stream=st)
+    assert nc == ref_correct
+    assert abs(ls - ref_loss) <= 1e-3 * max(1.0, abs(ref_loss))
+    # generated dropout masks: same seed -> same loss, different seed -> different loss, both finite
+    l1 = fresh.train_step(*args, n, seed=11, stream=st)
+    g1 = arena(fresh, 'grad')
+    fresh.set_params(P.params_to_flat(weights))
+    l2 = fresh.train_step(*args, n, seed=11, stream=st)
+    g2 = arena(fresh, 'grad')
+    fresh.set_params(P.params_to_flat(weights))
+    l3 = fresh.train_step(*args, n, seed=12, stream=st)
+    assert np.isfinite([l1, l2, l3]).all() and l1 == l2 and l1 != l3
+    assert np.array_equal(g1, g2)
+
+
+def test_fit_learns_and_keeps_the_history_schema(tmp_path):
+    """A separable toy problem: label = argmax of the atlas row -> loss falls within a few epochs."""
+    from cnn_cort.nets import Net
+    from cnn_cort import synth
+    n = 768
+    ax, co, sa, at = synth.patch_batch(n, seed=5)
+    y = at.argmax(1).astype(np.uint8)
+    at = (0.1 * at + 0.9 * np.eye(15, dtype=np.float32)[y]).astype(np.float32)
+    net = Net(weights_file=str(tmp_path / 'w.pkl'), history_file=str(tmp_path / 'h.pkl'), max_epochs=15, patience=20,
+              eval_size=0.25, batch_size=128, verbose=0, device=0, seed=1)
+    net.fit({'in1': ax, 'in2': co, 'in3': sa, 'in4': at}, y)
+    h = net.train_history_
+    print([(r['epoch'], round(r['train_loss'], 3), round(r['valid_loss'], 3), round(r['valid_accuracy'], 3)) for r in h])
+    assert len(h) == 15
+    assert set(h[0]) == {'epoch', 'train_loss', 'train_loss_best', 'valid_loss', 'valid_loss_best', 'valid_accuracy', 'dur'}
+    assert h[-1]['train_loss'] < h[0]['train_loss']
+    assert h[-1]['train_loss'] < 0.6 * h[0]['train_loss']
+    assert min(r['valid_loss'] for r in h) < h[0]['valid_loss'] and max(r['valid_accuracy'] for r in h) > 0.3
+    assert (tmp_path / 'w.f32').exists() and (tmp_path / 'h.json').exists()
+    # saved best weights reload and predict
+    net2 = Net(device=0)
+    net2.load_params_from(str(tmp_path / 'w.pkl'))
+    X = {'in1': ax[:64], 'in2': co[:64], 'in3': sa[:64], 'in4': at[:64]}
+    p = net2.predict_proba(X)
+    assert p.shape == (64, 15) and np.abs(p.sum(1) - 1).max() < 1e-5
+    assert np.array_equal(net2.predict(X), p.argmax(1))

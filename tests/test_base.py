@@ -1,0 +1,207 @@
+"""Host-side data path (cnn_cort.base / nifti / load_options / nets host logic) against the literal restatement
+of the reference's helpers (oracle/patches_ref.py) and the committed g6 fixtures.  CPU only."""
+import configparser
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import gold, GOLD
+from cnn_cort import base, nifti, synth
+from cnn_cort.load_options import load_options, is_true
+from cnn_cort.nets import stratified_first_fold, EarlyStopping
+from oracle import patches_ref as R
+
+
+@pytest.mark.parametrize('mode', ['axial', 'coronal', 'saggital'])
+def test_get_patches_equals_the_literal_restatement(mode):
+    vol = np.random.RandomState(0).randn(20, 23, 17).astype(np.float32)
+    rng = np.random.RandomState(1)
+    centers = [tuple(int(v) for v in rng.randint(0, s, 3)) for s in [vol.shape] * 40]
+    centers += [(0, 0, 0), (19, 22, 16), (0, 22, 0), (19, 0, 16)]          # every face / corner: zero padding
+    ref = np.array(R.get_patches(vol, centers, (32, 32), mode=mode))
+    got = base.get_patches(vol, centers, (32, 32), mode=mode)
+    assert got.shape == (44, 32, 32) and got.dtype == vol.dtype
+    assert np.array_equal(got, ref)
+    c = centers[5]                                                           # centre voxel lands at [16][16]
+    assert got[5, 16, 16] == vol[c]
+    assert base.get_patches(vol, [], (32, 32), mode=mode).shape == (0, 32, 32)
+
+
+def test_get_mask_voxels_order_and_seeded_shuffle():
+    m = np.random.RandomState(2).rand(6, 7, 5) > 0.6
+    ref = R.get_mask_voxels(m)
+    got = base.get_mask_voxels(m)
+    assert np.array_equal(got, np.asarray(ref))
+    x, y, z = np.stack(got, axis=1)                                          # the reference's scatter idiom (base.py:430)
+    assert m[x, y, z].all()
+    ref_s = R.get_mask_voxels(m, size=10, rng=random.Random(7))
+    got_s = base.get_mask_voxels(m, size=10, rng=random.Random(7))
+    assert np.array_equal(got_s, np.asarray(ref_s))
+
+
+def test_g6_inference_batches_match_fixture():
+    g = gold('g6_toy.npz')
+    vol, atlas, roi = g['volume'], g['atlas4d'], g['roi'].astype(bool)
+    vn = base._zscore(vol, False)
+    assert vn.dtype == np.float64                                            # integer T1 -> float64 arithmetic (base.py:358)
+    centers = base.get_mask_voxels(roi)
+    assert np.array_equal(centers, g['centers'])
+    assert np.array_equal(base.atlas_vectors_at(atlas, centers), g['atlas_vec'])
+    assert (g['atlas_vec'].sum(1) > 0).all() and (g['atlas_vec'][:, 14] == 1).any()   # zero rows became background
+    for nm, mode in (('ax', 'axial'), ('co', 'coronal'), ('sa', 'saggital')):
+        p = base.get_patches(vn, centers, (32, 32), mode=mode).astype(np.float32)[:, None]
+        assert np.allclose(p.astype(np.float64).sum(axis=(1, 2, 3)), g['sum_' + nm], rtol=0, atol=1e-9)
+        assert np.array_equal(p[:4], g['first_' + nm]) and np.array_equal(p[-4:], g['last_' + nm])
+
+
+def test_g6_training_set_assembly_matches_fixture():
+    g = gold('g6_toy.npz')
+    vol, atlas, labels = g['volume'], g['atlas4d'], g['labels']
+    im = base._zscore(vol, True)
+    assert im.dtype == np.float32 or im.dtype == np.float64
+    pos = base.get_mask_voxels(np.logical_and(labels > 0, labels < 15))
+    neg = base.get_mask_voxels(labels == 15, size=len(pos), rng=random.Random(1234))
+    cent = np.concatenate([pos, neg])
+    assert np.array_equal(cent, g['train_centers'])
+    xs = [np.concatenate([base.get_patches(im, pos, (32, 32), m), base.get_patches(im, neg, (32, 32), m)]) for m in ('axial', 'coronal', 'saggital')]
+    y_ax = np.concatenate([base.get_patches(labels, pos, (32, 32), 'axial'), base.get_patches(labels, neg, (32, 32), 'axial')])
+    atl = atlas[cent[:, 0], cent[:, 1], cent[:, 2]]
+    xa, xc, xsg, xt, yt = base.generate_training_set([xs[0]], [xs[1]], [xs[2]], [atl], [y_ax], {'seed': 777, 'debug': 'False'})
+    assert xa.shape[1:] == (1, 32, 32) and xa.dtype == np.float32 and yt.dtype == np.uint8
+    assert np.array_equal(yt, g['train_y']) and yt.max() <= 14                   # 15 -> 0 (base.py:88-89)
+    assert np.array_equal(xt, g['train_atlas'])
+    assert np.allclose(xa.astype(np.float64).sum(axis=(1, 2, 3)), g['train_sum_ax'], atol=1e-9)
+    assert np.allclose(xc.astype(np.float64).sum(axis=(1, 2, 3)), g['train_sum_co'], atol=1e-9)
+    assert np.allclose(xsg.astype(np.float64).sum(axis=(1, 2, 3)), g['train_sum_sa'], atol=1e-9)
+    assert np.array_equal(xa[:2], g['train_first_ax'])
+    un = base.generate_training_set([xs[0]], [xs[1]], [xs[2]], [atl], [y_ax], {'debug': 'False'}, randomize=False)
+    assert np.array_equal(un[0][:, 0], xs[0].astype(np.float32))
+
+
+def test_post_processing_matches_restatement_including_its_quirk():
+    g = gold('g6_toy.npz')
+    out = base.post_process_mask(g['pp_in'], g['pp_mask'].astype(bool))
+    assert np.array_equal(out, g['pp_out'])
+    assert np.array_equal(out, R.post_process_segmentation(g['pp_in'], g['pp_mask'].astype(bool)))
+
+
+def test_nifti_roundtrip_and_scaling(tmp_path):
+    a = (np.random.RandomState(3).rand(5, 6, 7) * 100).astype(np.int16)
+    nifti.save(a, str(tmp_path / 'a.nii.gz'), affine=np.diag([1.0, 2.0, 3.0, 1.0]))
+    img = nifti.load(str(tmp_path / 'a.nii.gz'))
+    assert img.get_data().dtype == np.int16 and np.array_equal(img.get_data(), a)
+    assert np.allclose(img.affine, np.diag([1.0, 2.0, 3.0, 1.0]))
+    f = np.random.RandomState(4).rand(4, 3, 2, 15)
+    nifti.save(f, str(tmp_path / 'f.nii'), like=img)
+    back = nifti.load(str(tmp_path / 'f.nii'))
+    assert back.shape == (4, 3, 2, 15) and np.array_equal(back.get_data(), f)
+    assert np.allclose(back.affine, img.affine)
+    with pytest.raises(IOError):
+        (tmp_path / 'bad.nii').write_bytes(b'\0' * 400)
+        nifti.load(str(tmp_path / 'bad.nii'))
+
+
+def make_subject(folder, shape=(40, 40, 40), seed=0, with_labels=False):
+    os.makedirs(os.path.join(folder, 'tmp'), exist_ok=True)
+    vol = synth.smooth_volume(shape, sigma=3.0, seed=seed, as_int=True)
+    atlas = synth.toy_atlas(shape, seed=seed + 1)
+    mask = (atlas[..., :13].sum(-1) > 0).astype(np.float32)
+    nifti.save(vol, os.path.join(folder, 'T1.nii.gz'))
+    nifti.save(atlas, os.path.join(folder, 'tmp', 'MNI_sub_probabilities.nii.gz'))
+    nifti.save(mask, os.path.join(folder, 'tmp', 'MNI_subcortical_mask.nii.gz'))
+    if with_labels:
+        nifti.save(synth.toy_labels(shape, atlas), os.path.join(folder, 'gt_15_classes.nii.gz'))
+    return vol, atlas, mask
+
+
+def test_load_patch_batch_and_load_data_on_files(tmp_path):
+    vol, atlas, mask = make_subject(str(tmp_path / 'train' / 's1'), with_labels=True)
+    make_subject(str(tmp_path / 'train' / 's2'), seed=5, with_labels=True)
+    opts = {'train_folder': str(tmp_path / 'train'), 'test_folder': str(tmp_path / 'train'), 't1_name': 'T1.nii.gz',
+            'roi_name': 'gt_15_classes.nii.gz', 'patch_size': [32, 32], 'test_batch_size': 700, 'crop': 'True',
+            'debug': 'False', 'seed': 3}
+    t1s, names = base.load_test_names(opts)
+    assert names == ['s1', 's2'] and t1s[0].endswith(os.path.join('s1', 'T1.nii.gz'))
+    from scipy import ndimage
+    roi = ndimage.binary_dilation(mask, iterations=10)
+    ref = list(R.load_patch_batch(vol, atlas, roi, 700))
+    got = list(base.load_patch_batch(t1s[0], opts))
+    assert len(got) == len(ref) and len(got) > 1
+    for a, b in zip(got, ref):
+        for i in range(4):
+            assert a[i].dtype == np.float32 and np.array_equal(a[i], b[i])
+        assert np.array_equal(a[4], np.asarray(b[4]))
+    x_ax, x_co, x_sa, y_ax, x_atl, nm = base.load_data(opts)
+    assert len(x_ax) == 2 and x_ax[0].shape[1:] == (32, 32) and x_atl[0].shape[1] == 15
+    assert x_ax[0].shape[0] == y_ax[0].shape[0] == x_atl[0].shape[0] and x_ax[0].shape[0] % 2 == 0
+    out = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts)
+    assert out[0].shape[0] == x_ax[0].shape[0] + x_ax[1].shape[0] and set(np.unique(out[4])) <= set(range(15))
+    os.remove(os.path.join(str(tmp_path / 'train' / 's2'), 'tmp', 'MNI_sub_probabilities.nii.gz'))
+    with pytest.raises(FileNotFoundError):
+        base.load_data(opts)
+
+
+def test_load_options_keys_and_string_semantics(tmp_path):
+    cfg = configparser.RawConfigParser()
+    cfg.read_string('''
+[database]
+train_folder = /a
+inference_folder = /b
+t1_name = T1.nii.gz
+roi_name = gt_15_classes.nii.gz
+save_tmp = True
+[model]
+name = miccai2012_v1
+mode = cuda0
+patch_size = 32
+batch_size = 256
+patience = 20
+net_verbose = 1
+max_epochs = 100
+train_split = 0.25
+test_batch_size = 100000
+load_weights = True
+out_probabilities = False
+speedup_segmentation = True
+post_process = True
+debug = True
+''')
+    o = load_options(cfg)
+    ref_keys = {'experiment', 'train_folder', 'test_folder', 'output_folder', 'current_scan', 't1_name', 'roi_name',
+                'out_name', 'save_tmp', 'mode', 'patch_size', 'weight_paths', 'train_split', 'max_epochs', 'patience',
+                'batch_size', 'test_batch_size', 'net_verbose', 'load_weights', 'randomize_train', 'debug',
+                'out_probabilities', 'post_process', 'crop'}
+    assert ref_keys <= set(o)
+    assert o['patch_size'] == [32, 32] and o['load_weights'] == 'True' and o['crop'] == 'True' and o['device'] == 0
+    assert is_true(o['debug']) and not is_true(o['out_probabilities']) and is_true(True) and not is_true('False')
+
+
+def test_train_split_is_the_first_stratified_fold():
+    y = np.array([0] * 10 + [1] * 6 + [2] * 3 + [0] * 5)
+    tr, va = stratified_first_fold(y, 4)
+    assert len(set(tr) & set(va)) == 0 and len(tr) + len(va) == len(y)
+    # per class the validation fold is the first ceil-share of that class's samples, in order of appearance
+    assert list(va[y[va] == 0]) == [0, 1, 2, 3] and list(va[y[va] == 1]) == [10, 11] and list(va[y[va] == 2]) == [16]
+
+
+def test_early_stopping_reproduces_the_shipped_history():
+    """nets/miccai2012_v1/miccai2012_v1_history.pkl: best valid loss at epoch 42, training ended after epoch 62
+    with patience 20 - replaying the history through the hook must stop exactly there."""
+    hist = json.load(open(os.path.join(GOLD, 'miccai2012_v1_history.json')))
+    assert len(hist) == 62 and set(hist[0]) == {'dur', 'epoch', 'train_loss', 'train_loss_best', 'valid_accuracy', 'valid_loss', 'valid_loss_best'}
+
+    class FakeNet:
+        verbose = 0
+        def get_all_params_values(self): return {}
+        def load_params_from(self, w): self.restored = True
+    hook, net, stopped = EarlyStopping(patience=20), FakeNet(), None
+    for i in range(len(hist)):
+        try:
+            hook(net, hist[:i + 1])
+        except StopIteration:
+            stopped = hist[i]['epoch']
+            break
+    assert hook.best_valid_epoch == 42 and stopped == 62 and net.restored

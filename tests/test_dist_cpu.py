@@ -1,0 +1,97 @@
+"""Multi-process path on CPU (gloo, world_size 2): sharding without collectives for inference, one gradient
+all-reduce per training step, lock-step schedule at a ragged epoch tail.  The compute stand-in on CPU is the
+oracle (tests may use it); on the GPU the same cnn_cort.dist calls wrap the libscs gradient arena (RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG, WEIGHTS
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from cnn_cort import dist, params as P, synth
+    from oracle import np_oracle as O
+    r, w, _ = dist.init_from_env(backend='gloo')
+    out = {'rank': r, 'world': w}
+    # --- inference sharding: contiguous ranges cover the units exactly once, no collective involved
+    lo, hi = dist.shard_range(1001)
+    out['range'] = (lo, hi)
+    out['subjects'] = dist.shard_list(['s%d' % i for i in range(5)])
+    labels = np.arange(lo, hi, dtype=np.int64) * 3
+    out['gathered_ok'] = bool(np.array_equal(dist.gather_concat(labels), np.arange(1001) * 3))
+    # --- training schedule: 5 batches over 2 ranks -> 3 lock-step steps, the last one has a single active rank
+    starts = list(range(0, 5 * 8, 8))
+    sched = list(dist.shard_steps(starts))
+    out['sched'] = sched
+    out['active'] = [dist.active_ranks(len(starts), s) for s in range(len(sched))]
+    # --- one data-parallel step: each rank back-propagates its own 4 samples, gradients are summed and scaled
+    weights = P.load_params(WEIGHTS)
+    ax, co, sa, at = synth.patch_batch(8, seed=9)
+    y = np.arange(8) % 15
+    rng = np.random.RandomState(3)
+    masks = {k: (rng.rand(8, 60, 3, 3) < 0.5).astype(np.uint8) for k in ('axial_l1drop', 'coronal_l1drop', 'saggital_l1drop')}
+    masks['f1_drop'] = (rng.rand(8, 540) < 0.5).astype(np.uint8)
+    masks['f2_drop'] = (rng.rand(8, 540) < 0.5).astype(np.uint8)
+    sl = slice(4 * r, 4 * r + 4)
+    loss, grads, _, _ = O.train_forward_backward(weights, ax[sl], co[sl], sa[sl], at[sl], y[sl], {k: v[sl] for k, v in masks.items()})
+    flat = torch.from_numpy(np.concatenate([np.asarray(g, np.float64).ravel() for n, _ in P.LAYER_SPEC for g in grads[n]]))
+    local = flat.clone()
+    scale = dist.allreduce_flat(flat, n_active=2)
+    out['avg'] = (flat * scale).numpy()
+    out['local'] = local.numpy()
+    out['mean_loss'] = dist.mean_scalar(loss, 1)
+    out['loss'] = loss
+    out['max'] = dist.max_scalar(float(r + 1))
+    dist.barrier()
+    q.put(out)
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_data_parallel_plumbing():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs], key=lambda d: d['rank'])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    assert (a['world'], b['world']) == (2, 2)
+    assert a['range'] == (0, 501) and b['range'] == (501, 1001)
+    assert a['subjects'] == ['s0', 's2', 's4'] and b['subjects'] == ['s1', 's3']
+    assert a['gathered_ok'] and b['gathered_ok']
+    assert a['sched'] == [(0, True), (16, True), (32, True)] and b['sched'] == [(8, True), (24, True), (None, False)]
+    assert a['active'] == [2, 2, 1]
+    assert np.array_equal(a['avg'], b['avg'])                                    # replicas see identical gradients
+    assert np.allclose(a['avg'], 0.5 * (a['local'] + b['local']), rtol=0, atol=1e-15)
+    assert abs(a['mean_loss'] - 0.5 * (a['loss'] + b['loss'])) < 1e-12 and a['max'] == 2.0
+
+
+def test_single_process_degrades_to_noops():
+    from cnn_cort import dist
+    assert dist.world_size() == 1 and dist.rank() == 0
+    assert dist.shard_range(10) == (0, 10) and dist.shard_list([1, 2, 3]) == [1, 2, 3]
+    assert list(dist.shard_steps([0, 4, 8])) == [(0, True), (4, True), (8, True)]
+    t = torch.ones(4)
+    assert dist.allreduce_flat(t, 1) == 1.0 and dist.mean_scalar(3.0, 2) == 3.0
+    dist.barrier()

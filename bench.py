@@ -53,13 +53,26 @@ def synth_on_device(torch, n, seed, dev):
     return views[0], views[1], views[2], atlas
 
 
+def usable_cpus():
+    """Host threads this process may actually run on: affinity mask capped by the cgroup CPU quota (the GPU boxes
+    expose 256 logical CPUs but grant a 16-CPU share; 256 torch threads on that share run 100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(weights, budget_s=12.0, batch=128):
     """float32 torch-CPU port on the host cores, bounded sample (kind 'port': the reference's Theano CPU path
     cannot run here - BASELINE.md section 3)."""
     import torch
     from oracle import torch_ref as T
     from cnn_cort import synth
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     net = T.FoldedCPUNet(weights)
     ax, co, sa, at = [torch.from_numpy(a) for a in synth.patch_batch(batch, seed=0)]

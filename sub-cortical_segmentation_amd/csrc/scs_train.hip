@@ -31,6 +31,8 @@ using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 1040, 1, 1>;
 
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 constexpr bool kPool[kConvs] = {false, true, false, true, false};
+constexpr int kRedSplit = 16;     // batch slices per channel in the two-stage BN reductions
+constexpr int kWgSplit = 4;       // batch slices in the weight-gradient kernel
 
 }  // namespace scs
 
@@ -52,6 +54,8 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* wdg[kTowers][kConvs]{};             // data-gradient packs (i >= 1)
     float* pack_base = nullptr;
     double* eval_acc = nullptr;                // [2]: loss sum, correct count
+    double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN reductions
+    float* wg_part = nullptr;                  // [3][kWgSplit][60*40*9] partial weight gradients
 };
 
 namespace scs {
@@ -65,6 +69,8 @@ void train_free(scs_ctx* h) {
     if (w->masks) (void)hipFree(w->masks);
     if (w->pack_base) (void)hipFree(w->pack_base);
     if (w->eval_acc) (void)hipFree(w->eval_acc);
+    if (w->red_part) (void)hipFree(w->red_part);
+    if (w->wg_part) (void)hipFree(w->wg_part);
     delete w;
     h->tws = nullptr;
 }
@@ -84,6 +90,8 @@ static int train_ensure(scs_ctx* h, int n) {
         for (int t = 0; t < kTowers; ++t)
             for (int i = 0; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
+        SCS_HIP(hipMalloc(&w->red_part, (size_t)kTowers * 64 * kRedSplit * 2 * sizeof(double)));
+        SCS_HIP(hipMalloc(&w->wg_part, (size_t)kTowers * kWgSplit * 60 * 40 * 9 * sizeof(float)));
     }
     if (n <= w->cap) return SCS_OK;
     if (w->base) { SCS_HIP(hipFree(w->base)); w->base = nullptr; }
@@ -217,30 +225,40 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
     return r;
 }
 
-// BN batch statistics of one channel: mean, inv_std = 1/sqrt(var + eps); running averages updated in the arena
-__global__ __launch_bounds__(256) void bn_stats_kernel(CPtr3 Z, int n, int C, int pix, float* stats /*[3][..]*/, int layer,
-                                                      float* params, int bn_off0, int tower_stride) {
+
+// BN batch statistics, stage 1: per (channel, tower, batch slice) partial sum / sum of squares in double
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(CPtr3 Z, int n, int C, int pix, double* part) {
     __shared__ double s_red[4];
-    const int c = blockIdx.x, t = blockIdx.y;
+    const int c = blockIdx.x, t = blockIdx.y, sp = blockIdx.z;
     const float* __restrict__ z = sel3(Z.p, t);
+    const int per = (n + kRedSplit - 1) / kRedSplit, n0 = sp * per, n1 = min(n, n0 + per);
     double s = 0, q = 0;
-    const long total = (long)n * pix;
+    const long total = (long)max(0, n1 - n0) * pix;
     for (long e = threadIdx.x; e < total; e += blockDim.x) {
-        const long ni = e / pix, p = e - ni * pix;
+        const long ni = n0 + e / pix, p = e % pix;
         const double v = z[(ni * C + c) * pix + p];
         s += v; q += v * v;
     }
     s = block_sum(s, s_red);
     q = block_sum(q, s_red);
-    if (threadIdx.x == 0) {
-        const double mean = s / total, var = fmax(q / total - mean * mean, 0.0);
-        const double inv = 1.0 / sqrt(var + (double)kBnEps);
-        float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
-        st[c] = (float)mean; st[64 + c] = (float)inv;
-        float* bn = params + bn_off0 + t * tower_stride;       // beta, gamma, mean, inv_std
-        bn[2 * C + c] = (1.f - kBnAlpha) * bn[2 * C + c] + kBnAlpha * (float)mean;
-        bn[3 * C + c] = (1.f - kBnAlpha) * bn[3 * C + c] + kBnAlpha * (float)inv;
-    }
+    if (threadIdx.x == 0) { double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; o[0] = s; o[1] = q; }
+}
+
+// stage 2: mean, inv_std = 1/sqrt(var + eps); running averages updated in the arena (alpha 0.1)
+__global__ void bn_stats_final_kernel(const double* part, int n, int C, int pix, float* stats, int layer, float* params,
+                                      int bn_off0, int tower_stride) {
+    const int c = threadIdx.x, t = blockIdx.x;
+    if (c >= C) return;
+    double s = 0, q = 0;
+    for (int sp = 0; sp < kRedSplit; ++sp) { const double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; s += o[0]; q += o[1]; }
+    const double total = (double)n * pix;
+    const double mean = s / total, var = fmax(q / total - mean * mean, 0.0);
+    const double inv = 1.0 / sqrt(var + (double)kBnEps);
+    float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+    st[c] = (float)mean; st[64 + c] = (float)inv;
+    float* bn = params + bn_off0 + t * tower_stride;           // beta, gamma, mean, inv_std
+    bn[2 * C + c] = (1.f - kBnAlpha) * bn[2 * C + c] + kBnAlpha * (float)mean;
+    bn[3 * C + c] = (1.f - kBnAlpha) * bn[3 * C + c] + kBnAlpha * (float)inv;
 }
 
 // y = gamma*(z-mean)*inv_std + beta; ReLU; optional 2x2 max-pool; optional dropout (x * mask * 2) -> next input
@@ -442,31 +460,39 @@ __device__ __forceinline__ float bn_dy(const float* __restrict__ z, const float*
 }
 
 template <bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(CPtr3 Z, CPtr3 dOut, int n, int C, int H, float* stats, int layer,
-                                                           const float* params, float* grads, int bn_off0, int tower_stride) {
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(CPtr3 Z, CPtr3 dOut, int n, int C, int H, const float* stats, int layer,
+                                                            const float* params, int bn_off0, int tower_stride, double* part) {
     __shared__ double s_red[4];
-    const int c = blockIdx.x, t = blockIdx.y;
+    const int c = blockIdx.x, t = blockIdx.y, sp = blockIdx.z;
     const float* __restrict__ z = sel3(Z.p, t);
     const float* __restrict__ d = sel3(dOut.p, t);
-    float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+    const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
     const float* bn = params + bn_off0 + t * tower_stride;
     const float mean = st[c], inv = st[64 + c], sc = bn[C + c] * inv, sh = bn[c] - mean * sc;
     const int pix = H * H;
+    const int per = (n + kRedSplit - 1) / kRedSplit, n0 = sp * per, n1 = min(n, n0 + per);
     double sb = 0, sg = 0;
-    const long total = (long)n * pix;
+    const long total = (long)max(0, n1 - n0) * pix;
     for (long e = threadIdx.x; e < total; e += blockDim.x) {
-        const long ni = e / pix; const int p = (int)(e - ni * pix);
+        const long ni = n0 + e / pix; const int p = (int)(e % pix);
         float xh;
         const float dy = bn_dy<POOL>(z, d, ni * C + c, H, p / H, p % H, sc, sh, &xh, mean, inv);
         sb += dy; sg += (double)dy * xh;
     }
     sb = block_sum(sb, s_red);
     sg = block_sum(sg, s_red);
-    if (threadIdx.x == 0) {
-        st[128 + c] = (float)sb; st[192 + c] = (float)sg;
-        float* gb = grads + bn_off0 + t * tower_stride;
-        gb[c] = (float)sb; gb[C + c] = (float)sg;             // d beta, d gamma (mean / inv_std stay 0)
-    }
+    if (threadIdx.x == 0) { double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; o[0] = sb; o[1] = sg; }
+}
+
+__global__ void bn_bwd_final_kernel(const double* part, int C, float* stats, int layer, float* grads, int bn_off0, int tower_stride) {
+    const int c = threadIdx.x, t = blockIdx.x;
+    if (c >= C) return;
+    double sb = 0, sg = 0;
+    for (int sp = 0; sp < kRedSplit; ++sp) { const double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; sb += o[0]; sg += o[1]; }
+    float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+    st[128 + c] = (float)sb; st[192 + c] = (float)sg;
+    float* gb = grads + bn_off0 + t * tower_stride;
+    gb[c] = (float)sb; gb[C + c] = (float)sg;                  // d beta, d gamma (mean / inv_std stay 0)
 }
 
 template <bool POOL>
@@ -490,29 +516,58 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, 
     }
 }
 
-// weight gradient of a true convolution: dW[o][c][2-dy][2-dx] = sum_{n,y,x} dz[n][o][y][x] * X[n][c][y+dy][x+dx]
-// one workgroup per (c, o, tower); the (n, pixel) sum is spread over the threads (L1/L2 serve the 9-tap re-reads)
-__global__ __launch_bounds__(256) void wgrad_kernel(CPtr3 X, CPtr3 dZ, int n, int Cin, int Cout, int HIN, float* grads, int w_off0,
-                                                   int tower_stride) {
-    __shared__ double s_red[4];
-    const int c = blockIdx.x, o = blockIdx.y, t = blockIdx.z;
+// weight gradient of a true convolution: dW[o][c][2-dy][2-dx] = sum_{n,y,x} dz[n][o][y][x] * X[n][c][y+dy][x+dx].
+// One workgroup per (c, group of 4 output channels, tower x batch slice): the 9 taps of X are loaded once per pixel and
+// feed 36 FMAs; the (n, pixel) sum is spread over the threads; slices are summed in a fixed order by wgrad_final_kernel.
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(CPtr3 X, CPtr3 dZ, int n, int Cin, int Cout, int HIN, float* part) {
+    __shared__ float s_red[4][36];
+    const int c = blockIdx.x, og = blockIdx.y, t = blockIdx.z / kWgSplit, sp = blockIdx.z % kWgSplit;
     const float* __restrict__ x = sel3(X.p, t);
     const float* __restrict__ dz = sel3(dZ.p, t);
     const int HO = HIN - 2, pix = HO * HO;
-    float acc[9] = {};
-    const long total = (long)n * pix;
+    const int per = (n + kWgSplit - 1) / kWgSplit, n0 = sp * per, n1 = min(n, n0 + per);
+    float acc[4][9] = {};
+    const long total = (long)max(0, n1 - n0) * pix;
     for (long e = threadIdx.x; e < total; e += blockDim.x) {
-        const long ni = e / pix; const int p = (int)(e - ni * pix), y = p / HO, xx = p - y * HO;
-        const float d = dz[(ni * Cout + o) * pix + p];
+        const long ni = n0 + e / pix; const int p = (int)(e % pix), y = p / HO, xx = p - y * HO;
         const float* xb = x + ((ni * Cin + c) * HIN + y) * HIN + xx;
+        float xv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) acc[k] = fmaf(d, xb[(k / 3) * HIN + k % 3], acc[k]);
+        for (int k = 0; k < 9; ++k) xv[k] = xb[(k / 3) * HIN + k % 3];
+        const float* dp = dz + (ni * Cout + og * 4) * pix + p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = dp[(long)j * pix];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[j][k] = fmaf(d, xv[k], acc[j][k]);
+        }
     }
-    float* gw = grads + w_off0 + t * tower_stride + (o * Cin + c) * 9;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const double s = block_sum((double)acc[k], s_red);
-        if (threadIdx.x == 0) gw[(2 - k / 3) * 3 + (2 - k % 3)] = (float)s;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float v = acc[j][k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) s_red[wv][j * 9 + k] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        // part[t][sp][o][c][9]
+        const int j = threadIdx.x / 9, k = threadIdx.x % 9;
+        part[((((size_t)t * kWgSplit + sp) * Cout + og * 4 + j) * Cin + c) * 9 + k] = v;
+    }
+}
+
+__global__ void wgrad_final_kernel(const float* part, int Cin, int Cout, float* grads, int w_off0, int tower_stride) {
+    const int t = blockIdx.y, tot = Cout * Cin * 9;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int sp = 0; sp < kWgSplit; ++sp) v += part[((size_t)t * kWgSplit + sp) * tot + e];
+        const int k = e % 9, oc = e / 9;
+        grads[w_off0 + t * tower_stride + oc * 9 + (2 - k / 3) * 3 + (2 - k % 3)] = v;     // flip back to Lasagne's W
     }
 }
 
@@ -602,7 +657,8 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
             else conv_launch<TF5>(a, st);
         }
         const int C = kCout[i], Hh = kHout[i];
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(C, kTowers), dim3(256), 0, st, c3(w->Z, i), n, C, Hh * Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kTowers, kRedSplit), dim3(256), 0, st, c3(w->Z, i), n, C, Hh * Hh, w->red_part);
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(kTowers), dim3(64), 0, st, w->red_part, n, C, Hh * Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
         Ptr3 out;
         for (int t = 0; t < kTowers; ++t) out.p[t] = (i == kConvs - 1) ? w->H5[t] : w->X[t][i + 1];
         const long tot = (long)n * C * (kPool[i] ? (Hh / 2) * (Hh / 2) : Hh * Hh);
@@ -693,16 +749,19 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         Ptr3 dZ{{w->dZ[0], w->dZ[1], w->dZ[2]}};
         const long tot = (long)n * C * Hh * Hh;
         if (kPool[i]) {
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(C, kTowers), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, G, T0.bn[i], kTowerFloats);
+            hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(C, kTowers, kRedSplit), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats, w->red_part);
+            hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(kTowers), dim3(64), 0, st, w->red_part, C, w->stats, i, G, T0.bn[i], kTowerFloats);
             hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
         } else {
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(C, kTowers), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, G, T0.bn[i], kTowerFloats);
+            hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(C, kTowers, kRedSplit), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats, w->red_part);
+            hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(kTowers), dim3(64), 0, st, w->red_part, C, w->stats, i, G, T0.bn[i], kTowerFloats);
             hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
         }
         CPtr3 Xi;
         for (int t = 0; t < kTowers; ++t) Xi.p[t] = (i == 0) ? xin[t] : w->X[t][i];
         CPtr3 dZc{{w->dZ[0], w->dZ[1], w->dZ[2]}};
-        hipLaunchKernelGGL(wgrad_kernel, dim3(kCin[i], C, kTowers), dim3(256), 0, st, Xi, dZc, n, kCin[i], C, kHin[i], G, T0.convW[i], kTowerFloats);
+        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kCin[i], C / 4, kTowers * kWgSplit), dim3(256), 0, st, Xi, dZc, n, kCin[i], C, kHin[i], w->wg_part);
+        hipLaunchKernelGGL(wgrad_final_kernel, dim3(32, kTowers), dim3(256), 0, st, w->wg_part, kCin[i], C, G, T0.convW[i], kTowerFloats);
         if (i > 0) {
             ConvArgs a{};
             a.n = n;

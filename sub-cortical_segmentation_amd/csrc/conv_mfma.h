@@ -43,14 +43,14 @@ struct ConvCfg {
     static constexpr int OUTB = POOL ? WB : PIXB;       // stored outputs per patch, channel and band
     static constexpr int XROWS = HINB + 2;              // rows of the raw 32x32 patch a fused-conv1 band needs
     static constexpr int PLANE = PLANE_;
-    static constexpr int NT = n_tiles(COUT_);
-    static constexpr int NS = n_stride(COUT_);
+    static constexpr int NT = n_tiles(COUT_);           // bias granularity
+    static constexpr int NT16 = nt16(COUT_), NT4 = nt4(COUT_), NS16 = ns16(COUT_), L4 = 4 * NT4;
     static constexpr int NC4 = CIN_ / 4;
     static constexpr int MTOT = G_ * PIXB;
     static constexpr int TILES = (MTOT + 15) / 16;
     static constexpr int TPW = (TILES + 3) / 4;         // tiles per wave (wave w owns tiles w, w+4, ...)
     static constexpr bool LAST_RAGGED = (3 + 4 * (TPW - 1)) >= TILES;   // some waves lack their last tile
-    static constexpr int WCHUNK = 36 * NS;              // floats per weight chunk
+    static constexpr int WCHUNK = conv_chunk_floats(COUT_);   // floats per weight chunk
     static constexpr int WCHUNK4 = WCHUNK / 4;
     static constexpr int WPT = (WCHUNK4 + 255) / 256;   // float4 per thread per chunk
     static constexpr int IN_FLOATS = G_ * CIN_ * PLANE_;
@@ -62,6 +62,7 @@ struct ConvCfg {
     static constexpr int MAIN_FLOATS = IN_FLOATS_AL + 2 * WCHUNK + XS_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)(MAIN_FLOATS > OUT_FLOATS ? MAIN_FLOATS : OUT_FLOATS) * 4;
     static_assert(CIN_ % 4 == 0, "k-steps are groups of 4 input channels");
+    static_assert(COUT_ % 4 == 0, "output channels are covered by 16-wide and 4-wide MFMA blocks");
     static_assert(HO % NB_ == 0 && (!POOL || (HOB % 2 == 0)), "bands must split the output rows (evenly for pooling)");
     static_assert(NB_ == 1 || (G_ == 1 && SRC_ != SRC_NCHW_PAD2), "bands: one patch per workgroup");
     static_assert(PLANE_ >= HINB * HIN_, "plane stride too small");
@@ -70,7 +71,7 @@ struct ConvCfg {
 
 struct ConvArgs {
     const float* in[kTowers];     // SRC_NCHW*: [n][CIN][HSRC][HSRC]; SRC_CONV1: [n][32][32]; SRC_VOLUME: the volume
-    const float* w[kTowers];      // packed [CIN/4][9][4][NS]
+    const float* w[kTowers];      // packed chunks per 4 input channels: [9][4][NS16] + [9][4][L4] (scs_common.h)
     const float* bias[kTowers];   // [NT*16] (unused for EPI_RAW)
     float* out[kTowers];          // [n][COUT][OUTPIX]
     const float* w1[kTowers];     // SRC_CONV1/VOLUME: conv1 weights+bias [20][10] (9 taps, then the bias)
@@ -169,11 +170,16 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     if constexpr (C::WPT > 2) wr2 = reinterpret_cast<const float4*>(wsrc)[wi2];
 
     // per-lane epilogue bias, fetched now so its latency hides under the staging
-    float bvs[C::NT];
+    float bvs[C::NT16 > 0 ? C::NT16 : 1], bv4[C::NT4 > 0 ? C::NT4 : 1];
 #pragma unroll
-    for (int nt = 0; nt < C::NT; ++nt) {
+    for (int nt = 0; nt < C::NT16; ++nt) {
         bvs[nt] = 0.f;
         if constexpr (C::EPI != EPI_RAW) bvs[nt] = pick3(a.bias, tower)[nt * 16 + lr];
+    }
+#pragma unroll
+    for (int u = 0; u < C::NT4; ++u) {
+        bv4[u] = 0.f;
+        if constexpr (C::EPI != EPI_RAW) bv4[u] = pick3(a.bias, tower)[C::NT16 * 16 + u * 4 + kq];
     }
 
     // ---- stage the input planes of this workgroup's patches
@@ -272,16 +278,20 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         abase[j] = (g * C::CIN + kq) * C::PLANE + y * C::WIN + x;
     }
 
-    f32x4 acc[C::TPW][C::NT];
+    f32x4 acc[C::TPW][C::NT16 > 0 ? C::NT16 : 1], acc4[C::TPW][C::NT4 > 0 ? C::NT4 : 1];
 #pragma unroll
-    for (int j = 0; j < C::TPW; ++j)
+    for (int j = 0; j < C::TPW; ++j) {
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < C::NT16; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < C::NT4; ++u) acc4[j][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     __syncthreads();
     if constexpr (C::STAMP) { if (tid == 0) stp[2] = __builtin_amdgcn_s_memtime(); }
 
-    const int boff = kq * C::NS + lr;
+    const int boff = kq * C::NS16 + lr;                       // main part: W[k = 4s + kq][cout = 16 nt + lr]
+    const int loff = 36 * C::NS16 + kq * C::L4 + (lane & 3);   // leftover: W[k = 4s + kq][cout = 16 NT16 + 4u + (lane&3)]
     const bool last_ok = (wave + 4 * (C::TPW - 1)) < C::TILES;
     for (int c4 = 0; c4 < C::NC4; ++c4) {
         if (c4 + 1 < C::NC4) {
@@ -290,21 +300,28 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
             if constexpr (C::WPT > 1) wr1 = src[wi1];
             if constexpr (C::WPT > 2) wr2 = src[wi2];
         }
-        const float* __restrict__ sw = s_w + (c4 & 1) * C::WCHUNK + boff;
+        const float* __restrict__ sw = s_w + (c4 & 1) * C::WCHUNK;
         const float* __restrict__ sa = s_in + c4 * 4 * C::PLANE;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = (tap / 3) * C::WIN + (tap % 3);
-            float b[C::NT];
+            float b[C::NT16 > 0 ? C::NT16 : 1], b4[C::NT4 > 0 ? C::NT4 : 1];
 #pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt) b[nt] = sw[tap * 4 * C::NS + nt * 16];
+            for (int nt = 0; nt < C::NT16; ++nt) b[nt] = sw[boff + tap * 4 * C::NS16 + nt * 16];
+#pragma unroll
+            for (int u = 0; u < C::NT4; ++u) b4[u] = sw[loff + tap * 4 * C::L4 + u * 4];
 #pragma unroll
             for (int j = 0; j < C::TPW; ++j) {
                 if (C::LAST_RAGGED && j == C::TPW - 1 && !last_ok) continue;   // wave-uniform: this wave has no such tile
                 const float av = sa[abase[j] + toff];
 #pragma unroll
-                for (int nt = 0; nt < C::NT; ++nt)
+                for (int nt = 0; nt < C::NT16; ++nt)
                     acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[j][nt], 0, 0, 0);
+                // 16 blocks of 4 couts x 4 pixels: block (l>>2) = (k-subgroup kq, pixel quad); partial sums over kq
+                // are combined in the epilogue
+#pragma unroll
+                for (int u = 0; u < C::NT4; ++u)
+                    acc4[j][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[j][u], 0, 0, 0);
             }
         }
         if (c4 + 1 < C::NC4) {
@@ -326,9 +343,8 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         const int t = wave + 4 * j;
         if (t >= C::TILES) continue;
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt) {
+        for (int nt = 0; nt < C::NT16; ++nt) {
             const int co = nt * 16 + lr;
-            if (co >= C::COUT) continue;
             const float bv = bvs[nt];
             if constexpr (C::POOL) {
                 const int widx = t * 4 + kq;
@@ -350,6 +366,39 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
                         if constexpr (C::EPI != EPI_RAW) v = fmaxf(v + bv, 0.f);
                         s_o[(g * C::COUT + co) * C::OSTR + r] = v;
                     }
+                }
+            }
+        }
+    }
+    // leftover channels: lane l holds, for pixel (l & 15), the partial sums of k-subgroup kq for 4 couts (vgpr i)
+#pragma unroll
+    for (int j = 0; j < C::TPW; ++j) {
+        const int t = wave + 4 * j;
+        if (t >= C::TILES) continue;
+#pragma unroll
+        for (int u = 0; u < C::NT4; ++u) {
+            f32x4 v = acc4[j][u];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] += __shfl_xor(v[i], 16); v[i] += __shfl_xor(v[i], 32); }
+            float val = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));    // this lane stores cout 4u + kq
+            const int co = C::NT16 * 16 + u * 4 + kq;
+            const float bv = bv4[u];
+            if constexpr (C::POOL) {
+                val = fmaxf(val, __shfl_xor(val, 1));
+                val = fmaxf(val, __shfl_xor(val, 2));
+                const int widx = t * 4 + ((lane & 15) >> 2);
+                if ((lane & 3) == 0 && widx < C::G * C::WB) {
+                    const int g = widx / C::WB;
+                    const int r = widx - g * C::WB;
+                    s_o[(g * C::COUT + co) * C::OSTR + r] = fmaxf(val + bv, 0.f);
+                }
+            } else {
+                const int m = t * 16 + (lane & 15);
+                if (m < C::MTOT) {
+                    const int g = m / C::PIXB;
+                    const int r = m - g * C::PIXB;
+                    if constexpr (C::EPI != EPI_RAW) val = fmaxf(val + bv, 0.f);
+                    s_o[(g * C::COUT + co) * C::OSTR + r] = val;
                 }
             }
         }

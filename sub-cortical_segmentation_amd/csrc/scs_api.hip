@@ -35,24 +35,21 @@ void set_error(const char* fmt, ...) {
 using CfgConv12 = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 2>;    // half a patch per workgroup
 using CfgConv12V = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_VOLUME, 496, 2, 2>;
 using CfgConv3 = ConvCfg<20, 40, 14, 2, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 3>;
-using CfgConv4 = ConvCfg<40, 40, 12, 2, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 2>;
-using CfgConv5 = ConvCfg<40, 60, 5, 16, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 1>;
+using CfgConv4 = ConvCfg<40, 40, 12, 1, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 4>;
+using CfgConv5 = ConvCfg<40, 60, 5, 8, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 2>;
 
 // ----------------------------------------------------------------------------- packing kernels
-// conv i (Cin >= 4): Wp[c4][tap][kk][n] = W[n][4*c4+kk][2-dy][2-dx] * scale[n]  (true conv -> correlation)
+// conv i (Cin >= 4): packed chunks (scs_common.h), element = W[n][4*c4+kk][2-dy][2-dx] * scale[n]  (true conv -> correlation)
 __global__ void pack_conv_kernel(const float* __restrict__ W, const float* __restrict__ bn, int cin, int cout,
-                                 int ns, int fold, float* __restrict__ wp, float* __restrict__ bias) {
-    const int total = (cin / 4) * 36 * ns;
+                                 int fold, float* __restrict__ wp, float* __restrict__ bias) {
+    const int total = (cin / 4) * conv_chunk_floats(cout);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int n = e % ns;
-        int r = e / ns;
-        const int kk = r & 3; r >>= 2;
-        const int tap = r % 9, c4 = r / 9;
+        const PackIdx ix = conv_pack_index(e, cout);
         float v = 0.f;
-        if (n < cout) {
-            const int c = c4 * 4 + kk, dy = tap / 3, dx = tap % 3;
-            v = W[((n * cin + c) * 3 + (2 - dy)) * 3 + (2 - dx)];
-            if (fold) v *= bn[cout + n] * bn[3 * cout + n];          // gamma * inv_std
+        if (ix.n >= 0) {
+            const int c = ix.c4 * 4 + ix.kk, dy = ix.tap / 3, dx = ix.tap % 3;
+            v = W[((ix.n * cin + c) * 3 + (2 - dy)) * 3 + (2 - dx)];
+            if (fold) v *= bn[cout + ix.n] * bn[3 * cout + ix.n];          // gamma * inv_std
         }
         wp[e] = v;
     }
@@ -211,7 +208,7 @@ int repack_inference(scs_ctx* h, hipStream_t st) {
         hipLaunchKernelGGL(pack_conv1_kernel, dim3(1), dim3(256), 0, st, P + T.convW[0], P + T.bn[0], 1, h->pk.conv1w[t]);
         for (int i = 1; i < kConvs; ++i)
             hipLaunchKernelGGL(pack_conv_kernel, dim3(32), dim3(256), 0, st, P + T.convW[i], P + T.bn[i], kCin[i],
-                               kCout[i], n_stride(kCout[i]), 1, h->pk.convw[t][i], h->pk.convb[t][i]);
+                               kCout[i], 1, h->pk.convw[t][i], h->pk.convb[t][i]);
         hipLaunchKernelGGL(pack_dense_kernel, dim3(64), dim3(256), 0, st, P + T.d1W, P + T.d1b, kFlat, kD1, kFlat,
                            gemm_ns(kD1), h->pk.d1w[t], h->pk.d1b[t]);
     }

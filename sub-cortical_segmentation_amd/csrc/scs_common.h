@@ -57,14 +57,35 @@ constexpr HeadOff head_off() {
 static_assert(head_off().end == SCS_N_PARAMS, "arena layout must match the 883455-float reference pickle");
 
 // ------------------------------------------------------------------ MFMA operand geometry
-// conv weights are packed [Cin/4][9 taps][4][NS] with NS = padded Cout such that NS % 32 == 16
-// (two k-rows read by one 32-lane LDS group then fall on disjoint banks).
-constexpr int n_tiles(int cout) { return (cout + 15) / 16; }
-constexpr int n_stride(int cout) { int n = n_tiles(cout) * 16; return (n % 32 == 16) ? n : n + 16; }
+// Output channels are covered without padding waste: Cout = 16*NT16 + 4*NT4.  The 16-wide part runs on
+// v_mfma_f32_16x16x4_f32, the remainder (4, 8 or 12 channels) on v_mfma_f32_4x4x1_16b_f32, whose 16 independent
+// 4x4 blocks take the SAME pixel operand register (block b = k-subgroup b>>2, pixel quad b&3).
+// Conv weights are packed per group of 4 input channels as one chunk:
+//   main     [9 taps][4][NS16]   NS16 = 16*NT16 padded so NS16 % 32 == 16 (two k-rows of a 32-lane LDS read group
+//                                land on disjoint banks)
+//   leftover [9 taps][4][L4]     L4 = 4*NT4
+constexpr int n_tiles(int cout) { return (cout + 15) / 16; }              // bias array granularity
+constexpr int n_stride(int cout) { int n = n_tiles(cout) * 16; return (n % 32 == 16) ? n : n + 16; }   // GEMM packs
+constexpr int nt16(int cout) { return cout / 16; }
+constexpr int nt4(int cout) { return (cout % 16) / 4; }
+constexpr int ns16(int cout) { int n = nt16(cout) * 16; return n == 0 ? 0 : ((n % 32 == 16) ? n : n + 16); }
+constexpr int conv_chunk_floats(int cout) { return 36 * (ns16(cout) + 4 * nt4(cout)); }
 // activation planes are padded so that plane stride % 32 == 16 where the LDS budget allows
 constexpr int plane_stride(int hw) { int p = hw; while (p % 32 != 16) ++p; return p; }
 
-constexpr int conv_pack_floats(int i) { return kCin[i] < 4 ? 0 : (kCin[i] / 4) * 36 * n_stride(kCout[i]); }
+constexpr int conv_pack_floats(int i) { return kCin[i] < 4 ? 0 : (kCin[i] / 4) * conv_chunk_floats(kCout[i]); }
+
+// source coordinates of element e of a packed conv weight array: input-channel group c4, tap, channel-in-group kk,
+// output channel n (-1 = padding, stored as zero)
+struct PackIdx { int c4, tap, kk, n; };
+__host__ __device__ constexpr PackIdx conv_pack_index(int e, int cout) {
+    const int ch = conv_chunk_floats(cout), n16 = ns16(cout), l4 = 4 * nt4(cout);
+    const int c4 = e / ch;
+    int r = e - c4 * ch, row = 0, n = -1;
+    if (r < 36 * n16) { row = r / n16; const int col = r - row * n16; n = col < nt16(cout) * 16 ? col : -1; }
+    else { r -= 36 * n16; row = r / l4; n = nt16(cout) * 16 + (r - row * l4); }
+    return PackIdx{c4, row >> 2, row & 3, n};
+}
 
 // GEMM weights are packed [K4][NS]: K padded to a multiple of 4, NS = padded N (multiple of 16, %32==16)
 constexpr int gemm_ns(int n) { return n_stride(n); }

@@ -25,7 +25,7 @@ using TF4 = ConvCfg<40, 40, 12, 2, EPI_RAW, SRC_NCHW, 144, 1, 2>;
 using TF5 = ConvCfg<40, 60, 5, 16, EPI_RAW, SRC_NCHW, 27, 1, 1>;
 // data gradients: input = dZ_i zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i
 using DG5 = ConvCfg<60, 40, 7, 8, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 1>;
-using DG4 = ConvCfg<40, 40, 14, 2, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 2>;
+using DG4 = ConvCfg<40, 40, 14, 2, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 1>;
 using DG3 = ConvCfg<40, 20, 16, 2, EPI_RAW, SRC_NCHW_PAD2, 272, 1, 1>;
 using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 1040, 1, 1>;
 
@@ -84,7 +84,7 @@ static int train_ensure(scs_ctx* h, int n) {
         for (int t = 0; t < kTowers; ++t)
             for (int i = 0; i < kConvs; ++i) {
                 of[t][i] = off; off += al64(i == 0 ? 200 : conv_pack_floats(i));
-                og[t][i] = off; off += al64(i == 0 ? 0 : (size_t)(kCout[i] / 4) * 36 * n_stride(kCin[i]));
+                og[t][i] = off; off += al64(i == 0 ? 0 : (size_t)(kCout[i] / 4) * conv_chunk_floats(kCin[i]));
             }
         SCS_HIP(hipMalloc(&w->pack_base, off * sizeof(float)));
         for (int t = 0; t < kTowers; ++t)
@@ -146,24 +146,19 @@ __global__ void pack_train_kernel(PackJobs jobs) {
         }
         return;
     }
-    const int ns = n_stride(J.cout), tot = (J.cin / 4) * 36 * ns;
+    const int tot = (J.cin / 4) * conv_chunk_floats(J.cout);
     for (int e = t0; e < tot; e += stride) {
-        const int n = e % ns;
-        int r = e / ns;
-        const int kk = r & 3; r >>= 2;
-        const int tap = r % 9, c4 = r / 9;
+        const PackIdx ix = conv_pack_index(e, J.cout);
         float v = 0.f;
-        if (n < J.cout) v = J.W[((n * J.cin + c4 * 4 + kk) * 3 + (2 - tap / 3)) * 3 + (2 - tap % 3)];
+        if (ix.n >= 0) v = J.W[((ix.n * J.cin + ix.c4 * 4 + ix.kk) * 3 + (2 - ix.tap / 3)) * 3 + (2 - ix.tap % 3)];
         J.fwd[e] = v;
     }
-    const int nsd = n_stride(J.cin), totd = (J.cout / 4) * 36 * nsd;
+    // data gradient: roles swapped (reduction over the conv's output channels, outputs = its input channels)
+    const int totd = (J.cout / 4) * conv_chunk_floats(J.cin);
     for (int e = t0; e < totd; e += stride) {
-        const int c = e % nsd;
-        int r = e / nsd;
-        const int kk = r & 3; r >>= 2;
-        const int tap = r % 9, o4 = r / 9;
+        const PackIdx ix = conv_pack_index(e, J.cin);
         float v = 0.f;
-        if (c < J.cin) v = J.W[(((o4 * 4 + kk) * J.cin + c) * 3 + tap / 3) * 3 + tap % 3];
+        if (ix.n >= 0) v = J.W[(((ix.c4 * 4 + ix.kk) * J.cin + ix.n) * 3 + ix.tap / 3) * 3 + ix.tap % 3];
         J.dg[e] = v;
     }
 }

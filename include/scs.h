@@ -60,8 +60,9 @@ int scs_destroy(scs_handle h);
 int scs_set_params(scs_handle h, const float* host_arena, size_t n);
 int scs_get_params(scs_handle h, float* host_arena, size_t n);
 
-/* Batch-chunk size used internally by the forward entry points (default 4096 patches; workspace is
- * allocated for one chunk).  Returns the value in effect. */
+/* Upper bound of the batch chunk used internally by the forward entry points (default 32768 patches; workspace
+ * ~140 KB per patch is allocated for one chunk; a call splits its n patches into equal chunks below this bound).
+ * Returns the value in effect (pass 0 to query). */
 int scs_set_chunk(scs_handle h, int patches_per_chunk);
 
 /* Deterministic forward on n patches (device pointers).  probs and/or labels may be NULL.

@@ -405,6 +405,14 @@ int scs_set_chunk(scs_handle h, int patches_per_chunk) {
     return h->chunk;
 }
 
+// split n patches into equal chunks no larger than the workspace chunk (a short tail chunk would leave the
+// dense-head GEMMs with too few workgroups to fill 256 CUs)
+static int balanced_chunk(int64_t n, int max_chunk) {
+    const int64_t k = (n + max_chunk - 1) / max_chunk;
+    int64_t c = ((n + k - 1) / k + 15) / 16 * 16;
+    return (int)(c > max_chunk ? max_chunk : c);
+}
+
 static int forward_common(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas,
                           const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
                           int64_t n, float* probs, int32_t* labels, void* stream) {
@@ -417,8 +425,9 @@ static int forward_common(scs_handle h, const float* ax, const float* co, const 
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
-    for (int64_t s = 0; s < n; s += h->chunk) {
-        const int m = (int)((n - s < h->chunk) ? (n - s) : h->chunk);
+    const int step = balanced_chunk(n, h->chunk);
+    for (int64_t s = 0; s < n; s += step) {
+        const int m = (int)((n - s < step) ? (n - s) : step);
         rc = forward_chunk(h, ax ? ax + s * 1024 : nullptr, co ? co + s * 1024 : nullptr, sa ? sa + s * 1024 : nullptr,
                            atlas ? atlas + s * 15 : nullptr, vol, dx, dy, dz, centers ? centers + s * 3 : nullptr, atlas4d,
                            m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, nullptr);
@@ -485,12 +494,13 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
-    const int nchunks = (int)((n + h->chunk - 1) / h->chunk);
+    const int step = balanced_chunk(n, h->chunk);
+    const int nchunks = (int)((n + step - 1) / step);
     std::vector<hipEvent_t> ev((size_t)nchunks * 9);
     for (auto& e : ev) SCS_HIP(hipEventCreate(&e));
     int c = 0;
-    for (int64_t s = 0; s < n; s += h->chunk, ++c) {
-        const int m = (int)((n - s < h->chunk) ? (n - s) : h->chunk);
+    for (int64_t s = 0; s < n; s += step, ++c) {
+        const int m = (int)((n - s < step) ? (n - s) : step);
         rc = forward_chunk(h, ax + s * 1024, co + s * 1024, sa + s * 1024, atlas + s * 15, nullptr, 0, 0, 0, nullptr, nullptr,
                            m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, &ev[(size_t)c * 9]);
         if (rc != SCS_OK) break;

@@ -22,7 +22,7 @@ struct scs_ctx {
     scs::PackedNet pk{};
 
     // forward workspace (one chunk)
-    int chunk = 4096;
+    int chunk = 32768;             // patches per internal chunk (workspace ~140 KB per patch)
     int ws_chunk = 0;              // chunk the workspace was allocated for
     float* ws = nullptr;
     float* a_pool1[scs::kTowers]{};   // [chunk][20][14][14]

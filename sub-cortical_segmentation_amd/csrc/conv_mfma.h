@@ -21,6 +21,8 @@
 
 namespace scs {
 
+constexpr int kW1Floats = 12 * 16 + 12 * 4 + 20;   // conv1 operands: [12][16] + [12][4] + bias[20]
+
 enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2 };
 enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3 };
 
@@ -55,7 +57,8 @@ struct ConvCfg {
     static constexpr int WPT = (WCHUNK4 + 255) / 256;   // float4 per thread per chunk
     static constexpr int IN_FLOATS = G_ * CIN_ * PLANE_;
     static constexpr int IN_FLOATS_AL = (IN_FLOATS + 3) / 4 * 4;
-    static constexpr int XS_FLOATS = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME) ? 32 * 32 : 0;
+    static constexpr int XS_ROWS_FLOATS = (XROWS * 32 + 3) / 4 * 4;
+    static constexpr int XS_FLOATS = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME) ? XS_ROWS_FLOATS + 4 + kW1Floats : 0;
     // the epilogue restages the outputs in LDS ([g][cout][OSTR], odd stride) and stores them as whole rows
     static constexpr int OSTR = OUTB | 1;
     static constexpr int OUT_FLOATS = G_ * COUT_ * OSTR;
@@ -74,7 +77,7 @@ struct ConvArgs {
     const float* w[kTowers];      // packed chunks per 4 input channels: [9][4][NS16] + [9][4][L4] (scs_common.h)
     const float* bias[kTowers];   // [NT*16] (unused for EPI_RAW)
     float* out[kTowers];          // [n][COUT][OUTPIX]
-    const float* w1[kTowers];     // SRC_CONV1/VOLUME: conv1 weights+bias [20][10] (9 taps, then the bias)
+    const float* w1[kTowers];     // SRC_CONV1/VOLUME: conv1 operands [12][16] + [12][4] + bias[20] (kW1Floats)
     const int32_t* centers;       // SRC_VOLUME: [n][3]
     int dimx, dimy, dimz;
     int n;                        // patches
@@ -87,33 +90,72 @@ __device__ __forceinline__ T pick3(T const (&arr)[kTowers], int t) {
     return t == 0 ? arr[0] : (t == 1 ? arr[1] : arr[2]);
 }
 
-// conv1 (1 -> 20 channels, K = 9) on the vector ALU: raw tile rows in LDS -> 20 planes of ROWS x 30 in LDS, bias + ReLU.
-// (nets.py:171; 2.8 % of a tower's MACs: not worth a K-padded MFMA pass.)  Each lane keeps the 3x3 neighbourhoods
-// of its pixels in registers; the 200 weights/biases are wave-uniform and arrive through scalar loads (SGPR
-// operands of v_fma), so the only LDS traffic is 9 reads and 20 writes per pixel.
+// ---- cross-lane helpers on the VALU (no LDS crossbar): v + v[lane^16] + v[lane^32] + v[lane^48], and quad maxima
+__device__ __forceinline__ float sum_xor16(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // odd rows of one copy <-> even rows of the other
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_ksub(float v) { return sum_xor32(sum_xor16(v)); }
+__device__ __forceinline__ float max_quad(float v) {     // max over the 4 lanes of a quad (lane ^ 1, lane ^ 2)
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));
+    return v;
+}
+
+// conv1 (1 -> 20 channels, 9 taps) on the matrix cores as well: K = 9 padded to 12 (3 k-steps, tap index on the
+// k axis), N = 20 = 16 + 4, M = ROWS*30 pixels.  Raw tile rows in LDS -> 20 planes of ROWS x 30 in LDS with bias +
+// ReLU (nets.py:171).  w1p: [12][16] main weights, [12][4] leftover weights, [20] bias (rows 9..11 are zero).
 template <int PLANE, int ROWS>
-__device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, const float* __restrict__ w1g,
-                                             float* __restrict__ s_out, int tid) {
-    constexpr int NPIX = ROWS * 30, NR = (NPIX + 255) / 256;
-    float in[NR][9];
+__device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, const float* __restrict__ s_w1,
+                                             float* __restrict__ s_out, int wave, int lane) {
+    constexpr int NPIX = ROWS * 30, T1 = (NPIX + 15) / 16;
+    const int lr = lane & 15, kq = lane >> 4;
+    int toff[3];
+    float bm[3], bl[3];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int p = min(tid + 256 * r, NPIX - 1);
-        const int y = p / 30, x = p - y * 30;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) in[r][t] = s_x[(y + t / 3) * 32 + x + t % 3];
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int k = 4 * s3 + kq, tk = k < 9 ? k : 8;
+        toff[s3] = (tk / 3) * 32 + tk % 3;
+        bm[s3] = s_w1[k * 16 + lr];
+        bl[s3] = s_w1[192 + k * 4 + (lane & 3)];
     }
+    const float bias_m = s_w1[240 + lr], bias_l = s_w1[240 + 16 + kq];
+    // all of a wave's tiles are independent straight-line chains (clamped indices, predicated stores), so the
+    // scheduler overlaps their LDS-read -> MFMA -> lane-exchange -> LDS-write latencies
+    constexpr int TW = (T1 + 3) / 4;
 #pragma unroll
-    for (int c = 0; c < 20; ++c) {
-        const float* __restrict__ w = w1g + c * 10;
+    for (int jj = 0; jj < TW; ++jj) {
+        const int t = wave + 4 * jj;
+        const int tc = min(t, T1 - 1);
+        const int p = min(tc * 16 + lr, NPIX - 1), y = p / 30, x = p - y * 30;
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            float o = w[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) o = fmaf(in[r][t], w[t], o);
-            const int p = tid + 256 * r;
-            if (p < NPIX) s_out[c * PLANE + p] = fmaxf(o, 0.f);
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const float av = s_x[y * 32 + x + toff[s3]];
+            am = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bm[s3], am, 0, 0, 0);
+            al = __builtin_amdgcn_mfma_f32_4x4x1f32(bl[s3], av, al, 0, 0, 0);
         }
+        // main: cout = lr, pixels 16t + 4kq + r (contiguous in the plane: rows are stored unpadded, 30 wide)
+        const int p0 = tc * 16 + kq * 4;
+        float* dst = s_out + lr * PLANE + p0;
+        const bool tile_ok = t < T1;
+        if (tile_ok && (NPIX % 16 == 0 || p0 + 3 < NPIX)) {
+            *reinterpret_cast<float4*>(dst) = float4{fmaxf(am[0] + bias_m, 0.f), fmaxf(am[1] + bias_m, 0.f),
+                                                     fmaxf(am[2] + bias_m, 0.f), fmaxf(am[3] + bias_m, 0.f)};
+        } else if (tile_ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (p0 + r < NPIX) dst[r] = fmaxf(am[r] + bias_m, 0.f);
+        }
+        // leftover: cout 16 + i in vgpr i, pixel = lr, partial over kq -> combine, lane group kq stores cout 16 + kq
+        const float v0 = sum_ksub(al[0]), v1 = sum_ksub(al[1]), v2 = sum_ksub(al[2]), v3 = sum_ksub(al[3]);
+        const float val = kq == 0 ? v0 : (kq == 1 ? v1 : (kq == 2 ? v2 : v3));
+        if (tile_ok && (NPIX % 16 == 0 || tc * 16 + lr < NPIX)) s_out[(16 + kq) * PLANE + tc * 16 + lr] = fmaxf(val + bias_l, 0.f);
     }
 }
 
@@ -157,6 +199,9 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         stp = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
         if (tid == 0) stp[0] = __builtin_amdgcn_s_memtime();
     }
+#ifdef SCS_PRIO
+    __builtin_amdgcn_s_setprio(SCS_PRIO);      // staging / epilogue phases are short and latency-bound: let them win issue
+#endif
     const float* __restrict__ wsrc = pick3(a.w, tower);
     const float* __restrict__ insrc = pick3(a.in, tower);
 
@@ -241,8 +286,11 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
                 s_x[e] = ok ? vol[((size_t)vx * a.dimy + vy) * a.dimz + vz] : 0.f;
             }
         }
+        float* s_w1 = s_x + C::XS_ROWS_FLOATS + 4;
+        for (int e = tid; e < kW1Floats; e += 256) s_w1[e] = pick3(a.w1, tower)[e];
         __syncthreads();
-        conv1_to_lds<C::PLANE, C::HINB>(s_x, pick3(a.w1, tower), s_in, tid);
+        if constexpr (C::STAMP) { if (tid == 0) stp[5] = __builtin_amdgcn_s_memtime(); }
+        conv1_to_lds<C::PLANE, C::HINB>(s_x, s_w1, s_in, wave, lane);
     }
 
     if constexpr (C::STAMP) { if (tid == 0) stp[1] = __builtin_amdgcn_s_memtime(); }
@@ -290,6 +338,9 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     __syncthreads();
     if constexpr (C::STAMP) { if (tid == 0) stp[2] = __builtin_amdgcn_s_memtime(); }
 
+#ifdef SCS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const int boff = kq * C::NS16 + lr;                       // main part: W[k = 4s + kq][cout = 16 nt + lr]
     const int loff = 36 * C::NS16 + kq * C::L4 + (lane & 3);   // leftover: W[k = 4s + kq][cout = 16 NT16 + 4u + (lane&3)]
     const bool last_ok = (wave + 4 * (C::TPW - 1)) < C::TILES;
@@ -334,6 +385,9 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     }
 
     if constexpr (C::STAMP) { if (tid == 0) stp[3] = __builtin_amdgcn_s_memtime(); }
+#ifdef SCS_PRIO
+    __builtin_amdgcn_s_setprio(SCS_PRIO);
+#endif
     // ---- epilogue: D row = 4*kq + r (pixel / window position), column = lr (cout).  Results are restaged in
     // LDS as [g][cout][OSTR] (every wave has passed the loop's last barrier, so the operand buffers are free) and
     // leave as whole rows: 64 lanes -> 256 contiguous bytes, instead of 64 scattered dwords per store.
@@ -377,15 +431,13 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         if (t >= C::TILES) continue;
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
-            f32x4 v = acc4[j][u];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] += __shfl_xor(v[i], 16); v[i] += __shfl_xor(v[i], 32); }
-            float val = kq == 0 ? v[0] : (kq == 1 ? v[1] : (kq == 2 ? v[2] : v[3]));    // this lane stores cout 4u + kq
+            const float v0 = sum_ksub(acc4[j][u][0]), v1 = sum_ksub(acc4[j][u][1]), v2 = sum_ksub(acc4[j][u][2]),
+                        v3 = sum_ksub(acc4[j][u][3]);
+            float val = kq == 0 ? v0 : (kq == 1 ? v1 : (kq == 2 ? v2 : v3));            // this lane stores cout 4u + kq
             const int co = C::NT16 * 16 + u * 4 + kq;
             const float bv = bv4[u];
             if constexpr (C::POOL) {
-                val = fmaxf(val, __shfl_xor(val, 1));
-                val = fmaxf(val, __shfl_xor(val, 2));
+                val = max_quad(val);
                 const int widx = t * 4 + ((lane & 15) >> 2);
                 if ((lane & 3) == 0 && widx < C::G * C::WB) {
                     const int g = widx / C::WB;
@@ -403,13 +455,20 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
             }
         }
     }
+    if constexpr (C::STAMP) { if (tid == 0) stp[6] = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
+    if constexpr (C::STAMP) { if (tid == 0) stp[7] = __builtin_amdgcn_s_memtime(); }
     {
         float* __restrict__ outp = pick3(a.out, tower) + (size_t)g0 * C::COUT * C::OUTPIX + band * C::OUTB;
         const int total = ng * C::COUT * C::OUTB;
-        for (int e = tid; e < total; e += 256) {
-            const int gc = e / C::OUTB, r = e - gc * C::OUTB;
-            outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
+        constexpr int ITER = (C::G * C::COUT * C::OUTB + 255) / 256;
+#pragma unroll 2
+        for (int it = 0; it < ITER; ++it) {
+            const int e = tid + 256 * it;
+            if (e < total) {
+                const int gc = e / C::OUTB, r = e - gc * C::OUTB;
+                outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
+            }
         }
     }
     if constexpr (C::STAMP) { if (tid == 0) stp[4] = __builtin_amdgcn_s_memtime(); }

@@ -61,22 +61,25 @@ __global__ void pack_conv_kernel(const float* __restrict__ W, const float* __res
     }
 }
 
-// conv1: w1b[c][10] = 9 correlation taps (flipped, BN scale folded) then the folded bias
+// conv1 operands for the MFMA form (conv_mfma.h: conv1_to_lds): [12][16] main, [12][4] leftover, [20] bias;
+// element (k = tap, c) = W[c][0][2-dy][2-dx] * scale[c] (true conv -> correlation, BN folded), rows 9..11 zero
 __global__ void pack_conv1_kernel(const float* __restrict__ W, const float* __restrict__ bn, int fold,
-                                  float* __restrict__ w1b) {
+                                  float* __restrict__ w1p) {
     const int t = threadIdx.x;
-    if (t < 200) {
-        const int c = t / 10, k = t % 10;
-        float v;
+    if (t >= kW1Floats) return;
+    float v = 0.f;
+    if (t < 240) {
+        const int k = t < 192 ? t / 16 : (t - 192) / 4;
+        const int c = t < 192 ? t % 16 : 16 + (t - 192) % 4;
         if (k < 9) {
-            const int dy = k / 3, dx = k % 3;
-            v = W[(c * 3 + (2 - dy)) * 3 + (2 - dx)];
-            if (fold) v *= bn[20 + c] * bn[60 + c];                     // gamma * inv_std
-        } else {
-            v = fold ? bn[c] - bn[40 + c] * bn[20 + c] * bn[60 + c] : 0.f;   // beta - mean*scale
+            v = W[(c * 3 + (2 - k / 3)) * 3 + (2 - k % 3)];
+            if (fold) v *= bn[20 + c] * bn[60 + c];                          // gamma * inv_std
         }
-        w1b[t] = v;
+    } else {
+        const int c = t - 240;
+        v = fold ? bn[c] - bn[40 + c] * bn[20 + c] * bn[60 + c] : 0.f;       // beta - mean*scale
     }
+    w1p[t] = v;
 }
 
 // dense: Wp[k][n] over [K4][NS] zero padded, bias padded to NS
@@ -178,7 +181,7 @@ static int alloc_packed(scs_ctx* h) {
     auto take = [&](size_t floats) { size_t o = off; off += align64(floats); return o; };
     size_t o_c1w[kTowers], o_c1b[kTowers], o_cw[kTowers][kConvs], o_cb[kTowers][kConvs], o_d1w[kTowers], o_d1b[kTowers];
     for (int t = 0; t < kTowers; ++t) {
-        o_c1w[t] = take(200); o_c1b[t] = take(1);
+        o_c1w[t] = take(kW1Floats); o_c1b[t] = take(1);
         for (int i = 1; i < kConvs; ++i) { o_cw[t][i] = take(conv_pack_floats(i)); o_cb[t][i] = take(n_tiles(kCout[i]) * 16); }
         o_d1w[t] = take((size_t)kFlat * gemm_ns(kD1)); o_d1b[t] = take(gemm_ns(kD1));
     }
@@ -205,7 +208,7 @@ int repack_inference(scs_ctx* h, hipStream_t st) {
     constexpr HeadOff H = head_off();
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
-        hipLaunchKernelGGL(pack_conv1_kernel, dim3(1), dim3(256), 0, st, P + T.convW[0], P + T.bn[0], 1, h->pk.conv1w[t]);
+        hipLaunchKernelGGL(pack_conv1_kernel, dim3(1), dim3(320), 0, st, P + T.convW[0], P + T.bn[0], 1, h->pk.conv1w[t]);
         for (int i = 1; i < kConvs; ++i)
             hipLaunchKernelGGL(pack_conv_kernel, dim3(32), dim3(256), 0, st, P + T.convW[i], P + T.bn[i], kCin[i],
                                kCout[i], 1, h->pk.convw[t][i], h->pk.convb[t][i]);

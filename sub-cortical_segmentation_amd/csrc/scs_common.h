@@ -92,7 +92,7 @@ constexpr int gemm_ns(int n) { return n_stride(n); }
 constexpr int round4(int k) { return (k + 3) / 4 * 4; }
 
 struct PackedNet {                 // device pointers into one packed-weights allocation
-    float* conv1w[kTowers];        // [20][10]: 9 folded/flipped taps + bias per channel
+    float* conv1w[kTowers];        // conv1 MFMA operands: [12][16] + [12][4] + bias[20]
     float* conv1b[kTowers];        // (unused)
     float* convw[kTowers][kConvs]; // i = 1..4: packed MFMA layout
     float* convb[kTowers][kConvs]; // [NT*16] zero padded

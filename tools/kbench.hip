@@ -30,7 +30,7 @@ static void run(const char* name, int n, int rounds, double macs_per_patch_tower
         a.in[t] = dev_random((size_t)n * in_per, 1 + t);
         a.w[t] = dev_random((size_t)C::NC4 * C::WCHUNK, 10 + t);
         a.bias[t] = dev_random(C::NT * 16, 20 + t);
-        a.w1[t] = dev_random(200, 30 + t);
+        a.w1[t] = dev_random(kW1Floats, 30 + t);
         float* o; CK(hipMalloc(&o, (size_t)n * C::COUT * C::OUTPIX * 4)); a.out[t] = o;
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -65,7 +65,7 @@ static void stamps(const char* name, int n) {
         a.in[t] = dev_random((size_t)n * in_per, 1 + t);
         a.w[t] = dev_random((size_t)C::NC4 * C::WCHUNK, 10 + t);
         a.bias[t] = dev_random(C::NT * 16, 20 + t);
-        a.w1[t] = dev_random(200, 30 + t);
+        a.w1[t] = dev_random(kW1Floats, 30 + t);
         float* o; CK(hipMalloc(&o, (size_t)n * C::COUT * C::OUTPIX * 4)); a.out[t] = o;
     }
     const size_t nwg = (size_t)((n + C::G - 1) / C::G) * C::NB * kTowers;
@@ -75,15 +75,20 @@ static void stamps(const char* name, int n) {
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(nwg * 8);
     CK(hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost));
-    double d[4] = {0, 0, 0, 0};
+    double d[4] = {0, 0, 0, 0}, in_wait = 0, epi_lds = 0, epi_bar = 0;
     unsigned long long tmin = ~0ull, tmax = 0;
     for (size_t w = 0; w < nwg; ++w) {
         for (int i = 0; i < 4; ++i) d[i] += (double)(h[w * 8 + i + 1] - h[w * 8 + i]);
+        if (C::SRC == SRC_CONV1) in_wait += (double)(h[w * 8 + 5] - h[w * 8 + 0]);
+        epi_lds += (double)(h[w * 8 + 6] - h[w * 8 + 3]);
+        epi_bar += (double)(h[w * 8 + 7] - h[w * 8 + 6]);
         tmin = h[w * 8] < tmin ? h[w * 8] : tmin;
         tmax = h[w * 8 + 4] > tmax ? h[w * 8 + 4] : tmax;
     }
     printf("%-18s per-WG s_memtime ticks: stage %.0f | w0+abase+barrier %.0f | main loop %.0f | epilogue %.0f | total %.0f ; kernel span %.0f ; WGs %zu\n",
            name, d[0] / nwg, d[1] / nwg, d[2] / nwg, d[3] / nwg, (d[0] + d[1] + d[2] + d[3]) / nwg, (double)(tmax - tmin), nwg);
+    printf("                     of stage: input-in-LDS at %.0f ; of epilogue: acc->LDS %.0f, barrier %.0f, copy-out %.0f\n", in_wait / nwg,
+           epi_lds / nwg, epi_bar / nwg, (d[3] - epi_lds - epi_bar) / nwg);
 }
 
 int main(int argc, char** argv) {

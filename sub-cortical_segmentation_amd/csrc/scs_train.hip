@@ -15,6 +15,7 @@
 #include "conv_mfma.h"
 #include "gemm_mfma.h"
 #include "scs_ctx.h"
+#include "wgrad_mfma.h"
 
 namespace scs {
 
@@ -32,7 +33,11 @@ using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 1040, 1, 1>;
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 constexpr bool kPool[kConvs] = {false, true, false, true, false};
 constexpr int kRedSplit = 16;     // batch slices per channel in the two-stage BN reductions
-constexpr int kWgSplit = 4;       // batch slices in the weight-gradient kernel
+constexpr int kWgSplit = 4;       // batch slices in the vector-ALU weight-gradient kernel (conv1, conv5)
+constexpr int kWgSlicesMax = 128; // batch slices of the MFMA weight-gradient kernel (conv2..4)
+using WG2 = WgCfg<20, 20, 30>;
+using WG3 = WgCfg<20, 40, 14>;
+using WG4 = WgCfg<40, 40, 12>;
 
 }  // namespace scs
 
@@ -91,7 +96,7 @@ static int train_ensure(scs_ctx* h, int n) {
             for (int i = 0; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
         SCS_HIP(hipMalloc(&w->red_part, (size_t)kTowers * 64 * kRedSplit * 2 * sizeof(double)));
-        SCS_HIP(hipMalloc(&w->wg_part, (size_t)kTowers * kWgSplit * 60 * 40 * 9 * sizeof(float)));
+        SCS_HIP(hipMalloc(&w->wg_part, (size_t)kTowers * kWgSlicesMax * 60 * 40 * 9 * sizeof(float)));
     }
     if (n <= w->cap) return SCS_OK;
     if (w->base) { SCS_HIP(hipFree(w->base)); w->base = nullptr; }
@@ -381,13 +386,17 @@ __global__ void dropout_bwd_kernel(Ptr3 g, const uint8_t* mask, int n) {
         p[e] = mask[(size_t)t * total + e] ? p[e] * 2.f : 0.f;
 }
 
-// out[j] = sum_r g[r][ldg + j]
-__global__ void colsum_kernel(const float* g, int ldg, int n, int cols, float* out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
+// out[j] = sum_r g[r][ldg + j]   (64 columns x 4 row groups per block, fixed summation order)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* g, int ldg, int n, int cols, float* out) {
+    __shared__ double s_p[4][64];
+    const int cj = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cj;
     double s = 0;
-    for (int r = 0; r < n; ++r) s += g[(size_t)r * ldg + j];
-    out[j] = (float)s;
+    if (j < cols)
+        for (int r = rg; r < n; r += 4) s += g[(size_t)r * ldg + j];
+    s_p[rg][cj] = s;
+    __syncthreads();
+    if (rg == 0 && j < cols) out[j] = (float)(s_p[0][cj] + s_p[1][cj] + s_p[2][cj] + s_p[3][cj]);
 }
 
 // ---- generic strided SGEMM on the vector ALU: C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
@@ -401,12 +410,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
     float acc[4][4] = {};
+    const bool a_kfast = P.sak == 1, b_nfast = P.sbn == 1;
     for (int k0 = 0; k0 < g.K; k0 += 16) {
         for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-            const int kk = e & 15, mm = e >> 4;               // consecutive threads walk k (fast when sak == 1) ...
+            // consecutive threads walk whichever index is contiguous in memory (wave-uniform choice)
+            const int kk = a_kfast ? (e & 15) : (e >> 6), mm = a_kfast ? (e >> 4) : (e & 63);
             const int m = m0 + mm, k = k0 + kk;
             sA[kk][mm] = (m < g.M && k < g.K) ? P.A[m * P.sam + k * P.sak] : 0.f;
-            const int nn = e & 63, kb = e >> 6;               // ... and n for B (fast when sbn == 1)
+            const int nn = b_nfast ? (e & 63) : (e >> 4), kb = b_nfast ? (e >> 6) : (e & 15);
             const int n = n0 + nn, k2 = k0 + kb;
             sB[kb][nn] = (n < g.N && k2 < g.K) ? P.B[k2 * P.sbk + n * P.sbn] : 0.f;
         }
@@ -556,11 +567,11 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(CPtr3 X, CPtr3 dZ, i
     }
 }
 
-__global__ void wgrad_final_kernel(const float* part, int Cin, int Cout, float* grads, int w_off0, int tower_stride) {
+__global__ void wgrad_final_kernel(const float* part, int nsplit, int Cin, int Cout, float* grads, int w_off0, int tower_stride) {
     const int t = blockIdx.y, tot = Cout * Cin * 9;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
         float v = 0.f;
-        for (int sp = 0; sp < kWgSplit; ++sp) v += part[((size_t)t * kWgSplit + sp) * tot + e];
+        for (int sp = 0; sp < nsplit; ++sp) v += part[((size_t)t * nsplit + sp) * tot + e];
         const int k = e % 9, oc = e / 9;
         grads[w_off0 + t * tower_stride + oc * 9 + (2 - k / 3) * 3 + (2 - k % 3)] = v;     // flip back to Lasagne's W
     }
@@ -582,6 +593,7 @@ static int set_train_attrs() {
     if (done) return SCS_OK;
     SCS_HIP(conv_set_attr<TF2>()); SCS_HIP(conv_set_attr<TF3>()); SCS_HIP(conv_set_attr<TF4>()); SCS_HIP(conv_set_attr<TF5>());
     SCS_HIP(conv_set_attr<DG5>()); SCS_HIP(conv_set_attr<DG4>()); SCS_HIP(conv_set_attr<DG3>()); SCS_HIP(conv_set_attr<DG2>());
+    SCS_HIP(wgrad_set_attr<WG2>()); SCS_HIP(wgrad_set_attr<WG3>()); SCS_HIP(wgrad_set_attr<WG4>());
     done = true;
     return SCS_OK;
 }
@@ -691,7 +703,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     s.M = kFC2; s.N = kClasses; s.K = n;
     s.p[0] = SgemmProblem{w->R2, 1, kFC2ld, w->dlog, 16, 1, G + H.outW, kClasses};
     sgemm(s, 1, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(64), 0, st, w->dlog, 16, n, kClasses, G + H.outb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, w->dlog, 16, n, kClasses, G + H.outb);
     s.M = n; s.N = kFC2; s.K = kClasses;
     s.p[0] = SgemmProblem{w->dlog, 16, 1, P + H.outW, 1, kClasses, w->dR2, kFC2ld};
     sgemm(s, 1, st);
@@ -700,7 +712,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     s.M = kFC1 + kAtlas; s.N = kFC2; s.K = n;
     s.p[0] = SgemmProblem{w->cat2, 1, kFC1ld, w->dR2, kFC2ld, 1, G + H.fc2W, kFC2};
     sgemm(s, 1, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3((kFC2 + 63) / 64), dim3(64), 0, st, w->dR2, kFC2ld, n, kFC2, G + H.fc2b);
+    hipLaunchKernelGGL(colsum_kernel, dim3((kFC2 + 63) / 64), dim3(256), 0, st, w->dR2, kFC2ld, n, kFC2, G + H.fc2b);
     s.M = n; s.N = kFC1; s.K = kFC2;
     s.p[0] = SgemmProblem{w->dR2, kFC2ld, 1, P + H.fc2W, 1, kFC2, w->dcat, kFC1};
     sgemm(s, 1, st);
@@ -709,7 +721,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     s.M = kFlat; s.N = kFC1; s.K = n;
     s.p[0] = SgemmProblem{w->featd, 1, kFlat, w->dcat, kFC1, 1, G + H.fc1W, kFC1};
     sgemm(s, 1, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64), dim3(64), 0, st, w->dcat, kFC1, n, kFC1, G + H.fc1b);
+    hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64), dim3(256), 0, st, w->dcat, kFC1, n, kFC1, G + H.fc1b);
     s.M = n; s.N = kFlat; s.K = kFC1;
     s.p[0] = SgemmProblem{w->dcat, kFC1, 1, P + H.fc1W, 1, kFC1, w->dfeat, kFlat};
     sgemm(s, 1, st);
@@ -723,7 +735,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     sgemm(s, kTowers, st);
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
-        hipLaunchKernelGGL(colsum_kernel, dim3((kD1 + 63) / 64), dim3(64), 0, st, w->dfeat + t * kD1, kFlat, n, kD1, G + T.d1b);
+        hipLaunchKernelGGL(colsum_kernel, dim3((kD1 + 63) / 64), dim3(256), 0, st, w->dfeat + t * kD1, kFlat, n, kD1, G + T.d1b);
     }
     s.M = n; s.N = kFlat; s.K = kD1;
     for (int t = 0; t < kTowers; ++t) {
@@ -755,8 +767,18 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         CPtr3 Xi;
         for (int t = 0; t < kTowers; ++t) Xi.p[t] = (i == 0) ? xin[t] : w->X[t][i];
         CPtr3 dZc{{w->dZ[0], w->dZ[1], w->dZ[2]}};
-        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kCin[i], C / 4, kTowers * kWgSplit), dim3(256), 0, st, Xi, dZc, n, kCin[i], C, kHin[i], w->wg_part);
-        hipLaunchKernelGGL(wgrad_final_kernel, dim3(32, kTowers), dim3(256), 0, st, w->wg_part, kCin[i], C, G, T0.convW[i], kTowerFloats);
+        if (i >= 1 && i <= 3) {
+            WgArgs wa{};
+            for (int t = 0; t < kTowers; ++t) { wa.X[t] = Xi.p[t]; wa.dZ[t] = w->dZ[t]; }
+            wa.part = w->wg_part; wa.n = n; wa.slices = n < kWgSlicesMax ? n : kWgSlicesMax;
+            if (i == 1) wgrad_launch<WG2>(wa, st);
+            else if (i == 2) wgrad_launch<WG3>(wa, st);
+            else wgrad_launch<WG4>(wa, st);
+            hipLaunchKernelGGL(wgrad_final_kernel, dim3(32, kTowers), dim3(256), 0, st, w->wg_part, wa.slices, kCin[i], C, G, T0.convW[i], kTowerFloats);
+        } else {
+            hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kCin[i], C / 4, kTowers * kWgSplit), dim3(256), 0, st, Xi, dZc, n, kCin[i], C, kHin[i], w->wg_part);
+            hipLaunchKernelGGL(wgrad_final_kernel, dim3(32, kTowers), dim3(256), 0, st, w->wg_part, kWgSplit, kCin[i], C, G, T0.convW[i], kTowerFloats);
+        }
         if (i > 0) {
             ConvArgs a{};
             a.n = n;

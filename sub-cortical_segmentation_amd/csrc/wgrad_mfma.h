@@ -1,0 +1,160 @@
+// Weight gradient of the 3x3 true convolutions on the fp32 matrix cores.
+//
+//   dW[o][c][2-dy][2-dx] = sum_{n,y,x} dz[n][o][y][x] * X[n][c][y+dy][x+dx]        (Theano autodiff of nets.py:171-177)
+//
+// GEMM view per patch:  D[(c,tap)][o] += sum_pixels  Xs[(c,tap)][pixel] * dz[pixel][o]  with
+//   rows  = (input channel, tap) pairs (16 per MFMA tile; the row's LDS base = c*plane + tap offset),
+//   cols  = output channels (16-wide v_mfma_f32_16x16x4_f32 blocks + 4-wide v_mfma_f32_4x4x1_16b_f32 blocks),
+//   k     = output pixels, 4 per step: the output row is padded to a multiple of 4 with ZERO dz columns so a k-step
+//           never straddles image rows and every operand address is base + immediate.
+// A workgroup walks a slice of the batch with its accumulators live, then writes one partial dW; partials are summed
+// in a fixed order (deterministic gradients) by wgrad_final_kernel.
+#pragma once
+#include "conv_mfma.h"
+
+namespace scs {
+
+template <int CIN_, int COUT_, int HIN_>
+struct WgCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2;
+    static constexpr int WOP = (HO + 3) / 4 * 4;             // padded output row
+    static constexpr int XPL = HIN_ * HIN_ + 8;              // X plane stride (tail absorbs the padded-column reads)
+    static constexpr int ZPL = HO * WOP;                     // dz plane stride
+    static constexpr int J = CIN_ * 9;                       // (c,tap) rows
+    static constexpr int MT = (J + 15) / 16;
+    static constexpr int MTW = (MT + 3) / 4;                 // row tiles per wave
+    static constexpr int NT16 = nt16(COUT_), NT4 = nt4(COUT_);
+    static constexpr int X_FLOATS = CIN_ * XPL, Z_FLOATS = COUT_ * ZPL;
+    static constexpr size_t LDS_BYTES = (size_t)(X_FLOATS + Z_FLOATS) * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+struct WgArgs {
+    const float* X[kTowers];      // [n][CIN][HIN][HIN]
+    const float* dZ[kTowers];     // [n][COUT][HO][HO]
+    float* part;                  // [tower][slice][COUT][CIN][9]
+    int n, slices;
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_x = smem;
+    float* s_z = smem + C::X_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int slice = blockIdx.x, tower = blockIdx.y;
+    const float* __restrict__ X = pick3(a.X, tower);
+    const float* __restrict__ dZ = pick3(a.dZ, tower);
+    const int per = (a.n + a.slices - 1) / a.slices, n0 = slice * per, n1 = min(a.n, n0 + per);
+
+    // zero once: dz padding columns and the X plane tails stay zero for the whole kernel
+    for (int e = tid; e < C::X_FLOATS + C::Z_FLOATS; e += 256) smem[e] = 0.f;
+
+    // per-lane row bases of this wave's (c,tap) tiles; rows beyond J are clamped (computed, never stored)
+    int xbase[C::MTW];
+#pragma unroll
+    for (int m = 0; m < C::MTW; ++m) {
+        const int j = min((wave + 4 * m) * 16 + lr, C::J - 1);
+        const int c = j / 9, tap = j - c * 9;
+        xbase[m] = c * C::XPL + (tap / 3) * C::HIN + tap % 3 + kq;
+    }
+    const int zoff16 = lr * C::ZPL + kq;                                   // dz[o = 16 nt + lr][pixel 4s + kq]
+    const int zoff4 = (C::NT16 * 16 + (lane & 3)) * C::ZPL + kq;           // dz[o = 16 NT16 + 4u + (lane&3)][pixel 4s + kq]
+
+    f32x4 acc[C::MTW][C::NT16 > 0 ? C::NT16 : 1], acc4[C::MTW][C::NT4 > 0 ? C::NT4 : 1];
+#pragma unroll
+    for (int m = 0; m < C::MTW; ++m) {
+#pragma unroll
+        for (int nt = 0; nt < C::NT16; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < C::NT4; ++u) acc4[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int ni = n0; ni < n1; ++ni) {
+        __syncthreads();                                                   // previous patch consumed (and the zero fill)
+        {
+            constexpr int HW = C::HIN * C::HIN;
+            const float* __restrict__ xs = X + (size_t)ni * C::CIN * HW;
+            if constexpr (HW % 4 == 0 && C::XPL % 4 == 0) {
+                const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xs);
+                staged_copy<C::CIN * HW / 4, float4>(
+                    tid, [&](int e) { return x4[e]; },
+                    [&](int e, float4 v) { const int pl = e / (HW / 4), r = e - pl * (HW / 4);
+                                           reinterpret_cast<float4*>(s_x)[pl * (C::XPL / 4) + r] = v; });
+            } else {
+                staged_copy<C::CIN * HW, float>(
+                    tid, [&](int e) { return xs[e]; },
+                    [&](int e, float v) { const int pl = e / HW, r = e - pl * HW; s_x[pl * C::XPL + r] = v; });
+            }
+            constexpr int PZ = C::HO * C::HO;
+            const float* __restrict__ zs = dZ + (size_t)ni * C::COUT * PZ;
+            staged_copy<C::COUT * PZ, float>(
+                tid, [&](int e) { return zs[e]; },
+                [&](int e, float v) { const int pl = e / PZ, r = e - pl * PZ, y = r / C::HO, x = r - y * C::HO;
+                                      s_z[pl * C::ZPL + y * C::WOP + x] = v; });
+        }
+        __syncthreads();
+        for (int y = 0; y < C::HO; ++y) {
+            const float* __restrict__ sxr = s_x + y * C::HIN;
+            const float* __restrict__ szr = s_z + y * C::WOP;
+#pragma unroll
+            for (int xg = 0; xg < C::WOP / 4; ++xg) {
+                float b[C::NT16 > 0 ? C::NT16 : 1], b4[C::NT4 > 0 ? C::NT4 : 1];
+#pragma unroll
+                for (int nt = 0; nt < C::NT16; ++nt) b[nt] = szr[zoff16 + nt * 16 * C::ZPL + 4 * xg];
+#pragma unroll
+                for (int u = 0; u < C::NT4; ++u) b4[u] = szr[zoff4 + u * 4 * C::ZPL + 4 * xg];
+#pragma unroll
+                for (int m = 0; m < C::MTW; ++m) {
+                    const float av = sxr[xbase[m] + 4 * xg];
+#pragma unroll
+                    for (int nt = 0; nt < C::NT16; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < C::NT4; ++u)
+                        acc4[m][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[m][u], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- partial dW of this slice: part[tower][slice][o][j = c*9 + tap]
+    float* __restrict__ out = a.part + ((size_t)tower * a.slices + slice) * C::COUT * C::J;
+#pragma unroll
+    for (int m = 0; m < C::MTW; ++m) {
+        const int t = wave + 4 * m;
+        if (t >= C::MT) continue;
+#pragma unroll
+        for (int nt = 0; nt < C::NT16; ++nt) {
+            const int o = nt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = t * 16 + kq * 4 + r;
+                if (j < C::J) out[o * C::J + j] = acc[m][nt][r];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < C::NT4; ++u) {
+            const float v0 = sum_ksub(acc4[m][u][0]), v1 = sum_ksub(acc4[m][u][1]), v2 = sum_ksub(acc4[m][u][2]),
+                        v3 = sum_ksub(acc4[m][u][3]);
+            const float val = kq == 0 ? v0 : (kq == 1 ? v1 : (kq == 2 ? v2 : v3));
+            const int o = C::NT16 * 16 + u * 4 + kq, j = t * 16 + lr;
+            if (j < C::J) out[o * C::J + j] = val;
+        }
+    }
+}
+
+template <class C>
+inline hipError_t wgrad_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_mfma_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)C::LDS_BYTES);
+}
+
+template <class C>
+inline void wgrad_launch(const WgArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_mfma_kernel<C>, dim3(a.slices, kTowers), dim3(256), C::LDS_BYTES, st, a);
+}
+
+}  // namespace scs

@@ -34,10 +34,12 @@ constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 constexpr bool kPool[kConvs] = {false, true, false, true, false};
 constexpr int kRedSplit = 16;     // batch slices per channel in the two-stage BN reductions
 constexpr int kWgSplit = 4;       // batch slices in the vector-ALU weight-gradient kernel (conv1, conv5)
-constexpr int kWgSlicesMax = 128; // batch slices of the MFMA weight-gradient kernel (conv2..4)
+constexpr int kWgSlicesMax = 64;  // batch slices of the MFMA weight-gradient kernel (conv2..4)
 using WG2 = WgCfg<20, 20, 30>;
 using WG3 = WgCfg<20, 40, 14>;
 using WG4 = WgCfg<40, 40, 12>;
+using WG1 = WgCfg<1, 20, 32>;
+using WG5 = WgCfg<40, 60, 5>;
 
 }  // namespace scs
 
@@ -59,6 +61,8 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* wdg[kTowers][kConvs]{};             // data-gradient packs (i >= 1)
     float* pack_base = nullptr;
     double* eval_acc = nullptr;                // [2]: loss sum, correct count
+    float* actT = nullptr;                     // transposed activations for the dense weight-gradient GEMMs [3][556][cap]
+    float* wT = nullptr;                       // transposed dense weights for the dense data-gradient GEMMs
     double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN reductions
     float* wg_part = nullptr;                  // [3][kWgSplit][60*40*9] partial weight gradients
 };
@@ -75,6 +79,7 @@ void train_free(scs_ctx* h) {
     if (w->pack_base) (void)hipFree(w->pack_base);
     if (w->eval_acc) (void)hipFree(w->eval_acc);
     if (w->red_part) (void)hipFree(w->red_part);
+    if (w->wT) (void)hipFree(w->wT);
     if (w->wg_part) (void)hipFree(w->wg_part);
     delete w;
     h->tws = nullptr;
@@ -95,6 +100,7 @@ static int train_ensure(scs_ctx* h, int n) {
         for (int t = 0; t < kTowers; ++t)
             for (int i = 0; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
+        SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540) * sizeof(float)));
         SCS_HIP(hipMalloc(&w->red_part, (size_t)kTowers * 64 * kRedSplit * 2 * sizeof(double)));
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)kTowers * kWgSlicesMax * 60 * 40 * 9 * sizeof(float)));
     }
@@ -118,7 +124,7 @@ static int train_ensure(scs_ctx* h, int n) {
     const size_t o_feat = take(c * kFlat), o_featd = take(c * kFlat), o_R1 = take(c * kFC1), o_cat2 = take(c * kFC1ld),
                  o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
-                 o_st = take((size_t)kTowers * kConvs * 4 * 64);
+                 o_st = take((size_t)kTowers * kConvs * 4 * 64), o_at = take((size_t)kTowers * kFC1ld * c);
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
     for (int t = 0; t < kTowers; ++t) {
@@ -130,6 +136,7 @@ static int train_ensure(scs_ctx* h, int n) {
     w->R2 = w->base + o_R2; w->probs = w->base + o_probs; w->dlog = w->base + o_dlog; w->dR2 = w->base + o_dR2;
     w->dcat = w->base + o_dcat; w->dfeat = w->base + o_dfeat; w->loss_rows = w->base + o_lr; w->loss_dev = w->base + o_ld;
     w->stats = w->base + o_st;
+    w->actT = w->base + o_at;
     SCS_HIP(hipMalloc(&w->masks, c * kFlat * 5));
     w->cap = (int)c;
     return SCS_OK;
@@ -399,6 +406,31 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* g, int ldg, in
     if (rg == 0 && j < cols) out[j] = (float)(s_p[0][cj] + s_p[1][cj] + s_p[2][cj] + s_p[3][cj]);
 }
 
+// out[c][r] (ldo) = in[r][c] (ldi), r < rows, c < cols; blockIdx.z selects one of up to 3 problems
+struct TrProblem { const float* in; int ldi; float* out; int ldo; };
+struct TrArgs { TrProblem p[kTowers]; int rows, cols; };
+__global__ __launch_bounds__(256) void transpose_kernel(TrArgs a) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z;
+    const TrProblem P = z == 0 ? a.p[0] : (z == 1 ? a.p[1] : a.p[2]);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < a.rows && c < a.cols) ? P.in[(size_t)r * P.ldi + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < a.cols && r < a.rows) P.out[(size_t)c * P.ldo + r] = tile[tx][ty + 8 * i];
+    }
+}
+static void transpose(const TrArgs& a, int nprob, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((a.cols + 31) / 32, (a.rows + 31) / 32, nprob), dim3(256), 0, st, a);
+}
+
 // ---- generic strided SGEMM on the vector ALU: C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
 struct SgemmProblem { const float* A; long sam, sak; const float* B; long sbk, sbn; float* C; long ldc; };
 struct SgemmArgs { SgemmProblem p[kTowers]; int M, N, K; };
@@ -594,6 +626,7 @@ static int set_train_attrs() {
     SCS_HIP(conv_set_attr<TF2>()); SCS_HIP(conv_set_attr<TF3>()); SCS_HIP(conv_set_attr<TF4>()); SCS_HIP(conv_set_attr<TF5>());
     SCS_HIP(conv_set_attr<DG5>()); SCS_HIP(conv_set_attr<DG4>()); SCS_HIP(conv_set_attr<DG3>()); SCS_HIP(conv_set_attr<DG2>());
     SCS_HIP(wgrad_set_attr<WG2>()); SCS_HIP(wgrad_set_attr<WG3>()); SCS_HIP(wgrad_set_attr<WG4>());
+    SCS_HIP(wgrad_set_attr<WG1>()); SCS_HIP(wgrad_set_attr<WG5>());
     done = true;
     return SCS_OK;
 }
@@ -708,41 +741,69 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     s.p[0] = SgemmProblem{w->dlog, 16, 1, P + H.outW, 1, kClasses, w->dR2, kFC2ld};
     sgemm(s, 1, st);
     hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC2), dim3(256), 0, st, w->dR2, kFC2ld, w->R2, kFC2ld, (const uint8_t*)nullptr, n, kFC2);
-    // fc_2
-    s.M = kFC1 + kAtlas; s.N = kFC2; s.K = n;
-    s.p[0] = SgemmProblem{w->cat2, 1, kFC1ld, w->dR2, kFC2ld, 1, G + H.fc2W, kFC2};
-    sgemm(s, 1, st);
+    // The remaining dense gradients run on the MFMA GEMM: weight gradients take the transposed activation as A
+    // ([in][n]) and the upstream gradient as W ([n][out]); data gradients take the transposed weight as W.
+    const int ldT = w->cap;
+    float* wT2 = w->wT;                       // [270][540]  = fc_2.W[:540]^T
+    float* wT1 = wT2 + 270 * 540;             // [540][540]  = FC1.W^T
+    float* wTd = wT1 + 540 * 540;             // [3][180][540] = d1.W^T
+    {
+        TrArgs tr{};
+        tr.rows = kFC1; tr.cols = kFC2; tr.p[0] = TrProblem{P + H.fc2W, kFC2, wT2, kFC1};
+        transpose(tr, 1, st);
+        tr.rows = kFlat; tr.cols = kFC1; tr.p[0] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat};
+        transpose(tr, 1, st);
+        tr.rows = kFlat; tr.cols = kD1;
+        for (int t = 0; t < kTowers; ++t) { const TowerOff T = tower_off(t * kTowerFloats); tr.p[t] = TrProblem{P + T.d1W, kD1, wTd + t * kD1 * kFlat, kFlat}; }
+        transpose(tr, kTowers, st);
+    }
+    GemmArgs bg{};
+    bg.relu = 0;
+    // fc_2: dW2 = cat2^T dPre2, db2, dcat = dPre2 W2[:540]^T
+    {
+        TrArgs tr{}; tr.rows = n; tr.cols = kFC1 + kAtlas; tr.p[0] = TrProblem{w->cat2, kFC1ld, w->actT, ldT};
+        transpose(tr, 1, st);
+    }
+    bg.M = kFC1 + kAtlas; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kFC2;
+    bg.p[0] = GemmProblem{w->actT, ldT, w->dR2, kFC2ld, nullptr, G + H.fc2W, kFC2};
+    gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(colsum_kernel, dim3((kFC2 + 63) / 64), dim3(256), 0, st, w->dR2, kFC2ld, n, kFC2, G + H.fc2b);
-    s.M = n; s.N = kFC1; s.K = kFC2;
-    s.p[0] = SgemmProblem{w->dR2, kFC2ld, 1, P + H.fc2W, 1, kFC2, w->dcat, kFC1};
-    sgemm(s, 1, st);
+    bg.M = n; bg.K4 = kFC2ld; bg.K = kFC2; bg.N = kFC1;
+    bg.p[0] = GemmProblem{w->dR2, kFC2ld, wT2, kFC1, nullptr, w->dcat, kFC1};
+    gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC1), dim3(256), 0, st, w->dcat, kFC1, w->R1, kFC1, mask2, n, kFC1);
     // FC1
-    s.M = kFlat; s.N = kFC1; s.K = n;
-    s.p[0] = SgemmProblem{w->featd, 1, kFlat, w->dcat, kFC1, 1, G + H.fc1W, kFC1};
-    sgemm(s, 1, st);
+    {
+        TrArgs tr{}; tr.rows = n; tr.cols = kFlat; tr.p[0] = TrProblem{w->featd, kFlat, w->actT, ldT};
+        transpose(tr, 1, st);
+    }
+    bg.M = kFlat; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kFC1;
+    bg.p[0] = GemmProblem{w->actT, ldT, w->dcat, kFC1, nullptr, G + H.fc1W, kFC1};
+    gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64), dim3(256), 0, st, w->dcat, kFC1, n, kFC1, G + H.fc1b);
-    s.M = n; s.N = kFlat; s.K = kFC1;
-    s.p[0] = SgemmProblem{w->dcat, kFC1, 1, P + H.fc1W, 1, kFC1, w->dfeat, kFlat};
-    sgemm(s, 1, st);
+    bg.M = n; bg.K4 = kFC1; bg.K = kFC1; bg.N = kFlat;
+    bg.p[0] = GemmProblem{w->dcat, kFC1, wT1, kFlat, nullptr, w->dfeat, kFlat};
+    gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFlat), dim3(256), 0, st, w->dfeat, kFlat, w->feat, kFlat, mask1, n, kFlat);
     // d1 x3
-    s.M = kFlat; s.N = kD1; s.K = n;
+    {
+        TrArgs tr{}; tr.rows = n; tr.cols = kFlat;
+        for (int t = 0; t < kTowers; ++t) tr.p[t] = TrProblem{w->H5[t], kFlat, w->actT + (size_t)t * kFC1ld * ldT, ldT};
+        transpose(tr, kTowers, st);
+    }
+    bg.M = kFlat; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kD1;
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
-        s.p[t] = SgemmProblem{w->H5[t], 1, kFlat, w->dfeat + t * kD1, kFlat, 1, G + T.d1W, kD1};
+        bg.p[t] = GemmProblem{w->actT + (size_t)t * kFC1ld * ldT, ldT, w->dfeat + t * kD1, kFlat, nullptr, G + T.d1W, kD1};
     }
-    sgemm(s, kTowers, st);
+    gemm_launch(bg, kTowers, st);
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
         hipLaunchKernelGGL(colsum_kernel, dim3((kD1 + 63) / 64), dim3(256), 0, st, w->dfeat + t * kD1, kFlat, n, kD1, G + T.d1b);
     }
-    s.M = n; s.N = kFlat; s.K = kD1;
-    for (int t = 0; t < kTowers; ++t) {
-        const TowerOff T = tower_off(t * kTowerFloats);
-        s.p[t] = SgemmProblem{w->dfeat + t * kD1, kFlat, 1, P + T.d1W, 1, kD1, w->dX[t][0], kFlat};
-    }
-    sgemm(s, kTowers, st);
+    bg.M = n; bg.K4 = kD1; bg.K = kD1; bg.N = kFlat;
+    for (int t = 0; t < kTowers; ++t) bg.p[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kFlat, kFlat, nullptr, w->dX[t][0], kFlat};
+    gemm_launch(bg, kTowers, st);
     {
         Ptr3 gp{{w->dX[0][0], w->dX[1][0], w->dX[2][0]}};
         hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid((long)n * kFlat).x, kTowers), dim3(256), 0, st, gp, mask5, n);
@@ -767,17 +828,18 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         CPtr3 Xi;
         for (int t = 0; t < kTowers; ++t) Xi.p[t] = (i == 0) ? xin[t] : w->X[t][i];
         CPtr3 dZc{{w->dZ[0], w->dZ[1], w->dZ[2]}};
-        if (i >= 1 && i <= 3) {
+        {
             WgArgs wa{};
             for (int t = 0; t < kTowers; ++t) { wa.X[t] = Xi.p[t]; wa.dZ[t] = w->dZ[t]; }
             wa.part = w->wg_part; wa.n = n; wa.slices = n < kWgSlicesMax ? n : kWgSlicesMax;
-            if (i == 1) wgrad_launch<WG2>(wa, st);
+            if (i == 0) wgrad_launch<WG1>(wa, st);
+            else if (i == 1) wgrad_launch<WG2>(wa, st);
             else if (i == 2) wgrad_launch<WG3>(wa, st);
-            else wgrad_launch<WG4>(wa, st);
-            hipLaunchKernelGGL(wgrad_final_kernel, dim3(32, kTowers), dim3(256), 0, st, w->wg_part, wa.slices, kCin[i], C, G, T0.convW[i], kTowerFloats);
-        } else {
-            hipLaunchKernelGGL(wgrad_partial_kernel, dim3(kCin[i], C / 4, kTowers * kWgSplit), dim3(256), 0, st, Xi, dZc, n, kCin[i], C, kHin[i], w->wg_part);
-            hipLaunchKernelGGL(wgrad_final_kernel, dim3(32, kTowers), dim3(256), 0, st, w->wg_part, kWgSplit, kCin[i], C, G, T0.convW[i], kTowerFloats);
+            else if (i == 3) wgrad_launch<WG4>(wa, st);
+            else wgrad_launch<WG5>(wa, st);
+            const int tot = kCin[i] * C * 9;
+            hipLaunchKernelGGL(wgrad_final_kernel, dim3((tot + 255) / 256, kTowers), dim3(256), 0, st, w->wg_part, wa.slices, kCin[i], C, G,
+                               T0.convW[i], kTowerFloats);
         }
         if (i > 0) {
             ConvArgs a{};

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
                 for (int u = 0; u < C::NT4; ++u) b4[u] = szr[zoff4 + u * 4 * C::ZPL + 4 * xg];
 #pragma unroll
                 for (int m = 0; m < C::MTW; ++m) {
+                    if ((3 + 4 * m) >= C::MT && (wave + 4 * m) >= C::MT) continue;      // wave-uniform: no such row tile
                     const float av = sxr[xbase[m] + 4 * xg];
 #pragma unroll
                     for (int nt = 0; nt < C::NT16; ++nt)

@@ -92,7 +92,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--mode', choices=['forward', 'train'], default='forward')
+    ap.add_argument('--mode', choices=['forward', 'train', 'volume'], default='forward')
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu', action='store_true')
@@ -124,6 +124,26 @@ def main():
             h.forward(ax, co, sa, at, B, probs, labels, st)
         flop_per_patch = FWD_FLOP
         workload = 'forward-only inference, synthetic 32x32x3-view float32 patches, batch %d per GPU (BASELINE configs[1])' % B
+    elif args.mode == 'volume':
+        # BASELINE configs[4]: one subject per GPU, gather-fused inference over a ~400 000-voxel ROI of a 256x256x192
+        # volume (synthetic, z-scored noise), labels + probabilities from one pass
+        dims = (256, 256, 192)
+        g = torch.Generator(device=dev)
+        g.manual_seed(7 + rank)
+        vol = torch.randn(dims, generator=g, device=dev, dtype=torch.float32)
+        e = torch.rand(dims + (15,), generator=g, device=dev, dtype=torch.float32)
+        atlas4d = (e / e.sum(-1, keepdim=True)).contiguous()
+        zz, yy, xx = torch.meshgrid(*[torch.arange(s, device=dev) for s in dims], indexing='ij')
+        roi = (((zz - 128) / 60.0) ** 2 + ((yy - 128) / 52.0) ** 2 + ((xx - 96) / 31.0) ** 2) <= 1.0
+        centers = torch.nonzero(roi).to(torch.int32).contiguous()          # C order, like np.nonzero (base.py:310-331)
+        B = int(centers.shape[0])
+        probs = torch.empty((B, 15), device=dev)
+        labels = torch.empty((B,), dtype=torch.int32, device=dev)
+
+        def step():
+            h.forward_volume(vol, dims, centers, atlas4d, B, probs, labels, st)
+        flop_per_patch = FWD_FLOP
+        workload = 'gather-fused whole-subject inference (scs_forward_volume), 256x256x192 volume, %d ROI voxels per GPU (BASELINE configs[4])' % B
     else:
         B = args.batch or 256
         ax, co, sa, at = synth_on_device(torch, B, 1000 * rank, dev)
@@ -153,12 +173,12 @@ def main():
     value = world * B * args.steps / dt
 
     out = {
-        'metric': 'tri-view 32x32 patches/s (%s)' % ('forward' if args.mode == 'forward' else 'train step'),
+        'metric': 'tri-view 32x32 patches/s (%s)' % {'forward': 'forward', 'train': 'train step', 'volume': 'forward, gather-fused'}[args.mode],
         'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': workload, 'weights': 'miccai2012_v1 (shipped)', 'per_gpu_batch': B, 'chunk': chunk,
-                   'parallelism': 'independent patch shards, no data-path collective' if args.mode == 'forward'
+                   'parallelism': 'independent patch shards, no data-path collective' if args.mode != 'train'
                    else 'dp%d, one RCCL all-reduce of the 3.5 MB gradient arena per step' % world},
         'net_tflops': value * flop_per_patch / 1e12,
         'net_frac_of_f32_peak': value * flop_per_patch / 1e12 / (PEAK_F32_TFLOPS * world),

@@ -60,7 +60,8 @@ struct ConvCfg {
     static constexpr int XS_ROWS_FLOATS = (XROWS * 32 + 3) / 4 * 4;
     static constexpr int XS_FLOATS = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME) ? XS_ROWS_FLOATS + 4 + kW1Floats : 0;
     // the epilogue restages the outputs in LDS ([g][cout][OSTR], odd stride) and stores them as whole rows
-    static constexpr int OSTR = OUTB | 1;
+    static constexpr bool OUT_VEC4 = (OUTB % 4 == 0) && (OUTPIX % 4 == 0);
+    static constexpr int OSTR = OUT_VEC4 ? OUTB + 4 : (OUTB | 1);
     static constexpr int OUT_FLOATS = G_ * COUT_ * OSTR;
     static constexpr int MAIN_FLOATS = IN_FLOATS_AL + 2 * WCHUNK + XS_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)(MAIN_FLOATS > OUT_FLOATS ? MAIN_FLOATS : OUT_FLOATS) * 4;
@@ -82,6 +83,7 @@ struct ConvArgs {
     int dimx, dimy, dimz;
     int n;                        // patches
     unsigned long long* stamps;   // diagnostic builds only (STAMP): [workgroup][8] s_memtime values
+    int stagger;                  // start delay unit (in 64-cycle sleeps) for the first workgroups of a launch, see kernel
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -102,6 +104,22 @@ __device__ __forceinline__ float sum_xor32(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float sum_ksub(float v) { return sum_xor32(sum_xor16(v)); }
+
+// The 4x4x1 accumulators hold, per lane group kq = lane >> 4, the partial sums of k-subgroup kq for 4 output channels
+// (vgpr i).  Lane group kq stores channel i = kq, so what is needed is a 4x4 transpose-and-add across the lane groups:
+// two exchange rounds (lane ^ 16 through the LDS crossbar's swizzle, lane ^ 32 through ds_bpermute - neither occupies
+// the vector ALU, which the f32 MFMAs of the other waves need) and three adds.
+__device__ __forceinline__ float ksub_reduce(const f32x4 v, int kq, int xor32_addr) {
+    const bool odd = kq & 1, hi = kq & 2;
+    const float keepA = odd ? v[1] : v[0], sendA = odd ? v[0] : v[1];
+    const float keepB = odd ? v[3] : v[2], sendB = odd ? v[2] : v[3];
+    const float recvA = __uint_as_float(__builtin_amdgcn_ds_swizzle(__float_as_uint(sendA), 0x401F));   // lane ^ 16
+    const float recvB = __uint_as_float(__builtin_amdgcn_ds_swizzle(__float_as_uint(sendB), 0x401F));
+    const float sA = keepA + recvA, sB = keepB + recvB;
+    const float keep = hi ? sB : sA, send = hi ? sA : sB;
+    const float recv = __uint_as_float(__builtin_amdgcn_ds_bpermute(xor32_addr, __float_as_uint(send)));  // lane ^ 32
+    return keep + recv;
+}
 __device__ __forceinline__ float max_quad(float v) {     // max over the 4 lanes of a quad (lane ^ 1, lane ^ 2)
     v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true)));
     v = fmaxf(v, __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xF, 0xF, true)));
@@ -199,6 +217,17 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         stp = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
         if (tid == 0) stp[0] = __builtin_amdgcn_s_memtime();
     }
+    // De-phase the workgroups that share a CU.  All resident workgroups start together and take the same time, so
+    // without this they stay in lock-step: every one stages, then every one wants the matrix pipe, then every one
+    // stores - the phases never overlap.  The first `slots` waves of workgroups (one per CU each, in dispatch order)
+    // are delayed by slot * stagger; later workgroups inherit the offset of the slot they replace.
+    if (a.stagger > 0) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned slot = lin / 256u;
+        if (slot > 0 && slot < 8u) {
+            for (int i = 0; i < (int)slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+    }
 #ifdef SCS_PRIO
     __builtin_amdgcn_s_setprio(SCS_PRIO);      // staging / epilogue phases are short and latency-bound: let them win issue
 #endif
@@ -290,7 +319,9 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         for (int e = tid; e < kW1Floats; e += 256) s_w1[e] = pick3(a.w1, tower)[e];
         __syncthreads();
         if constexpr (C::STAMP) { if (tid == 0) stp[5] = __builtin_amdgcn_s_memtime(); }
+#if !(defined(SCS_ABLATE) && SCS_ABLATE == 3)
         conv1_to_lds<C::PLANE, C::HINB>(s_x, s_w1, s_in, wave, lane);
+#endif
     }
 
     if constexpr (C::STAMP) { if (tid == 0) stp[1] = __builtin_amdgcn_s_memtime(); }
@@ -364,7 +395,17 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < C::TPW; ++j) {
                 if (C::LAST_RAGGED && j == C::TPW - 1 && !last_ok) continue;   // wave-uniform: this wave has no such tile
+#if defined(SCS_ABLATE) && SCS_ABLATE == 2
+                const float av = __builtin_bit_cast(float, abase[j] + toff);       // ablation: no activation reads
+#else
                 const float av = sa[abase[j] + toff];
+#endif
+#if defined(SCS_ABLATE) && SCS_ABLATE == 1
+#pragma unroll
+                for (int nt = 0; nt < C::NT16; ++nt) acc[j][nt][0] += av * b[nt];  // ablation: no MFMA
+#pragma unroll
+                for (int u = 0; u < C::NT4; ++u) acc4[j][u][0] += av * b4[u];
+#else
 #pragma unroll
                 for (int nt = 0; nt < C::NT16; ++nt)
                     acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[j][nt], 0, 0, 0);
@@ -373,6 +414,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int u = 0; u < C::NT4; ++u)
                     acc4[j][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[j][u], 0, 0, 0);
+#endif
             }
         }
         if (c4 + 1 < C::NC4) {
@@ -425,15 +467,17 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         }
     }
     // leftover channels: lane l holds, for pixel (l & 15), the partial sums of k-subgroup kq for 4 couts (vgpr i)
+    const int xor32_addr = (lane ^ 32) << 2;
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
         const int t = wave + 4 * j;
         if (t >= C::TILES) continue;
+#if defined(SCS_ABLATE) && SCS_ABLATE == 4
+        if (t >= 0) { s_o[lane] = acc4[j][0][0] + acc4[j][0][1] + acc4[j][0][2] + acc4[j][0][3]; continue; }
+#endif
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
-            const float v0 = sum_ksub(acc4[j][u][0]), v1 = sum_ksub(acc4[j][u][1]), v2 = sum_ksub(acc4[j][u][2]),
-                        v3 = sum_ksub(acc4[j][u][3]);
-            float val = kq == 0 ? v0 : (kq == 1 ? v1 : (kq == 2 ? v2 : v3));            // this lane stores cout 4u + kq
+            float val = ksub_reduce(acc4[j][u], kq, xor32_addr);                         // this lane stores cout 4u + kq
             const int co = C::NT16 * 16 + u * 4 + kq;
             const float bv = bv4[u];
             if constexpr (C::POOL) {
@@ -460,14 +504,34 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     if constexpr (C::STAMP) { if (tid == 0) stp[7] = __builtin_amdgcn_s_memtime(); }
     {
         float* __restrict__ outp = pick3(a.out, tower) + (size_t)g0 * C::COUT * C::OUTPIX + band * C::OUTB;
-        const int total = ng * C::COUT * C::OUTB;
-        constexpr int ITER = (C::G * C::COUT * C::OUTB + 255) / 256;
+        if constexpr (C::OUT_VEC4) {
+            constexpr int O4 = C::OUTB / 4, ITER = (C::G * C::COUT * O4 + 255) / 256;
+            const int total = ng * C::COUT * O4;
+#if defined(SCS_ABLATE) && SCS_ABLATE == 5
+            if (tid < 0)
+#endif
+#pragma unroll 4
+            for (int it = 0; it < ITER; ++it) {
+                const int e = tid + 256 * it;
+                if (e < total) {
+                    const int gc = e / O4, r = e - gc * O4;
+                    *reinterpret_cast<float4*>(outp + (size_t)gc * C::OUTPIX + 4 * r) =
+                        *reinterpret_cast<const float4*>(s_o + gc * C::OSTR + 4 * r);
+                }
+            }
+        } else {
+            const int total = ng * C::COUT * C::OUTB;
+            constexpr int ITER = (C::G * C::COUT * C::OUTB + 255) / 256;
+#if defined(SCS_ABLATE) && SCS_ABLATE == 5
+            if (tid < 0)
+#endif
 #pragma unroll 2
-        for (int it = 0; it < ITER; ++it) {
-            const int e = tid + 256 * it;
-            if (e < total) {
-                const int gc = e / C::OUTB, r = e - gc * C::OUTB;
-                outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
+            for (int it = 0; it < ITER; ++it) {
+                const int e = tid + 256 * it;
+                if (e < total) {
+                    const int gc = e / C::OUTB, r = e - gc * C::OUTB;
+                    outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
+                }
             }
         }
     }

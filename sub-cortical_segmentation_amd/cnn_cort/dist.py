@@ -49,10 +49,14 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
+            backend = os.environ.get('SCS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            # one GPU per rank; LOCAL_RANK wraps around only in single-GPU rehearsals (gloo backend)
+            local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
         td.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=world)
+    if torch.cuda.is_available():
+        local = local % max(1, torch.cuda.device_count())
     return rank(), world_size(), local
 
 

@@ -127,3 +127,25 @@ def test_fit_learns_and_keeps_the_history_schema(tmp_path):
     p = net2.predict_proba(X)
     assert p.shape == (64, 15) and np.abs(p.sum(1) - 1).max() < 1e-5
     assert np.array_equal(net2.predict(X), p.argmax(1))
+
+
+def test_two_rank_gradient_exchange(tmp_path):
+    """Two ranks (gloo rehearsal, both on cuda:0): each back-propagates its half of the g5 batch, the gradient arenas
+    are summed through cnn_cort.dist and Adam applies the 1/world scale: replicas end identical and the exchanged
+    gradient equals the sum of the two local ones."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, SCS_DIST_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    r0, r1 = np.load(str(tmp_path / 'rank0.npz')), np.load(str(tmp_path / 'rank1.npz'))
+    assert float(r0['scale']) == 0.5 and float(r1['scale']) == 0.5
+    assert np.array_equal(r0['summed'], r1['summed'])
+    assert np.allclose(r0['summed'], r0['local'] + r1['local'], rtol=0, atol=1e-6 * np.abs(r0['summed']).max())
+    assert not np.array_equal(r0['local'], r1['local'])
+    assert np.array_equal(r0['params'], r1['params'])             # replicas stay identical after Adam + BN reconcile

@@ -171,8 +171,7 @@ __device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, cons
             for (int r = 0; r < 4; ++r) if (p0 + r < NPIX) dst[r] = fmaxf(am[r] + bias_m, 0.f);
         }
         // leftover: cout 16 + i in vgpr i, pixel = lr, partial over kq -> combine, lane group kq stores cout 16 + kq
-        const float v0 = sum_ksub(al[0]), v1 = sum_ksub(al[1]), v2 = sum_ksub(al[2]), v3 = sum_ksub(al[3]);
-        const float val = kq == 0 ? v0 : (kq == 1 ? v1 : (kq == 2 ? v2 : v3));
+        const float val = ksub_reduce(al, kq, (lane ^ 32) << 2);
         if (tile_ok && (NPIX % 16 == 0 || tc * 16 + lr < NPIX)) s_out[(16 + kq) * PLANE + tc * 16 + lr] = fmaxf(val + bias_l, 0.f);
     }
 }

@@ -138,9 +138,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
-            const float v0 = sum_ksub(acc4[m][u][0]), v1 = sum_ksub(acc4[m][u][1]), v2 = sum_ksub(acc4[m][u][2]),
-                        v3 = sum_ksub(acc4[m][u][3]);
-            const float val = kq == 0 ? v0 : (kq == 1 ? v1 : (kq == 2 ? v2 : v3));
+            const float val = ksub_reduce(acc4[m][u], kq, (lane ^ 32) << 2);
             const int o = C::NT16 * 16 + u * 4 + kq, j = t * 16 + lr;
             if (j < C::J) out[o * C::J + j] = val;
         }

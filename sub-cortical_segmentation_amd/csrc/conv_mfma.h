@@ -289,11 +289,10 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         for (int e = tid; e < C::G * C::CIN * C::PLANE; e += 256) s_in[e] = 0.f;
         __syncthreads();
         const int total = ng * C::CIN * HW;
-        for (int e = tid; e < total; e += 256) {
-            const int pl = e / HW, r = e - pl * HW;
-            const int y = r / HS, x = r - y * HS;
-            s_in[pl * C::PLANE + (y + 2) * C::WIN + x + 2] = src[e];
-        }
+        staged_copy<C::G * C::CIN * HW, float>(
+            tid, [&](int e) { return (e < total) ? src[e] : 0.f; },
+            [&](int e, float v) { const int pl = e / HW, r = e - pl * HW, y = r / HS, x = r - y * HS;
+                                  if (e < total) s_in[pl * C::PLANE + (y + 2) * C::WIN + x + 2] = v; });
     } else {
         static_assert(C::SRC == SRC_NCHW || C::SRC == SRC_NCHW_PAD2 || C::G == 1, "fused conv1 variants take one patch per workgroup");
         if constexpr (C::SRC == SRC_CONV1) {

@@ -24,56 +24,64 @@ struct GemmArgs {
     int relu;
 };
 
-constexpr int kGemmBM = 128, kGemmBN = 96, kGemmBK = 32, kGemmAS = 34, kGemmBS = 112;
-constexpr size_t kGemmLds = (size_t)(2 * kGemmBM * kGemmAS + 2 * kGemmBK * kGemmBS) * 4;
+constexpr int kGemmBK = 32, kGemmAS = 34;
 
-template <int VARIANT = 0>
+// MT = 16-row tiles per wave, NT = 16-column tiles per workgroup: workgroup tile (64*MT) x (16*NT)
+template <int MT, int NT>
+struct GemmTile {
+    static constexpr int BM = 64 * MT, BN = 16 * NT, BS = (BN % 32 == 16) ? BN : BN + 16;
+    static constexpr int A_PER = BM * kGemmBK / 256, B_PER = (kGemmBK * BN + 255) / 256;
+    static constexpr size_t LDS = (size_t)(2 * BM * kGemmAS + 2 * kGemmBK * BS) * 4;
+};
+
+template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
+    using T = GemmTile<MT, NT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_a = smem;                                  // [2][128][34]
-    float* s_b = smem + 2 * kGemmBM * kGemmAS;          // [2][32][112]
+    float* s_a = smem;                                  // [2][BM][34]
+    float* s_b = smem + 2 * T::BM * kGemmAS;            // [2][32][BS]
     const int z = blockIdx.z;
     const GemmProblem P = z == 0 ? g.p[0] : (z == 1 ? g.p[1] : g.p[2]);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
-    const int m0 = blockIdx.x * kGemmBM, n0 = blockIdx.y * kGemmBN;
+    const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
 
     const int kmax = g.K ? g.K : g.K4;
-    float ra[16], rb[12];
+    float ra[T::A_PER], rb[T::B_PER];
     const int a_col = tid & 31, a_row = tid >> 5;       // A slab: rows a_row + 8*i, column a_col
     auto load_slab = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < T::A_PER; ++i) {
             const int row = m0 + a_row + 8 * i, k = k0 + a_col;
             ra[i] = (row < g.M && k < g.K4) ? P.A[(size_t)row * P.lda + k] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < T::B_PER; ++i) {
             const int e = tid + 256 * i;
-            const int kr = e / kGemmBN, c = e - kr * kGemmBN;
+            const int kr = e / T::BN, c = e - kr * T::BN;
             const int k = k0 + kr, n = n0 + c;
-            rb[i] = (k < kmax && n < P.NS) ? P.W[(size_t)k * P.NS + n] : 0.f;
+            rb[i] = (kr < kGemmBK && k < kmax && n < P.NS) ? P.W[(size_t)k * P.NS + n] : 0.f;
         }
     };
     auto store_slab = [&](int buf) {
-        float* da = s_a + buf * kGemmBM * kGemmAS;
-        float* db = s_b + buf * kGemmBK * kGemmBS;
+        float* da = s_a + buf * T::BM * kGemmAS;
+        float* db = s_b + buf * kGemmBK * T::BS;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) da[(a_row + 8 * i) * kGemmAS + a_col] = ra[i];
+        for (int i = 0; i < T::A_PER; ++i) da[(a_row + 8 * i) * kGemmAS + a_col] = ra[i];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
+        for (int i = 0; i < T::B_PER; ++i) {
             const int e = tid + 256 * i;
-            const int kr = e / kGemmBN, c = e - kr * kGemmBN;
-            db[kr * kGemmBS + c] = rb[i];
+            const int kr = e / T::BN, c = e - kr * T::BN;
+            if (kr < kGemmBK) db[kr * T::BS + c] = rb[i];
         }
     };
 
-    f32x4 acc[2][6];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nslab = (g.K4 + kGemmBK - 1) / kGemmBK;
     load_slab(0);
@@ -81,19 +89,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
         if (s + 1 < nslab) load_slab((s + 1) * kGemmBK);
-        const float* sa = s_a + (s & 1) * kGemmBM * kGemmAS + (wave * 32 + lr) * kGemmAS + kq;
-        const float* sb = s_b + (s & 1) * kGemmBK * kGemmBS + kq * kGemmBS + lr;
+        const float* sa = s_a + (s & 1) * T::BM * kGemmAS + (wave * 16 * MT + lr) * kGemmAS + kq;
+        const float* sb = s_b + (s & 1) * kGemmBK * T::BS + kq * T::BS + lr;
 #pragma unroll
         for (int ks = 0; ks < kGemmBK / 4; ++ks) {
-            float a[2], b[6];
+            float a[MT], b[NT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sa[i * 16 * kGemmAS + ks * 4];
+            for (int i = 0; i < MT; ++i) a[i] = sa[i * 16 * kGemmAS + ks * 4];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) b[j] = sb[ks * 4 * kGemmBS + j * 16];
+            for (int j = 0; j < NT; ++j) b[j] = sb[ks * 4 * T::BS + j * 16];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
+                for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (s + 1 < nslab) store_slab((s + 1) & 1);
@@ -101,15 +109,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
     }
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int col = n0 + j * 16 + lr;
             if (col >= g.N) continue;
             const float bv = P.bias ? P.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wave * 32 + i * 16 + kq * 4 + r;
+                const int row = m0 + wave * 16 * MT + i * 16 + kq * 4 + r;
                 if (row < g.M) {
                     float v = acc[i][j][r] + bv;
                     if (g.relu) v = fmaxf(v, 0.f);
@@ -119,10 +127,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
         }
 }
 
+// big tile (128 x 96) when it fills the chip, small tile (64 x 48) for the short-M / short-N training GEMMs
 inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
     if (g.M <= 0) return;
-    dim3 grid((g.M + kGemmBM - 1) / kGemmBM, (g.N + kGemmBN - 1) / kGemmBN, nproblems);
-    hipLaunchKernelGGL(gemm_mfma_kernel<0>, grid, dim3(256), kGemmLds, st, g);
+    using Big = GemmTile<2, 6>;
+    using Small = GemmTile<1, 3>;
+    const long big_wgs = (long)((g.M + Big::BM - 1) / Big::BM) * ((g.N + Big::BN - 1) / Big::BN) * nproblems;
+    if (big_wgs >= 192) {
+        dim3 grid((g.M + Big::BM - 1) / Big::BM, (g.N + Big::BN - 1) / Big::BN, nproblems);
+        hipLaunchKernelGGL((gemm_mfma_kernel<2, 6>), grid, dim3(256), Big::LDS, st, g);
+    } else {
+        dim3 grid((g.M + Small::BM - 1) / Small::BM, (g.N + Small::BN - 1) / Small::BN, nproblems);
+        hipLaunchKernelGGL((gemm_mfma_kernel<1, 3>), grid, dim3(256), Small::LDS, st, g);
+    }
 }
 
 }  // namespace scs

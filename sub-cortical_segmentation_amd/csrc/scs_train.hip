@@ -240,11 +240,11 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(CPtr3 Z, int n, i
     const float* __restrict__ z = sel3(Z.p, t);
     const int per = (n + kRedSplit - 1) / kRedSplit, n0 = sp * per, n1 = min(n, n0 + per);
     double s = 0, q = 0;
-    const long total = (long)max(0, n1 - n0) * pix;
-    for (long e = threadIdx.x; e < total; e += blockDim.x) {
-        const long ni = n0 + e / pix, p = e % pix;
-        const double v = z[(ni * C + c) * pix + p];
-        s += v; q += v * v;
+    for (int ni = n0; ni < n1; ++ni) {
+        const float* __restrict__ zp = z + ((size_t)ni * C + c) * pix;
+        float fs = 0.f, fq = 0.f;                                  // per-patch partials in float, accumulated in double
+        for (int p = threadIdx.x; p < pix; p += 256) { const float v = zp[p]; fs += v; fq = fmaf(v, v, fq); }
+        s += fs; q += fq;
     }
     s = block_sum(s, s_red);
     q = block_sum(q, s_red);
@@ -510,12 +510,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(CPtr3 Z, CPtr3 dOut
     const int pix = H * H;
     const int per = (n + kRedSplit - 1) / kRedSplit, n0 = sp * per, n1 = min(n, n0 + per);
     double sb = 0, sg = 0;
-    const long total = (long)max(0, n1 - n0) * pix;
-    for (long e = threadIdx.x; e < total; e += blockDim.x) {
-        const long ni = n0 + e / pix; const int p = (int)(e % pix);
-        float xh;
-        const float dy = bn_dy<POOL>(z, d, ni * C + c, H, p / H, p % H, sc, sh, &xh, mean, inv);
-        sb += dy; sg += (double)dy * xh;
+    for (int ni = n0; ni < n1; ++ni) {
+        float fb = 0.f, fg = 0.f;
+        for (int p = threadIdx.x; p < pix; p += 256) {
+            float xh;
+            const float dy = bn_dy<POOL>(z, d, (long)ni * C + c, H, p / H, p % H, sc, sh, &xh, mean, inv);
+            fb += dy; fg = fmaf(dy, xh, fg);
+        }
+        sb += fb; sg += fg;
     }
     sb = block_sum(sb, s_red);
     sg = block_sum(sg, s_red);

@@ -840,7 +840,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
             else if (i == 3) wgrad_launch<WG4>(wa, st);
             else wgrad_launch<WG5>(wa, st);
             const int tot = kCin[i] * C * 9;
-            hipLaunchKernelGGL(wgrad_final_kernel, dim3((tot + 255) / 256, kTowers), dim3(256), 0, st, w->wg_part, wa.slices, kCin[i], C, G,
+            hipLaunchKernelGGL(wgrad_final_kernel, dim3((tot + 255) / 256, kTowers), dim3(256), 0, st, w->wg_part, wa.slices * (i == 0 ? WG1::PARTS : 1), kCin[i], C, G,
                                T0.convW[i], kTowerFloats);
         }
         if (i > 0) {

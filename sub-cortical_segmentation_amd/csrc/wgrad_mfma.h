@@ -24,6 +24,10 @@ struct WgCfg {
     static constexpr int MT = (J + 15) / 16;
     static constexpr int MTW = (MT + 3) / 4;                 // row tiles per wave
     static constexpr int NT16 = nt16(COUT_), NT4 = nt4(COUT_);
+    // a single row tile (conv1: 9 rows) would leave three waves idle: the waves then split the image rows instead and
+    // each writes its own partial (the final reduction sums slices x 4 partials)
+    static constexpr bool ROWSPLIT = (MT == 1);
+    static constexpr int PARTS = ROWSPLIT ? 4 : 1;
     static constexpr int X_FLOATS = CIN_ * XPL, Z_FLOATS = COUT_ * ZPL;
     static constexpr size_t LDS_BYTES = (size_t)(X_FLOATS + Z_FLOATS) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
     int xbase[C::MTW];
 #pragma unroll
     for (int m = 0; m < C::MTW; ++m) {
-        const int j = min((wave + 4 * m) * 16 + lr, C::J - 1);
+        const int j = min(((C::ROWSPLIT ? 0 : wave) + 4 * m) * 16 + lr, C::J - 1);
         const int c = j / 9, tap = j - c * 9;
         xbase[m] = c * C::XPL + (tap / 3) * C::HIN + tap % 3 + kq;
     }
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
                                       s_z[pl * C::ZPL + y * C::WOP + x] = v; });
         }
         __syncthreads();
-        for (int y = 0; y < C::HO; ++y) {
+        for (int y = C::ROWSPLIT ? wave : 0; y < C::HO; y += C::PARTS) {
             const float* __restrict__ sxr = s_x + y * C::HIN;
             const float* __restrict__ szr = s_z + y * C::WOP;
 #pragma unroll
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
                 for (int u = 0; u < C::NT4; ++u) b4[u] = szr[zoff4 + u * 4 * C::ZPL + 4 * xg];
 #pragma unroll
                 for (int m = 0; m < C::MTW; ++m) {
-                    if ((3 + 4 * m) >= C::MT && (wave + 4 * m) >= C::MT) continue;      // wave-uniform: no such row tile
+                if (!C::ROWSPLIT && (3 + 4 * m) >= C::MT && (wave + 4 * m) >= C::MT) continue;   // wave-uniform: no such row tile
                     const float av = sxr[xbase[m] + 4 * xg];
 #pragma unroll
                     for (int nt = 0; nt < C::NT16; ++nt)
@@ -122,10 +126,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
     }
 
     // ---- partial dW of this slice: part[tower][slice][o][j = c*9 + tap]
-    float* __restrict__ out = a.part + ((size_t)tower * a.slices + slice) * C::COUT * C::J;
+    float* __restrict__ out = a.part + ((size_t)tower * a.slices * C::PARTS + slice * C::PARTS + (C::ROWSPLIT ? wave : 0)) * C::COUT * C::J;
 #pragma unroll
     for (int m = 0; m < C::MTW; ++m) {
-        const int t = wave + 4 * m;
+        const int t = (C::ROWSPLIT ? 0 : wave) + 4 * m;
         if (t >= C::MT) continue;
 #pragma unroll
         for (int nt = 0; nt < C::NT16; ++nt) {

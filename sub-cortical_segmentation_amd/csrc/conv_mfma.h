@@ -83,7 +83,6 @@ struct ConvArgs {
     int dimx, dimy, dimz;
     int n;                        // patches
     unsigned long long* stamps;   // diagnostic builds only (STAMP): [workgroup][8] s_memtime values
-    int stagger;                  // start delay unit (in 64-cycle sleeps) for the first workgroups of a launch, see kernel
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -216,20 +215,6 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         stp = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
         if (tid == 0) stp[0] = __builtin_amdgcn_s_memtime();
     }
-    // De-phase the workgroups that share a CU.  All resident workgroups start together and take the same time, so
-    // without this they stay in lock-step: every one stages, then every one wants the matrix pipe, then every one
-    // stores - the phases never overlap.  The first `slots` waves of workgroups (one per CU each, in dispatch order)
-    // are delayed by slot * stagger; later workgroups inherit the offset of the slot they replace.
-    if (a.stagger > 0) {
-        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const unsigned slot = lin / 256u;
-        if (slot > 0 && slot < 8u) {
-            for (int i = 0; i < (int)slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-        }
-    }
-#ifdef SCS_PRIO
-    __builtin_amdgcn_s_setprio(SCS_PRIO);      // staging / epilogue phases are short and latency-bound: let them win issue
-#endif
     const float* __restrict__ wsrc = pick3(a.w, tower);
     const float* __restrict__ insrc = pick3(a.in, tower);
 
@@ -367,9 +352,6 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     __syncthreads();
     if constexpr (C::STAMP) { if (tid == 0) stp[2] = __builtin_amdgcn_s_memtime(); }
 
-#ifdef SCS_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     const int boff = kq * C::NS16 + lr;                       // main part: W[k = 4s + kq][cout = 16 nt + lr]
     const int loff = 36 * C::NS16 + kq * C::L4 + (lane & 3);   // leftover: W[k = 4s + kq][cout = 16 NT16 + 4u + (lane&3)]
     const bool last_ok = (wave + 4 * (C::TPW - 1)) < C::TILES;
@@ -425,9 +407,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     }
 
     if constexpr (C::STAMP) { if (tid == 0) stp[3] = __builtin_amdgcn_s_memtime(); }
-#ifdef SCS_PRIO
-    __builtin_amdgcn_s_setprio(SCS_PRIO);
-#endif
+
     // ---- epilogue: D row = 4*kq + r (pixel / window position), column = lr (cout).  Results are restaged in
     // LDS as [g][cout][OSTR] (every wave has passed the loop's last barrier, so the operand buffers are free) and
     // leave as whole rows: 64 lanes -> 256 contiguous bytes, instead of 64 scattered dwords per store.

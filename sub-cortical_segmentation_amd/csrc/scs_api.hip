@@ -226,11 +226,16 @@ int repack_inference(scs_ctx* h, hipStream_t st) {
 }
 
 // ----------------------------------------------------------------------------- workspace
-int ensure_workspace(scs_ctx* h) {
-    if (h->ws && h->ws_chunk == h->chunk) return SCS_OK;
+// workspace for chunks of up to `need` patches (grown on demand, never beyond the chunk bound: a 64-patch predict
+// must not reserve the 4.6 GB a 32768-patch chunk needs)
+int ensure_workspace(scs_ctx* h, int need) {
+    if (need > h->chunk) need = h->chunk;
+    need = (need + 15) / 16 * 16;
+    if (h->ws && h->ws_chunk >= need) return SCS_OK;
+    SCS_HIP(hipDeviceSynchronize());                       // a previous call may still be using the old buffers
     if (h->ws) { SCS_HIP(hipFree(h->ws)); h->ws = nullptr; }
-    if (h->stage_dev) { SCS_HIP(hipFree(h->stage_dev)); h->stage_dev = nullptr; }
-    const size_t c = (size_t)h->chunk;
+    if (h->stage_dev) { SCS_HIP(hipFree(h->stage_dev)); h->stage_dev = nullptr; h->stage_floats = 0; }
+    const size_t c = (size_t)need;
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off += align64(floats); return o; };
     size_t o1[kTowers], o3[kTowers], o2[kTowers], o5[kTowers];
@@ -244,7 +249,7 @@ int ensure_workspace(scs_ctx* h) {
         h->a_pool2[t] = h->ws + o2[t]; h->a_conv5[t] = h->ws + o5[t];
     }
     h->a_feat = h->ws + of; h->a_fc1 = h->ws + o_fc1; h->a_fc2 = h->ws + o_fc2; h->a_logits = h->ws + o_lg;
-    h->ws_chunk = h->chunk;
+    h->ws_chunk = need;
     h->last_n = 0;
     return SCS_OK;
 }
@@ -425,11 +430,11 @@ static int forward_common(scs_handle h, const float* ax, const float* co, const 
     if (!h->has_params) { set_error("scs_forward before scs_set_params"); return SCS_ERR_STATE; }
     if (n == 0) return SCS_OK;
     SCS_HIP(hipSetDevice(h->device));
-    int rc = ensure_workspace(h);
+    const int step = balanced_chunk(n, h->chunk);
+    int rc = ensure_workspace(h, step);
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
-    const int step = balanced_chunk(n, h->chunk);
     for (int64_t s = 0; s < n; s += step) {
         const int m = (int)((n - s < step) ? (n - s) : step);
         rc = forward_chunk(h, ax ? ax + s * 1024 : nullptr, co ? co + s * 1024 : nullptr, sa ? sa + s * 1024 : nullptr,
@@ -461,10 +466,11 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
     if (!h->has_params) { set_error("scs_forward_host before scs_set_params"); return SCS_ERR_STATE; }
     if (n == 0) return SCS_OK;
     SCS_HIP(hipSetDevice(h->device));
-    int rc = ensure_workspace(h);
+    const int hstep = balanced_chunk(n, h->chunk);
+    int rc = ensure_workspace(h, hstep);
     if (rc != SCS_OK) return rc;
     if (h->packed_dirty) { rc = repack_inference(h, nullptr); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
-    const size_t c = (size_t)h->chunk;
+    const size_t c = (size_t)h->ws_chunk;
     const size_t per = 3 * 1024 + 15 + 15 + 1;                  // views, atlas, probs, label
     if (!h->stage_dev || h->stage_floats < c * per) {
         if (h->stage_dev) SCS_HIP(hipFree(h->stage_dev));
@@ -473,8 +479,8 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
     }
     float* d_ax = h->stage_dev; float* d_co = d_ax + c * 1024; float* d_sa = d_co + c * 1024;
     float* d_at = d_sa + c * 1024; float* d_pr = d_at + c * 15; int32_t* d_lb = reinterpret_cast<int32_t*>(d_pr + c * 15);
-    for (int64_t s = 0; s < n; s += h->chunk) {
-        const size_t m = (size_t)((n - s < h->chunk) ? (n - s) : h->chunk);
+    for (int64_t s = 0; s < n; s += hstep) {
+        const size_t m = (size_t)((n - s < hstep) ? (n - s) : hstep);
         SCS_HIP(hipMemcpyAsync(d_ax, ax + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
         SCS_HIP(hipMemcpyAsync(d_co, co + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
         SCS_HIP(hipMemcpyAsync(d_sa, sa + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
@@ -494,11 +500,11 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
     SCS_ARG(n > 0 && ax && co && sa && atlas, "null input pointer or n <= 0");
     if (!h->has_params) { set_error("scs_forward_profiled before scs_set_params"); return SCS_ERR_STATE; }
     SCS_HIP(hipSetDevice(h->device));
-    int rc = ensure_workspace(h);
+    const int step = balanced_chunk(n, h->chunk);
+    int rc = ensure_workspace(h, step);
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
-    const int step = balanced_chunk(n, h->chunk);
     const int nchunks = (int)((n + step - 1) / step);
     std::vector<hipEvent_t> ev((size_t)nchunks * 9);
     for (auto& e : ev) SCS_HIP(hipEventCreate(&e));

@@ -44,7 +44,7 @@ struct scs_ctx {
 };
 
 namespace scs {
-int ensure_workspace(scs_ctx* h);
+int ensure_workspace(scs_ctx* h, int need);
 int repack_inference(scs_ctx* h, hipStream_t st);
 int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,

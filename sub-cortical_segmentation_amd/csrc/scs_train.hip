@@ -889,15 +889,16 @@ int scs_eval_batch(scs_handle h, const float* ax, const float* co, const float* 
     SCS_HIP(hipSetDevice(h->device));
     int rc = train_ensure(h, 1);
     if (rc != SCS_OK) return rc;
-    rc = ensure_workspace(h);
+    const int estep = (int)(n < h->chunk ? (n + 15) / 16 * 16 : h->chunk);
+    rc = ensure_workspace(h, estep);
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
     TrainWs* w = h->tws;
     SCS_HIP(hipMemsetAsync(w->eval_acc, 0, 2 * sizeof(double), st));
     constexpr HeadOff H = head_off();
-    for (int64_t s = 0; s < n; s += h->chunk) {
-        const int m = (int)((n - s < h->chunk) ? (n - s) : h->chunk);
+    for (int64_t s = 0; s < n; s += estep) {
+        const int m = (int)((n - s < estep) ? (n - s) : estep);
         rc = forward_chunk(h, ax + s * 1024, co + s * 1024, sa + s * 1024, atlas + s * 15, nullptr, 0, 0, 0, nullptr, nullptr, m,
                            nullptr, nullptr, st, nullptr);
         if (rc != SCS_OK) return rc;

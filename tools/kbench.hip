@@ -1,5 +1,8 @@
-// kbench - A/B timing of conv3x3_mfma_kernel configurations in ONE process (cdna_hip_programming.md rule 24).
-// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I sub-cortical_segmentation_amd/csrc tools/kbench.hip -o gpurun_out/kbench
+// kbench - A/B timing of conv3x3_mfma_kernel configurations in ONE process (cdna_hip_programming.md rule 24), plus
+// per-phase s_memtime stamps of diagnostic (STAMP) instantiations.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I sub-cortical_segmentation_amd/csrc tools/kbench.hip -o build/kbench
+// Ablation builds: add -DSCS_ABLATE=1 (no MFMA) / 2 (no activation reads) / 3 (no conv1) / 4 (no 4-wide epilogue) /
+// 5 (no copy-out); their outputs are wrong on purpose, only the timings mean something.
 // Inputs are random (rule 25); outputs are not checked here (tests/ do that through the C ABI).
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +23,6 @@ static float* dev_random(size_t n, unsigned seed) {
     return d;
 }
 
-static int g_stagger = 0;
 template <class C>
 static void run(const char* name, int n, int rounds, double macs_per_patch_tower) {
     CK(conv_set_attr<C>());
@@ -48,7 +50,7 @@ static void run(const char* name, int n, int rounds, double macs_per_patch_tower
     }
     CK(hipGetLastError());
     const double flop = 2.0 * macs_per_patch_tower * 3.0 * n;
-    printf("%-4d %-32s n=%d  min %.3f ms  mean %.3f ms  %.1f TF/s (min)  LDS %zu B  TPW %d\n", g_stagger, name, n, best, sum / rounds,
+    printf("%-36s n=%d  min %.3f ms  mean %.3f ms  %.1f TF/s (min)  LDS %zu B  TPW %d\n", name, n, best, sum / rounds,
            flop / (best * 1e-3) / 1e12, (size_t)C::LDS_BYTES, C::TPW);
     for (int t = 0; t < kTowers; ++t) {
         CK(hipFree((void*)a.in[t])); CK(hipFree((void*)a.w[t])); CK(hipFree((void*)a.bias[t]));

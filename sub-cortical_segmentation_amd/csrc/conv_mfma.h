@@ -22,6 +22,7 @@
 namespace scs {
 
 constexpr int kW1Floats = 12 * 16 + 12 * 4 + 20;   // conv1 operands: [12][16] + [12][4] + bias[20]
+static_assert(kW1Floats > 256 && kW1Floats <= 512, "conv1 operand staging assumes two loads per thread");
 
 enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2 };
 enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3 };
@@ -280,6 +281,10 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
                                   if (e < total) s_in[pl * C::PLANE + (y + 2) * C::WIN + x + 2] = v; });
     } else {
         static_assert(C::SRC == SRC_NCHW || C::SRC == SRC_NCHW_PAD2 || C::G == 1, "fused conv1 variants take one patch per workgroup");
+        // conv1 operands and the raw rows are fetched together: one global round trip, not two
+        const float* __restrict__ w1g = pick3(a.w1, tower);
+        const float w1a = w1g[min(tid, kW1Floats - 1)];
+        const float w1b = w1g[min(tid + 256, kW1Floats - 1)];
         if constexpr (C::SRC == SRC_CONV1) {
             const float4* __restrict__ src = reinterpret_cast<const float4*>(insrc + (size_t)g0 * 1024 + band * C::HOB * 32);
             if (tid < C::XROWS * 8) reinterpret_cast<float4*>(s_x)[tid] = src[tid];
@@ -299,7 +304,8 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
             }
         }
         float* s_w1 = s_x + C::XS_ROWS_FLOATS + 4;
-        for (int e = tid; e < kW1Floats; e += 256) s_w1[e] = pick3(a.w1, tower)[e];
+        s_w1[tid] = w1a;                                   // kW1Floats = 260: 256 + 4
+        if (tid + 256 < kW1Floats) s_w1[tid + 256] = w1b;
         __syncthreads();
         if constexpr (C::STAMP) { if (tid == 0) stp[5] = __builtin_amdgcn_s_memtime(); }
 #if !(defined(SCS_ABLATE) && SCS_ABLATE == 3)

@@ -450,22 +450,32 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
             }
         }
     }
-    // leftover channels: lane l holds, for pixel (l & 15), the partial sums of k-subgroup kq for 4 couts (vgpr i)
+    // leftover channels: lane l holds, for pixel (l & 15), the partial sums of k-subgroup kq for 4 couts (vgpr i).
+    // All cross-lane reductions first, as one branch-free block (independent chains the scheduler can overlap: each
+    // has two LDS-crossbar round trips), then the guarded stores.
     const int xor32_addr = (lane ^ 32) << 2;
+    float lval[C::TPW][C::NT4 > 0 ? C::NT4 : 1];
+#pragma unroll
+    for (int j = 0; j < C::TPW; ++j)
+#pragma unroll
+        for (int u = 0; u < C::NT4; ++u) {
+            float val = ksub_reduce(acc4[j][u], kq, xor32_addr);                         // this lane stores cout 4u + kq
+            if constexpr (C::POOL) val = max_quad(val);
+            lval[j][u] = val;
+        }
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
         const int t = wave + 4 * j;
         if (t >= C::TILES) continue;
 #if defined(SCS_ABLATE) && SCS_ABLATE == 4
-        if (t >= 0) { s_o[lane] = acc4[j][0][0] + acc4[j][0][1] + acc4[j][0][2] + acc4[j][0][3]; continue; }
+        if (t >= 0) { s_o[lane] = lval[j][0]; continue; }
 #endif
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
-            float val = ksub_reduce(acc4[j][u], kq, xor32_addr);                         // this lane stores cout 4u + kq
+            float val = lval[j][u];
             const int co = C::NT16 * 16 + u * 4 + kq;
             const float bv = bv4[u];
             if constexpr (C::POOL) {
-                val = max_quad(val);
                 const int widx = t * 4 + ((lane & 15) >> 2);
                 if ((lane & 3) == 0 && widx < C::G * C::WB) {
                     const int g = widx / C::WB;

@@ -79,7 +79,8 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
  *   vol_dev     float32 [X][Y][Z] (C order), already normalised (base.py:358)
  *   centers_dev int32 [n][3] voxel coordinates (x,y,z); patches are zero padded outside the volume and the
  *               centre lands at patch index [16][16] (base.py:293-306)
- *   atlas4d_dev float32 [X][Y][Z][15]; rows that sum to 0 become background, channel 14 = 1 (base.py:391-394)
+ *   atlas4d_dev float32 [X][Y][Z][15]; rows that sum to 0 become background, channel 14 = 1 (base.py:391-394);
+ *               a centre outside the volume (the Python layer rejects those) reads an all-zero prior, never memory
  * Replaces: the host loop load_patch_batch + get_patches (base.py:380-397, 272-308) feeding net.predict. */
 int scs_forward_volume(scs_handle h, const float* vol_dev, int dim_x, int dim_y, int dim_z,
                        const int32_t* centers_dev, const float* atlas4d_dev, int64_t n,

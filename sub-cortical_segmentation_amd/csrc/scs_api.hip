@@ -108,10 +108,11 @@ __global__ void atlas_gather_kernel(const float* __restrict__ atlas4d, const int
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     const int x = centers[row * 3], y = centers[row * 3 + 1], z = centers[row * 3 + 2];
-    const float* src = atlas4d + (((size_t)x * dy + y) * dz + z) * 15;
+    const bool inside = (unsigned)x < (unsigned)dx && (unsigned)y < (unsigned)dy && (unsigned)z < (unsigned)dz;
+    const float* src = atlas4d + (inside ? (((size_t)x * dy + y) * dz + z) * 15 : 0);
     float v[15], s = 0.f;
 #pragma unroll
-    for (int c = 0; c < 15; ++c) { v[c] = src[c]; s += v[c]; }
+    for (int c = 0; c < 15; ++c) { v[c] = inside ? src[c] : 0.f; s += v[c]; }     // a centre outside the volume reads as "no prior"
     if (s == 0.f) v[14] = 1.f;
     float* dst = fc1 + (size_t)row * kFC1ld + kFC1;
 #pragma unroll

@@ -101,9 +101,20 @@ class _DevArray:
         self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f4', 'data': (int(ptr), False), 'version': 2}
 
 
+_wrapped = {}
+
+
 def wrap_device_floats(ptr, n, device):
+    """torch view of `n` floats at device pointer `ptr` (cached: the arenas live as long as their handle)."""
     import torch
-    return torch.as_tensor(_DevArray(ptr, n), device='cuda:%d' % device)
+    key = (int(ptr), int(n), int(device))
+    t = _wrapped.get(key)
+    if t is None:
+        t = torch.as_tensor(_DevArray(ptr, n), device='cuda:%d' % device)
+        if len(_wrapped) > 64:
+            _wrapped.clear()
+        _wrapped[key] = t
+    return t
 
 
 def allreduce_flat(t, n_active):
@@ -113,9 +124,6 @@ def allreduce_flat(t, n_active):
         td = _td()
         td.all_reduce(t, op=td.ReduceOp.SUM)
     return 1.0 / max(1, n_active)
-
-
-_step_state = {'n_active': None}
 
 
 def allreduce_grads(handle, active, stream=0, n_active=None):

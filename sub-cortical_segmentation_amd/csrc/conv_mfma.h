@@ -69,7 +69,7 @@ struct ConvCfg {
     static_assert(CIN_ % 4 == 0, "k-steps are groups of 4 input channels");
     static_assert(COUT_ % 4 == 0, "output channels are covered by 16-wide and 4-wide MFMA blocks");
     static_assert(HO % NB_ == 0 && (!POOL || (HOB % 2 == 0)), "bands must split the output rows (evenly for pooling)");
-    static_assert(NB_ == 1 || (G_ == 1 && SRC_ != SRC_NCHW_PAD2), "bands: one patch per workgroup");
+    static_assert(NB_ == 1 || G_ == 1, "bands: one patch per workgroup");
     static_assert(PLANE_ >= HINB * HIN_, "plane stride too small");
     static_assert(LDS_BYTES * WPS_ <= 160 * 1024, "LDS budget (WPS workgroups of 4 waves per CU)");
 };
@@ -270,15 +270,20 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
                 [&](int e, float v) { const int pl = e / BW, r = e - pl * BW; s_in[pl * C::PLANE + r] = v; });
         }
     } else if constexpr (C::SRC == SRC_NCHW_PAD2) {
-        constexpr int HS = C::HSRC, HW = HS * HS;
+        // destination-driven: every element of the (band of the) zero-padded plane is written once, taken from the
+        // source when it falls inside it (padded row yp = band*HOB + yl <-> source row yp - 2)
+        constexpr int HS = C::HSRC, HW = HS * HS, BW = C::HINB * C::WIN;
         const float* __restrict__ src = insrc + (size_t)g0 * C::CIN * HW;
-        for (int e = tid; e < C::G * C::CIN * C::PLANE; e += 256) s_in[e] = 0.f;
-        __syncthreads();
-        const int total = ng * C::CIN * HW;
-        staged_copy<C::G * C::CIN * HW, float>(
-            tid, [&](int e) { return (e < total) ? src[e] : 0.f; },
-            [&](int e, float v) { const int pl = e / HW, r = e - pl * HW, y = r / HS, x = r - y * HS;
-                                  if (e < total) s_in[pl * C::PLANE + (y + 2) * C::WIN + x + 2] = v; });
+        const int planes = ng * C::CIN;
+        staged_copy<C::G * C::CIN * BW, float>(
+            tid,
+            [&](int e) {
+                const int pl = e / BW, r = e - pl * BW, yl = r / C::WIN, xp = r - yl * C::WIN;
+                const int ys = band * C::HOB + yl - 2, xs = xp - 2;
+                const bool ok = pl < planes && (unsigned)ys < (unsigned)HS && (unsigned)xs < (unsigned)HS;
+                return ok ? src[(size_t)pl * HW + ys * HS + xs] : 0.f;
+            },
+            [&](int e, float v) { const int pl = e / BW, r = e - pl * BW; s_in[pl * C::PLANE + r] = v; });
     } else {
         static_assert(C::SRC == SRC_NCHW || C::SRC == SRC_NCHW_PAD2 || C::G == 1, "fused conv1 variants take one patch per workgroup");
         // conv1 operands and the raw rows are fetched together: one global round trip, not two

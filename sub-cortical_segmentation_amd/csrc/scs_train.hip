@@ -22,13 +22,13 @@ namespace scs {
 // ------------------------------------------------------------------------------------------- configurations
 using TF2 = ConvCfg<20, 20, 30, 1, EPI_RAW, SRC_NCHW, 496, 2, 2>;
 using TF3 = ConvCfg<20, 40, 14, 2, EPI_RAW, SRC_NCHW, 208, 1, 2>;
-using TF4 = ConvCfg<40, 40, 12, 2, EPI_RAW, SRC_NCHW, 144, 1, 2>;
-using TF5 = ConvCfg<40, 60, 5, 16, EPI_RAW, SRC_NCHW, 27, 1, 1>;
+using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW, SRC_NCHW, 144, 1, 4>;
+using TF5 = ConvCfg<40, 60, 5, 8, EPI_RAW, SRC_NCHW, 27, 1, 2>;
 // data gradients: input = dZ_i zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i
 using DG5 = ConvCfg<60, 40, 7, 8, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 1>;
-using DG4 = ConvCfg<40, 40, 14, 2, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 1>;
-using DG3 = ConvCfg<40, 20, 16, 2, EPI_RAW, SRC_NCHW_PAD2, 272, 1, 1>;
-using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 1040, 1, 1>;
+using DG4 = ConvCfg<40, 40, 14, 1, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 3>;
+using DG3 = ConvCfg<40, 20, 16, 1, EPI_RAW, SRC_NCHW_PAD2, 144, 2, 4>;
+using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 544, 2, 3>;
 
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 constexpr bool kPool[kConvs] = {false, true, false, true, false};

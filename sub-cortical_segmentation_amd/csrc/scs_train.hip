@@ -10,6 +10,7 @@
 // BN statistics/gradients are per-channel reductions with double accumulators; weight gradients and the
 // dense-layer backward GEMMs are plain LDS-tiled vector-ALU kernels in this round.
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "conv_mfma.h"
@@ -497,8 +498,8 @@ __device__ __forceinline__ float bn_dy(const float* __restrict__ z, const float*
     return yv > 0.f ? dout[nc * H * H + y * H + x] : 0.f;
 }
 
-template <bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(CPtr3 Z, CPtr3 dOut, int n, int C, int H, const float* stats, int layer,
+template <bool POOL, int H>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(CPtr3 Z, CPtr3 dOut, int n, int C, const float* stats, int layer,
                                                             const float* params, int bn_off0, int tower_stride, double* part) {
     __shared__ double s_red[4];
     const int c = blockIdx.x, t = blockIdx.y, sp = blockIdx.z;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(CPtr3 Z, CPtr3 dOut
     const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
     const float* bn = params + bn_off0 + t * tower_stride;
     const float mean = st[c], inv = st[64 + c], sc = bn[C + c] * inv, sh = bn[c] - mean * sc;
-    const int pix = H * H;
+    constexpr int pix = H * H;
     const int per = (n + kRedSplit - 1) / kRedSplit, n0 = sp * per, n1 = min(n, n0 + per);
     double sb = 0, sg = 0;
     for (int ni = n0; ni < n1; ++ni) {
@@ -535,8 +536,8 @@ __global__ void bn_bwd_final_kernel(const double* part, int C, float* stats, int
     gb[c] = (float)sb; gb[C + c] = (float)sg;                  // d beta, d gamma (mean / inv_std stay 0)
 }
 
-template <bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, Ptr3 dZ, int n, int C, int H, const float* stats,
+template <bool POOL, int H>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, Ptr3 dZ, int n, int C, const float* stats,
                                                           int layer, const float* params, int bn_off0, int tower_stride) {
     const int t = blockIdx.y;
     const float* __restrict__ z = sel3(Z.p, t);
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, 
     float* __restrict__ dz = sel3(dZ.p, t);
     const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
     const float* bn = params + bn_off0 + t * tower_stride;
-    const int pix = H * H;
+    constexpr int pix = H * H;
     const float invM = 1.f / ((float)n * pix);
     const long total = (long)n * C * pix;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -818,15 +819,21 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         CPtr3 Zi = c3(w->Z, i), dOut{{w->dX[0][cur], w->dX[1][cur], w->dX[2][cur]}};
         Ptr3 dZ{{w->dZ[0], w->dZ[1], w->dZ[2]}};
         const long tot = (long)n * C * Hh * Hh;
-        if (kPool[i]) {
-            hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(C, kTowers, kRedSplit), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats, w->red_part);
+        auto bn_bwd = [&](auto pool_tag, auto h_tag) {
+            constexpr bool PL = decltype(pool_tag)::value;
+            constexpr int HH = decltype(h_tag)::value;
+            hipLaunchKernelGGL((bn_bwd_partial_kernel<PL, HH>), dim3(C, kTowers, kRedSplit), dim3(256), 0, st, Zi, dOut, n, C, w->stats, i, P,
+                               T0.bn[i], kTowerFloats, w->red_part);
             hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(kTowers), dim3(64), 0, st, w->red_part, C, w->stats, i, G, T0.bn[i], kTowerFloats);
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
-        } else {
-            hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(C, kTowers, kRedSplit), dim3(256), 0, st, Zi, dOut, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats, w->red_part);
-            hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(kTowers), dim3(64), 0, st, w->red_part, C, w->stats, i, G, T0.bn[i], kTowerFloats);
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
-        }
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, HH>), dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, w->stats, i, P,
+                               T0.bn[i], kTowerFloats);
+        };
+        using std::integral_constant;
+        if (i == 0) bn_bwd(integral_constant<bool, false>{}, integral_constant<int, 30>{});
+        else if (i == 1) bn_bwd(integral_constant<bool, true>{}, integral_constant<int, 28>{});
+        else if (i == 2) bn_bwd(integral_constant<bool, false>{}, integral_constant<int, 12>{});
+        else if (i == 3) bn_bwd(integral_constant<bool, true>{}, integral_constant<int, 10>{});
+        else bn_bwd(integral_constant<bool, false>{}, integral_constant<int, 3>{});
         CPtr3 Xi;
         for (int t = 0; t < kTowers; ++t) Xi.p[t] = (i == 0) ? xin[t] : w->X[t][i];
         CPtr3 dZc{{w->dZ[0], w->dZ[1], w->dZ[2]}};

@@ -86,6 +86,13 @@ int scs_forward_volume(scs_handle h, const float* vol_dev, int dim_x, int dim_y,
                        const int32_t* centers_dev, const float* atlas4d_dev, int64_t n,
                        float* probs_dev, int32_t* labels_dev, void* stream);
 
+/* Same patch gather, but the priors arrive as rows: atlas_rows_dev float32 [n][15], one row per centre, ALREADY carrying
+ * the background rule (what load_patch_batch yields as x_atlas, base.py:388-394).  For hosts that keep the 4-D prior in
+ * the file's own (Fortran) order and gather the n rows themselves instead of shipping X*Y*Z*15 floats to the device. */
+int scs_forward_volume_rows(scs_handle h, const float* vol_dev, int dim_x, int dim_y, int dim_z,
+                            const int32_t* centers_dev, const float* atlas_rows_dev, int64_t n,
+                            float* probs_dev, int32_t* labels_dev, void* stream);
+
 /* Measurement hook (bench.py): scs_forward with HIP events recorded on `stream` around each stage of every
  * chunk; synchronises.  stage_ms[8] receives the summed elapsed milliseconds of
  *   0 conv1+conv2+pool1, 1 conv3, 2 conv4+pool2, 3 conv5, 4 d1 x3, 5 FC1 (+atlas concat), 6 fc_2, 7 out+softmax

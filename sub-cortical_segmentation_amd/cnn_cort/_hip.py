@@ -32,6 +32,7 @@ SIGNATURES = {
     'scs_forward': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
     'scs_forward_host': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
     'scs_forward_volume': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
+    'scs_forward_volume_rows': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
     'scs_forward_profiled': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _c.POINTER(_c.c_int)]),
     'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
     'scs_train_step': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
@@ -128,6 +129,11 @@ class Handle:
         _check(self.lib.scs_forward_volume(self.h, _ptr(vol), int(dims[0]), int(dims[1]), int(dims[2]), _ptr(centers),
                                            _ptr(atlas4d), int(n), _ptr(probs), _ptr(labels), stream or None),
                'scs_forward_volume')
+
+    def forward_volume_rows(self, vol, dims, centers, atlas_rows, n, probs=None, labels=None, stream=0):
+        _check(self.lib.scs_forward_volume_rows(self.h, _ptr(vol), int(dims[0]), int(dims[1]), int(dims[2]),
+                                                _ptr(centers), _ptr(atlas_rows), int(n), _ptr(probs), _ptr(labels),
+                                                stream or None), 'scs_forward_volume_rows')
 
     def forward_profiled(self, ax, co, sa, atlas, n, probs=None, labels=None, stream=0):
         """-> (stage_ms float32[8], launches) measured with HIP events on `stream`."""

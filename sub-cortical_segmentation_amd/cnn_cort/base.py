@@ -197,7 +197,9 @@ def _crop_enabled(options):
 
 
 def _scan_inputs(scan_name, options):
-    """Everything test_scan / load_patch_batch need from disk: normalised volume, ROI centres, atlas."""
+    """Everything test_scan / load_patch_batch need from disk: normalised volume, ROI centres, and the prior rows
+    of those centres.  The 15-channel prior volume itself (~0.8 GB for a 256x256x192 subject) is never held:
+    nifti.load_rows streams the file once and keeps the ROI entries."""
     dir_name = os.path.dirname(scan_name)
     t1 = nifti.load(scan_name)
     image = t1.get_data()
@@ -215,30 +217,41 @@ def _scan_inputs(scan_name, options):
         centers = get_mask_voxels(image.astype(bool))
     if is_true(options.get('debug')):
         print("    -->  num of samples to test:", len(centers))
-    atlas_image = nifti.load(atlas_name).get_data()
-    return t1, image, image_norm, centers, atlas_image
+    return t1, image, image_norm, centers, atlas_rows_from_file(atlas_name, centers, image.shape)
+
+
+def _background_rule(v):
+    """Rows without any prior become background: channel 14 = 1 (base.py:391-394)."""
+    v = np.asarray(v).astype(np.float32)
+    v[v.sum(axis=1) == 0, 14] = 1
+    return v
 
 
 def atlas_vectors_at(atlas_image, centers):
     """[N,15] float32 prior rows with the inference-path background rule (base.py:388-394)."""
     c = np.asarray(centers, dtype=np.int64).reshape(-1, 3)
-    v = np.asarray(atlas_image[c[:, 0], c[:, 1], c[:, 2]]).astype(np.float32)
-    zero = v.sum(axis=1) == 0
-    v[zero, 14] = 1
-    return v
+    return _background_rule(atlas_image[c[:, 0], c[:, 1], c[:, 2]])
+
+
+def atlas_rows_from_file(atlas_name, centers, volume_shape=None):
+    """atlas_vectors_at(load(atlas_name).get_data(), centers) without loading the volume."""
+    rows = nifti.load_rows(atlas_name, centers)
+    if rows.ndim != 2 or rows.shape[1] != 15:
+        raise ValueError('%s: expected a 4-D prior with 15 channels' % atlas_name)
+    return _background_rule(rows)
 
 
 def load_patch_batch(scan_name, options, datatype=np.float32):
     """Generator over host-side test batches, as the reference yields them (base.py:335-397):
     (axial [B,1,p,p], coronal, saggital, atlas [B,15], centers).  Kept for API compatibility and for tests;
     test_scan itself uses the gather-fused GPU path instead."""
-    _, _, image_norm, centers_all, atlas_image = _scan_inputs(scan_name, options)
+    _, _, image_norm, centers_all, atlas_rows = _scan_inputs(scan_name, options)
     bs = options['test_batch_size']
     for i in range(0, len(centers_all), bs):
         centers = centers_all[i:i + bs]
         views = [np.stack([get_patches(image_norm, centers, options['patch_size'], mode=m).astype(datatype)], axis=1)
                  for m in _MODES]
-        yield views[0], views[1], views[2], atlas_vectors_at(atlas_image, centers), centers
+        yield views[0], views[1], views[2], atlas_rows[i:i + bs], centers
 
 
 def test_scan(net, test_scan, options):
@@ -246,19 +259,21 @@ def test_scan(net, test_scan, options):
     elapsed minutes (base.py:401-458)."""
     s_time = time.time()
     image_path = os.path.dirname(test_scan)
-    t1, raw, image_norm, centers, atlas_image = _scan_inputs(test_scan, options)
+    t1, raw, image_norm, centers, atlas_rows = _scan_inputs(test_scan, options)
     want_probs = is_true(options.get('out_probabilities'))
     image = np.zeros_like(raw)
-    image_proba = np.zeros(tuple(raw.shape) + (15,)) if want_probs else None
 
+    # the priors stay on the host; only the ROI rows travel (base.py:388-394 rule already applied)
     labels, probs = net.predict_volume(np.ascontiguousarray(image_norm, dtype=np.float32), centers,
-                                       np.ascontiguousarray(atlas_image, dtype=np.float32), want_probs=want_probs,
+                                       atlas_rows=atlas_rows, want_probs=want_probs,
                                        batch=options['test_batch_size'])
     x, y, z = centers[:, 0], centers[:, 1], centers[:, 2]
     image[x, y, z] = labels
     if want_probs:
-        image_proba[x, y, z, :] = probs
-        nifti.save(image_proba, os.path.join(image_path, 'out_subcortical_prob.nii.gz'), like=t1)
+        # the reference fills a dense float64 [X,Y,Z,15] array (base.py:417,438) and saves it; the same file is
+        # written here from the ROI rows alone (1.5 GB dense for a 256x256x192 subject, ~99 % zeros)
+        nifti.save_sparse(os.path.join(image_path, 'out_subcortical_prob.nii.gz'), tuple(raw.shape) + (15,),
+                          np.float64, centers, probs, like=t1)
     if is_true(options.get('post_process')):
         nifti.save(post_process_segmentation(image_path, image), os.path.join(image_path, 'out_subcortical_seg_prec.nii.gz'), like=t1)
     else:

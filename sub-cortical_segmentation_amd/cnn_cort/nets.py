@@ -220,19 +220,28 @@ class Net:
         """int64 [N] = argmax(predict_proba) - base.py:425-428 (nolearn, use_label_encoder=False)."""
         return self._forward(X, False)[1]
 
-    def predict_volume(self, volume, centers, atlas4d, want_probs=False, batch=100000):
-        """Gather-fused inference for test_scan: `volume` float32 [X,Y,Z] already z-scored, `centers` int [N,3],
-        `atlas4d` float32 [X,Y,Z,15].  Returns (labels int64 [N], probs float32 [N,15] or None).
+    def predict_volume(self, volume, centers, atlas4d=None, want_probs=False, batch=100000, atlas_rows=None):
+        """Gather-fused inference for test_scan: `volume` float32 [X,Y,Z] already z-scored, `centers` int [N,3], and
+        the priors either as `atlas4d` float32 [X,Y,Z,15] (gathered on the device, background rule applied there)
+        or as `atlas_rows` float32 [N,15] already gathered by the caller with the rule applied (base.atlas_vectors_at).
+        Returns (labels int64 [N], probs float32 [N,15] or None).
         Replaces load_patch_batch + net.predict/predict_proba (base.py:380-397, 425-438)."""
         torch = self._torch()
         volume = np.ascontiguousarray(volume, dtype=np.float32)
-        atlas4d = np.ascontiguousarray(atlas4d, dtype=np.float32)
         centers = np.ascontiguousarray(np.asarray(centers).reshape(-1, 3), dtype=np.int32)
         if volume.ndim != 3:
             raise ValueError('volume must be 3-D, got shape %r' % (volume.shape,))
-        if tuple(atlas4d.shape) != tuple(volume.shape) + (15,):
-            raise ValueError('atlas4d shape %r does not match volume shape %r + (15,)' % (atlas4d.shape, volume.shape))
+        if (atlas4d is None) == (atlas_rows is None):
+            raise ValueError('give exactly one of atlas4d and atlas_rows')
         n = centers.shape[0]
+        if atlas_rows is not None:
+            atlas_rows = np.ascontiguousarray(atlas_rows, dtype=np.float32)
+            if atlas_rows.shape != (n, 15):
+                raise ValueError('atlas_rows must be [%d, 15], got %r' % (n, atlas_rows.shape))
+        else:
+            atlas4d = np.ascontiguousarray(atlas4d, dtype=np.float32)
+            if tuple(atlas4d.shape) != tuple(volume.shape) + (15,):
+                raise ValueError('atlas4d shape %r does not match volume shape %r + (15,)' % (atlas4d.shape, volume.shape))
         if n and ((centers < 0).any() or (centers >= np.asarray(volume.shape, np.int32)).any()):
             raise ValueError('patch centres outside the volume')
         if n == 0:
@@ -241,15 +250,19 @@ class Net:
         dev = 'cuda:%d' % self._dev()
         stream = torch.cuda.current_stream(self._dev()).cuda_stream
         d_vol = torch.from_numpy(volume).to(dev)
-        d_atl = torch.from_numpy(atlas4d).to(dev)
+        d_atl = torch.from_numpy(atlas_rows if atlas_rows is not None else atlas4d).to(dev)
         d_cen = torch.from_numpy(centers).to(dev)
         d_lab = torch.empty((n,), dtype=torch.int32, device=dev)
         d_pr = torch.empty((n, 15), dtype=torch.float32, device=dev) if want_probs else None
         batch = max(1, int(batch))
         for lo in range(0, n, batch):
             hi = min(n, lo + batch)
-            h.forward_volume(d_vol, volume.shape, d_cen[lo:hi], d_atl, hi - lo,
-                             d_pr[lo:hi] if want_probs else None, d_lab[lo:hi], stream)
+            if atlas_rows is not None:
+                h.forward_volume_rows(d_vol, volume.shape, d_cen[lo:hi], d_atl[lo:hi], hi - lo,
+                                      d_pr[lo:hi] if want_probs else None, d_lab[lo:hi], stream)
+            else:
+                h.forward_volume(d_vol, volume.shape, d_cen[lo:hi], d_atl, hi - lo,
+                                 d_pr[lo:hi] if want_probs else None, d_lab[lo:hi], stream)
         labels = d_lab.cpu().numpy().astype(np.int64)
         return labels, (d_pr.cpu().numpy() if want_probs else None)
 

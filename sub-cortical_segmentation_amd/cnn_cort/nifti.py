@@ -5,11 +5,22 @@ The reference reads and writes volumes through nibabel (/root/reference/cnn_cort
 which is not available here and must not be assumed on a GPU box; the hot path only needs: load the voxel
 array in (x,y,z[,t]) index order with scl_slope/inter applied the way ``get_data()`` does, keep the header's
 geometry, and write an array back with that geometry.
+
+A subject of BASELINE configs[4] moves ~0.8 GB of priors in and ~1.5 GB of float64 probabilities out per scan, so
+the file layer is written for throughput: arrays keep the file's Fortran memory order (as nibabel's do; no
+transposing copy), .gz input is inflated in one zlib call per member, and .gz output is deflated in parallel as
+independent gzip members (a valid RFC-1952 stream that gzip/zcat/nibabel read as one file).
 """
-import gzip
+import os
 import struct
+import threading
+import zlib
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
+
+GZIP_LEVEL = 1                     # nibabel's default_compresslevel
+_MEMBER_BYTES = 16 << 20           # uncompressed bytes per gzip member
 
 _DTYPES = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64,
            256: np.int8, 512: np.uint16, 768: np.uint32, 1024: np.int64, 1280: np.uint64}
@@ -43,50 +54,213 @@ class NiftiImage:
         return np.diag([pixdim[1], pixdim[2], pixdim[3], 1.0]).astype(np.float64)
 
 
-def _open(path, mode):
-    return gzip.open(path, mode) if str(path).endswith('.gz') else open(path, mode)
+def _workers():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:                                               # container CPU quota (cgroup v2), when one is set
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+_STREAM_BYTES = 8 << 20             # inflated bytes handed on per step
+_FEED_BYTES = 256 << 10             # compressed bytes fed to zlib per call
+
+
+def _inflate_stream(f):
+    """Yield the inflated content of an open (possibly multi-member) gzip file in pieces of <= _STREAM_BYTES,
+    never holding more than one piece (the temporary blocks are recycled by the allocator, so a 1 GB volume costs
+    one pass of page touching in its final buffer, not three)."""
+    d = zlib.decompressobj(31)
+    pending = b''
+    while True:
+        if not pending:
+            pending = f.read(_FEED_BYTES)
+            if not pending:
+                break
+        if d.eof:                                       # next member (zero padding between members is legal)
+            pending = pending.lstrip(b'\x00')
+            if not pending:
+                continue
+            d = zlib.decompressobj(31)
+        out = d.decompress(pending, _STREAM_BYTES)
+        pending = d.unused_data if d.eof else d.unconsumed_tail
+        if out:
+            yield out
+    while not d.eof:                                    # output still buffered inside zlib after the last input
+        out = d.decompress(b'', _STREAM_BYTES)
+        if not out:
+            raise IOError('truncated gzip stream')
+        yield out
+
+
+def _plain_stream(f):
+    while True:
+        out = f.read(_STREAM_BYTES)
+        if not out:
+            return
+        yield out
+
+
+def _stream(path, f):
+    magic = f.read(2)
+    f.seek(0)
+    return _inflate_stream(f) if magic == b'\x1f\x8b' else _plain_stream(f)
+
+
+class _Header:
+    def __init__(self, raw, path):
+        if len(raw) < 352:
+            raise IOError('%s: too short for a NIfTI-1 file' % path)
+        endian = '<'
+        if struct.unpack('<i', raw[0:4])[0] != 348:
+            if struct.unpack('>i', raw[0:4])[0] != 348:
+                raise IOError('%s: not a NIfTI-1 file (sizeof_hdr != 348)' % path)
+            endian = '>'
+        if raw[344:348] not in (b'n+1\x00',):
+            raise IOError('%s: only single-file NIfTI-1 (magic n+1) is supported' % path)
+        dim = struct.unpack(endian + '8h', raw[40:56])
+        shape = tuple(int(d) for d in dim[1:1 + dim[0]])
+        while len(shape) > 3 and shape[-1] == 1:
+            shape = shape[:-1]
+        datatype = struct.unpack(endian + 'h', raw[70:72])[0]
+        if datatype not in _DTYPES:
+            raise IOError('%s: unsupported NIfTI datatype code %d' % (path, datatype))
+        self.endian, self.shape = endian, shape
+        self.vox_offset = int(struct.unpack(endian + 'f', raw[108:112])[0])
+        if self.vox_offset < 352:
+            raise IOError('%s: vox_offset %d inside the header' % (path, self.vox_offset))
+        slope, inter = struct.unpack(endian + '2f', raw[112:120])
+        self.scaled = bool(np.isfinite(slope) and slope != 0 and not (slope == 1.0 and inter == 0.0))
+        self.slope, self.inter = slope, inter
+        self.dtype = np.dtype(_DTYPES[datatype]).newbyteorder(endian)
+        self.n = int(np.prod(shape))
+        self.raw = bytes(raw[:348])
+
+    def finish(self, data):
+        """nibabel get_data(): native byte order; scaled -> float64."""
+        if self.endian == '>':
+            data = data.astype(self.dtype.newbyteorder('='))
+        if self.scaled:
+            data = data.astype(np.float64) * self.slope + self.inter
+        return data
+
+
+def _voxel_pieces(path):
+    """-> (header, iterator over (first_byte_index, bytes) pieces of the voxel block, in order)."""
+    f = open(path, 'rb')
+    stream = _stream(path, f)
+    head = b''
+    for piece in stream:                                # the header always fits the first pieces
+        head += piece
+        if len(head) >= 352:
+            break
+    try:
+        hdr = _Header(head, path)
+    except Exception:
+        f.close()
+        raise
+
+    def pieces():
+        try:
+            pos = -hdr.vox_offset                       # byte index relative to the first voxel
+            first = head
+            for piece in _chain(first, stream):
+                lo, hi = pos, pos + len(piece)
+                pos = hi
+                if hi <= 0:
+                    continue
+                if lo < 0:
+                    piece, lo = piece[-lo:], 0
+                yield lo, piece
+        finally:
+            f.close()
+    return hdr, pieces()
+
+
+def _chain(first, rest):
+    yield first
+    for p in rest:
+        yield p
 
 
 def load(path):
-    with _open(path, 'rb') as f:
-        raw = f.read()
-    if len(raw) < 352:
-        raise IOError('%s: too short for a NIfTI-1 file' % path)
-    endian = '<'
-    if struct.unpack('<i', raw[0:4])[0] != 348:
-        if struct.unpack('>i', raw[0:4])[0] != 348:
-            raise IOError('%s: not a NIfTI-1 file (sizeof_hdr != 348)' % path)
-        endian = '>'
-    if raw[344:348] not in (b'n+1\x00',):
-        raise IOError('%s: only single-file NIfTI-1 (magic n+1) is supported' % path)
-    dim = struct.unpack(endian + '8h', raw[40:56])
-    ndim = dim[0]
-    shape = tuple(int(d) for d in dim[1:1 + ndim])
-    while len(shape) > 3 and shape[-1] == 1:
-        shape = shape[:-1]
-    datatype = struct.unpack(endian + 'h', raw[70:72])[0]
-    if datatype not in _DTYPES:
-        raise IOError('%s: unsupported NIfTI datatype code %d' % (path, datatype))
-    vox_offset = int(struct.unpack(endian + 'f', raw[108:112])[0])
-    slope, inter = struct.unpack(endian + '2f', raw[112:120])
-    dt = np.dtype(_DTYPES[datatype]).newbyteorder(endian)
-    n = int(np.prod(shape))
-    data = np.frombuffer(raw, dtype=dt, count=n, offset=vox_offset).reshape(shape, order='F')
-    data = np.ascontiguousarray(data.astype(dt.newbyteorder('=')))
-    if np.isfinite(slope) and slope != 0 and not (slope == 1.0 and inter == 0.0):
-        data = data.astype(np.float64) * slope + inter        # nibabel get_data(): scaled -> float64
-    return NiftiImage(data, header_bytes=raw[:348], endian=endian)
+    hdr, pieces = _voxel_pieces(path)
+    nbytes = hdr.n * hdr.dtype.itemsize
+    buf = np.empty(nbytes, dtype=np.uint8)              # the only full-size allocation; written once
+    got = 0
+    for lo, piece in pieces:
+        take = min(len(piece), nbytes - lo)
+        if take <= 0:
+            break
+        buf[lo:lo + take] = np.frombuffer(piece, dtype=np.uint8, count=take)
+        got = lo + take
+    if got < nbytes:
+        raise IOError('%s: voxel data truncated' % path)
+    # Fortran memory order, as on disk and as nibabel returns it: indexing is [x,y,z(,t)] either way
+    data = hdr.finish(buf.view(hdr.dtype)).reshape(hdr.shape, order='F')
+    return NiftiImage(data, header_bytes=hdr.raw, endian=hdr.endian)
 
 
-def save(data, path, like=None, affine=None):
-    """Write `data` (<= 5-D) as NIfTI-1.  Geometry is copied from `like` (a NiftiImage) when given, else built
-    from `affine` (default identity)."""
-    data = np.asarray(data)
-    if data.dtype == np.bool_:
-        data = data.astype(np.uint8)
-    code = _CODES.get(data.dtype.str[1:])
+def load_rows(path, voxels):
+    """Values of a 3-D/4-D volume at a list of voxels, WITHOUT materialising the volume: the file is streamed once
+    and only the requested entries are kept.  `voxels` int [N,3] (x,y,z); returns [N] (3-D file) or [N,T] (4-D)
+    in the dtype get_data() would have.  Equals  load(path).get_data()[x, y, z]  exactly.
+
+    This is how test_scan reads the 15-channel prior (base.py:388-394 needs 15 numbers per ROI voxel out of a
+    ~0.8 GB volume)."""
+    hdr, pieces = _voxel_pieces(path)
+    v = np.asarray(voxels, dtype=np.int64).reshape(-1, 3)
+    shape = hdr.shape
+    if len(shape) not in (3, 4):
+        raise ValueError('%s: load_rows needs a 3-D or 4-D volume, found shape %r' % (path, shape))
+    if v.size and ((v < 0).any() or (v >= np.asarray(shape[:3])).any()):
+        raise ValueError('voxel outside the volume')
+    nvox, nt = shape[0] * shape[1] * shape[2], (shape[3] if len(shape) == 4 else 1)
+    lin = v[:, 0] + shape[0] * (v[:, 1] + shape[1] * v[:, 2])
+    order = np.argsort(lin, kind='stable')
+    lin_sorted = lin[order]
+    # element positions wanted, ascending: channel-major (Fortran order: the last axis is the slowest)
+    pos = (np.arange(nt, dtype=np.int64)[:, None] * nvox + lin_sorted[None, :]).ravel()
+    out = np.empty(pos.size, dtype=hdr.dtype)
+    item = hdr.dtype.itemsize
+    done, carry, carry_lo = 0, b'', 0
+    for lo, piece in pieces:
+        if done >= pos.size:
+            break
+        if carry:                                       # an element straddling two pieces
+            piece, lo = carry + piece, carry_lo
+        e0 = -(-lo // item)                             # first whole element in this piece
+        skip = e0 * item - lo
+        ne = (len(piece) - skip) // item
+        tail = skip + ne * item
+        carry, carry_lo = piece[tail:], lo + tail
+        if ne <= 0:
+            continue
+        hi = np.searchsorted(pos, e0 + ne, side='left')
+        if hi > done:
+            arr = np.frombuffer(piece, dtype=hdr.dtype, count=ne, offset=skip)
+            out[done:hi] = arr[pos[done:hi] - e0]
+            done = hi
+    if done < pos.size:
+        raise IOError('%s: voxel data truncated' % path)
+    rows = np.empty((v.shape[0], nt), dtype=out.dtype)
+    rows[order] = out.reshape(nt, -1).T
+    rows = hdr.finish(rows)
+    return rows if len(shape) == 4 else rows[:, 0]
+
+
+def _header_bytes(data_shape, dtype, like, affine):
+    code = _CODES.get(np.dtype(dtype).str[1:])
     if code is None:
-        raise ValueError('cannot store dtype %s in NIfTI-1' % data.dtype)
+        raise ValueError('cannot store dtype %s in NIfTI-1' % dtype)
+    if len(data_shape) > 7:
+        raise ValueError('NIfTI-1 stores at most 7 dimensions')
     hdr = bytearray(348)
     if like is not None and like.header_bytes is not None and like.endian == '<':
         hdr[:] = like.header_bytes
@@ -100,13 +274,107 @@ def save(data, path, like=None, affine=None):
         struct.pack_into('<8f', hdr, 76, 1.0, vox[0], vox[1], vox[2], 1.0, 1.0, 1.0, 1.0)
         hdr[123] = 10                                                         # xyzt_units: mm + s
     struct.pack_into('<i', hdr, 0, 348)
-    dims = [data.ndim] + list(data.shape) + [1] * (7 - data.ndim)
+    dims = [len(data_shape)] + list(data_shape) + [1] * (7 - len(data_shape))
     struct.pack_into('<8h', hdr, 40, *dims)
     struct.pack_into('<h', hdr, 70, code)
-    struct.pack_into('<h', hdr, 72, data.dtype.itemsize * 8)
+    struct.pack_into('<h', hdr, 72, np.dtype(dtype).itemsize * 8)
     struct.pack_into('<f', hdr, 108, 352.0)
     struct.pack_into('<2f', hdr, 112, 1.0, 0.0)                               # scl_slope, scl_inter
     hdr[344:348] = b'n+1\x00'
-    payload = bytes(hdr) + b'\x00\x00\x00\x00' + np.asfortranarray(data).astype(data.dtype.newbyteorder('<')).tobytes(order='F')
-    with _open(path, 'wb') as f:
-        f.write(payload)
+    return bytes(hdr) + b'\x00\x00\x00\x00'
+
+
+def _gzip_member(chunk):
+    c = zlib.compressobj(GZIP_LEVEL, zlib.DEFLATED, 31)
+    return c.compress(chunk) + c.flush()
+
+
+def _write_gzip(path, buffers):
+    """Write the concatenation of `buffers` (bytes-like, C-contiguous) as parallel-deflated gzip members."""
+    chunks = []
+    for b in buffers:
+        mv = memoryview(b).cast('B')
+        chunks.extend(mv[o:o + _MEMBER_BYTES] for o in range(0, len(mv), _MEMBER_BYTES))
+    with open(path, 'wb') as f, ThreadPoolExecutor(_workers()) as pool:
+        for member in pool.map(_gzip_member, chunks):   # zlib releases the GIL; map keeps the order
+            f.write(member)
+
+
+def save_sparse(path, shape, dtype, voxels, values, like=None, affine=None):
+    """Write a volume that is zero except at `voxels` (int [N,3]) where it holds `values` ([N] for a 3-D shape,
+    [N,T] for a 4-D one), without building the dense array: the voxel block is produced member by member (dense
+    scratch per worker), and all-zero members are deflated once and reused.  The file is byte-for-byte what
+    save() writes for the equivalent dense array.  Later duplicates of a voxel win, as in a fancy assignment.
+
+    test_scan uses it for the float64 [X,Y,Z,15] probability volume (1.5 GB dense, ~99 % zeros)."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(d) for d in shape)
+    if len(shape) not in (3, 4):
+        raise ValueError('save_sparse writes 3-D or 4-D volumes')
+    v = np.asarray(voxels, dtype=np.int64).reshape(-1, 3)
+    if v.size and ((v < 0).any() or (v >= np.asarray(shape[:3])).any()):
+        raise ValueError('voxel outside the volume')
+    nvox, nt = shape[0] * shape[1] * shape[2], (shape[3] if len(shape) == 4 else 1)
+    vals = np.asarray(values).reshape(v.shape[0], nt)
+    lin = v[:, 0] + shape[0] * (v[:, 1] + shape[1] * v[:, 2])
+    order = np.argsort(lin, kind='stable')
+    pos = (np.arange(nt, dtype=np.int64)[:, None] * nvox + lin[order][None, :]).ravel()
+    flat_vals = np.ascontiguousarray(vals[order].T, dtype=dtype.newbyteorder('<')).ravel()
+    head = _header_bytes(shape, dtype, like, affine)
+    per = max(1, _MEMBER_BYTES // dtype.itemsize)       # elements per member
+    total = nvox * nt
+    bounds = np.searchsorted(pos, np.arange(0, total + per, per))
+    zero_member = {}
+    scratch = threading.local()
+
+    def member(k):
+        e0, e1 = k * per, min(total, (k + 1) * per)
+        lo, hi = bounds[k], bounds[k + 1]
+        if lo == hi:
+            key = e1 - e0
+            if key not in zero_member:
+                zero_member[key] = _gzip_member(bytes(key * dtype.itemsize))
+            return zero_member[key]
+        buf = getattr(scratch, 'buf', None)
+        if buf is None:
+            buf = scratch.buf = np.zeros(per, dtype=dtype.newbyteorder('<'))
+        idx = pos[lo:hi] - e0
+        buf[idx] = flat_vals[lo:hi]
+        out = _gzip_member(memoryview(buf[:e1 - e0]).cast('B'))
+        buf[idx] = 0                                    # leave the scratch clean for its next member
+        return out
+
+    nmem = (total + per - 1) // per
+    if str(path).endswith('.gz'):
+        with open(path, 'wb') as f, ThreadPoolExecutor(_workers()) as pool:
+            f.write(_gzip_member(head))
+            for m in pool.map(member, range(nmem)):
+                f.write(m)
+    else:
+        with open(path, 'wb') as f:
+            f.write(head)
+            buf = np.zeros(per, dtype=dtype.newbyteorder('<'))
+            for k in range(nmem):
+                e0, e1 = k * per, min(total, (k + 1) * per)
+                lo, hi = bounds[k], bounds[k + 1]
+                idx = pos[lo:hi] - e0
+                buf[idx] = flat_vals[lo:hi]
+                f.write(memoryview(buf[:e1 - e0]).cast('B'))
+                buf[idx] = 0
+
+
+def save(data, path, like=None, affine=None):
+    """Write `data` (<= 7-D) as NIfTI-1.  Geometry is copied from `like` (a NiftiImage) when given, else built
+    from `affine` (default identity)."""
+    data = np.asarray(data)
+    if data.dtype == np.bool_:
+        data = data.astype(np.uint8)
+    head = _header_bytes(data.shape, data.dtype, like, affine)
+    # voxel bytes in Fortran order = the C-order bytes of the transposed array (no copy when data is F-contiguous)
+    vox = np.ascontiguousarray(data.T, dtype=data.dtype.newbyteorder('<'))
+    if str(path).endswith('.gz'):
+        _write_gzip(path, [head, vox])
+    else:
+        with open(path, 'wb') as f:
+            f.write(head)
+            f.write(memoryview(vox).cast('B'))

@@ -1,6 +1,6 @@
 // im2col-free 3x3 "valid" convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), gfx950.
 //
-// One workgroup (4 waves) owns G whole patches.  Their input planes sit in LDS ([g][cin][PLANE]); the
+// One workgroup (NW waves, 4 unless stated) owns G whole patches.  Their input planes sit in LDS ([g][cin][PLANE]); the
 // GEMM view is  out[pixel][cout] = sum_k in[pixel @ (cin,tap)] * W[(cin,tap)][cout]  with
 //   M = G * output pixels (16 per MFMA tile), N = Cout padded to 16s, K = Cin*9 walked as
 //   (cin-group of 4) x (9 taps) so that one k-step = 4 consecutive input channels at one tap:
@@ -27,9 +27,10 @@ static_assert(kW1Floats > 256 && kW1Floats <= 512, "conv1 operand staging assume
 enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2 };
 enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3 };
 
-template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0>
+template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4>
 struct ConvCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_;
+    static constexpr int NW = NW_, NTH = 64 * NW_;          // waves / threads per workgroup
     // SRC_NCHW_PAD2: the global input is (HIN_-4)^2 and is zero-padded by 2 on every side in LDS (dgrad)
     static constexpr int HIN = HIN_, WIN = HIN_;
     static constexpr int HSRC = (SRC_ == SRC_NCHW_PAD2) ? HIN_ - 4 : HIN_;
@@ -51,11 +52,11 @@ struct ConvCfg {
     static constexpr int NC4 = CIN_ / 4;
     static constexpr int MTOT = G_ * PIXB;
     static constexpr int TILES = (MTOT + 15) / 16;
-    static constexpr int TPW = (TILES + 3) / 4;         // tiles per wave (wave w owns tiles w, w+4, ...)
-    static constexpr bool LAST_RAGGED = (3 + 4 * (TPW - 1)) >= TILES;   // some waves lack their last tile
+    static constexpr int TPW = (TILES + NW - 1) / NW;   // tiles per wave (wave w owns tiles w, w+NW, ...)
+    static constexpr bool LAST_RAGGED = (NW - 1 + NW * (TPW - 1)) >= TILES;   // some waves lack their last tile
     static constexpr int WCHUNK = conv_chunk_floats(COUT_);   // floats per weight chunk
     static constexpr int WCHUNK4 = WCHUNK / 4;
-    static constexpr int WPT = (WCHUNK4 + 255) / 256;   // float4 per thread per chunk
+    static constexpr int WPT = (WCHUNK4 + NTH - 1) / NTH;   // float4 per thread per chunk
     static constexpr int IN_FLOATS = G_ * CIN_ * PLANE_;
     static constexpr int IN_FLOATS_AL = (IN_FLOATS + 3) / 4 * 4;
     static constexpr int XS_ROWS_FLOATS = (XROWS * 32 + 3) / 4 * 4;
@@ -71,7 +72,8 @@ struct ConvCfg {
     static_assert(HO % NB_ == 0 && (!POOL || (HOB % 2 == 0)), "bands must split the output rows (evenly for pooling)");
     static_assert(NB_ == 1 || G_ == 1, "bands: one patch per workgroup");
     static_assert(PLANE_ >= HINB * HIN_, "plane stride too small");
-    static_assert(LDS_BYTES * WPS_ <= 160 * 1024, "LDS budget (WPS workgroups of 4 waves per CU)");
+    static_assert(LDS_BYTES * WPS_ <= 160 * 1024, "LDS budget (WPS workgroups per CU)");
+    static_assert(NW_ == 4 || (SRC_ != SRC_CONV1 && SRC_ != SRC_VOLUME), "the fused conv1 stage is written for 4 waves");
 };
 
 struct ConvArgs {
@@ -178,25 +180,25 @@ __device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, cons
 
 // batched copy helper: K independent loads in flight per thread before the LDS writes (a plain strided loop
 // serialises one global-load latency per iteration)
-template <int TOTAL, class V, class SrcF, class DstF>
+template <int TOTAL, class V, int NTH = 256, class SrcF, class DstF>
 __device__ __forceinline__ void staged_copy(int tid, SrcF&& src_of, DstF&& dst_of) {
-    constexpr int ITER = (TOTAL + 255) / 256, K = 8;
+    constexpr int ITER = (TOTAL + NTH - 1) / NTH, K = 8;
 #pragma unroll
     for (int i0 = 0; i0 < ITER; i0 += K) {
         V v[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (i0 + k < ITER) { const int e = min(tid + 256 * (i0 + k), TOTAL - 1); v[k] = src_of(e); }
+            if (i0 + k < ITER) { const int e = min(tid + NTH * (i0 + k), TOTAL - 1); v[k] = src_of(e); }
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (i0 + k < ITER) { const int e = tid + 256 * (i0 + k); if (e < TOTAL) dst_of(e, v[k]); }
+            if (i0 + k < ITER) { const int e = tid + NTH * (i0 + k); if (e < TOTAL) dst_of(e, v[k]); }
         }
     }
 }
 
 template <class C>
-__global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + C::IN_FLOATS_AL;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     // ---- weight chunk 0 -> registers (lands in LDS after the input staging)
     // (named registers, clamped indices: an indexed array here ends up in scratch behind a vmcnt(0))
     static_assert(C::WPT <= 3, "weight chunk prefetch holds at most 3 float4 per thread");
-    const int wi0 = min(tid, C::WCHUNK4 - 1), wi1 = min(tid + 256, C::WCHUNK4 - 1), wi2 = min(tid + 512, C::WCHUNK4 - 1);
+    const int wi0 = min(tid, C::WCHUNK4 - 1), wi1 = min(tid + C::NTH, C::WCHUNK4 - 1), wi2 = min(tid + 2 * C::NTH, C::WCHUNK4 - 1);
     float4 wr0, wr1, wr2;
     wr0 = reinterpret_cast<const float4*>(wsrc)[wi0];
     if constexpr (C::WPT > 1) wr1 = reinterpret_cast<const float4*>(wsrc)[wi1];
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
             constexpr int BW4 = BW / 4;
             const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
             float4* dst4 = reinterpret_cast<float4*>(s_in);
-            staged_copy<C::G * C::CIN * BW4, float4>(
+            staged_copy<C::G * C::CIN * BW4, float4, C::NTH>(
                 tid,
                 [&](int e) { const int pl = e / BW4, r = e - pl * BW4;
                              return (pl < planes) ? src4[(size_t)pl * (HW / 4) + r] : float4{0.f, 0.f, 0.f, 0.f}; },
@@ -260,11 +262,11 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
             const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
             float4* dst4 = reinterpret_cast<float4*>(s_in);
             const int tot4 = planes * HW / 4;      // ng*CIN*HW is a multiple of 4 whenever CIN*HW is
-            staged_copy<C::G * C::CIN * HW / 4, float4>(
+            staged_copy<C::G * C::CIN * HW / 4, float4, C::NTH>(
                 tid, [&](int e) { return (e < tot4) ? src4[e] : float4{0.f, 0.f, 0.f, 0.f}; },
                 [&](int e, float4 v) { dst4[e] = v; });
         } else {
-            staged_copy<C::G * C::CIN * BW, float>(
+            staged_copy<C::G * C::CIN * BW, float, C::NTH>(
                 tid,
                 [&](int e) { const int pl = e / BW, r = e - pl * BW; return (pl < planes) ? src[(size_t)pl * HW + r] : 0.f; },
                 [&](int e, float v) { const int pl = e / BW, r = e - pl * BW; s_in[pl * C::PLANE + r] = v; });
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         constexpr int HS = C::HSRC, HW = HS * HS, BW = C::HINB * C::WIN;
         const float* __restrict__ src = insrc + (size_t)g0 * C::CIN * HW;
         const int planes = ng * C::CIN;
-        staged_copy<C::G * C::CIN * BW, float>(
+        staged_copy<C::G * C::CIN * BW, float, C::NTH>(
             tid,
             [&](int e) {
                 const int pl = e / BW, r = e - pl * BW, yl = r / C::WIN, xp = r - yl * C::WIN;
@@ -323,15 +325,15 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     {
         float4* dst = reinterpret_cast<float4*>(s_w);
         if (tid < C::WCHUNK4) dst[tid] = wr0;
-        if constexpr (C::WPT > 1) { if (tid + 256 < C::WCHUNK4) dst[tid + 256] = wr1; }
-        if constexpr (C::WPT > 2) { if (tid + 512 < C::WCHUNK4) dst[tid + 512] = wr2; }
+        if constexpr (C::WPT > 1) { if (tid + C::NTH < C::WCHUNK4) dst[tid + C::NTH] = wr1; }
+        if constexpr (C::WPT > 2) { if (tid + 2 * C::NTH < C::WCHUNK4) dst[tid + 2 * C::NTH] = wr2; }
     }
 
     // ---- per-lane A base offsets (floats) for the wave's tiles; out-of-range tiles are clamped, never stored
     int abase[C::TPW];
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
-        int m = (wave + 4 * j) * 16 + lr;
+        int m = (wave + C::NW * j) * 16 + lr;
         int g, y, x;
         if constexpr (C::POOL) {
             int widx = min(m >> 2, C::G * C::WB - 1);
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
 
     const int boff = kq * C::NS16 + lr;                       // main part: W[k = 4s + kq][cout = 16 nt + lr]
     const int loff = 36 * C::NS16 + kq * C::L4 + (lane & 3);   // leftover: W[k = 4s + kq][cout = 16 NT16 + 4u + (lane&3)]
-    const bool last_ok = (wave + 4 * (C::TPW - 1)) < C::TILES;
+    const bool last_ok = (wave + C::NW * (C::TPW - 1)) < C::TILES;
     for (int c4 = 0; c4 < C::NC4; ++c4) {
         if (c4 + 1 < C::NC4) {
             const float4* __restrict__ src = reinterpret_cast<const float4*>(wsrc + (size_t)(c4 + 1) * C::WCHUNK);
@@ -411,8 +413,8 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         if (c4 + 1 < C::NC4) {
             float4* dst = reinterpret_cast<float4*>(s_w + ((c4 + 1) & 1) * C::WCHUNK);
             if (tid < C::WCHUNK4) dst[tid] = wr0;
-            if constexpr (C::WPT > 1) { if (tid + 256 < C::WCHUNK4) dst[tid + 256] = wr1; }
-            if constexpr (C::WPT > 2) { if (tid + 512 < C::WCHUNK4) dst[tid + 512] = wr2; }
+            if constexpr (C::WPT > 1) { if (tid + C::NTH < C::WCHUNK4) dst[tid + C::NTH] = wr1; }
+            if constexpr (C::WPT > 2) { if (tid + 2 * C::NTH < C::WCHUNK4) dst[tid + 2 * C::NTH] = wr2; }
         }
         __syncthreads();
     }
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     float* s_o = smem;
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
-        const int t = wave + 4 * j;
+        const int t = wave + C::NW * j;
         if (t >= C::TILES) continue;
 #pragma unroll
         for (int nt = 0; nt < C::NT16; ++nt) {
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
         }
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
-        const int t = wave + 4 * j;
+        const int t = wave + C::NW * j;
         if (t >= C::TILES) continue;
 #if defined(SCS_ABLATE) && SCS_ABLATE == 4
         if (t >= 0) { s_o[lane] = lval[j][0]; continue; }
@@ -504,14 +506,14 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
     {
         float* __restrict__ outp = pick3(a.out, tower) + (size_t)g0 * C::COUT * C::OUTPIX + band * C::OUTB;
         if constexpr (C::OUT_VEC4) {
-            constexpr int O4 = C::OUTB / 4, ITER = (C::G * C::COUT * O4 + 255) / 256;
+            constexpr int O4 = C::OUTB / 4, ITER = (C::G * C::COUT * O4 + C::NTH - 1) / C::NTH;
             const int total = ng * C::COUT * O4;
 #if defined(SCS_ABLATE) && SCS_ABLATE == 5
             if (tid < 0)
 #endif
 #pragma unroll 4
             for (int it = 0; it < ITER; ++it) {
-                const int e = tid + 256 * it;
+                const int e = tid + C::NTH * it;
                 if (e < total) {
                     const int gc = e / O4, r = e - gc * O4;
                     *reinterpret_cast<float4*>(outp + (size_t)gc * C::OUTPIX + 4 * r) =
@@ -520,13 +522,13 @@ __global__ __launch_bounds__(256, C::WPS) void conv3x3_mfma_kernel(ConvArgs a) {
             }
         } else {
             const int total = ng * C::COUT * C::OUTB;
-            constexpr int ITER = (C::G * C::COUT * C::OUTB + 255) / 256;
+            constexpr int ITER = (C::G * C::COUT * C::OUTB + C::NTH - 1) / C::NTH;
 #if defined(SCS_ABLATE) && SCS_ABLATE == 5
             if (tid < 0)
 #endif
 #pragma unroll 2
             for (int it = 0; it < ITER; ++it) {
-                const int e = tid + 256 * it;
+                const int e = tid + C::NTH * it;
                 if (e < total) {
                     const int gc = e / C::OUTB, r = e - gc * C::OUTB;
                     outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
@@ -547,7 +549,7 @@ template <class C>
 inline void conv_launch(const ConvArgs& a, hipStream_t st) {
     if (a.n <= 0) return;
     dim3 grid(((a.n + C::G - 1) / C::G) * C::NB, kTowers);
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<C>, grid, dim3(C::NTH), C::LDS_BYTES, st, a);
 }
 
 }  // namespace scs

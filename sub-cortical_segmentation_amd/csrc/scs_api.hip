@@ -300,7 +300,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     g.K4 = kFC1; g.N = kFC1;
     g.p[0] = GemmProblem{h->a_feat, kFlat, pk.fc1w, gemm_ns(kFC1), pk.fc1b, h->a_fc1, kFC1ld};
     gemm_launch(g, 1, st);
-    if (vol)
+    if (vol && atlas4d)
         hipLaunchKernelGGL(atlas_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->a_fc1, n);
     else
         hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, h->a_fc1, n);
@@ -457,6 +457,13 @@ int scs_forward_volume(scs_handle h, const float* vol, int dx, int dy, int dz, c
     SCS_ARG(n == 0 || (vol && centers && atlas4d), "null input pointer");
     SCS_ARG(dx > 0 && dy > 0 && dz > 0, "volume dims must be positive");
     return forward_common(h, nullptr, nullptr, nullptr, nullptr, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, stream);
+}
+
+int scs_forward_volume_rows(scs_handle h, const float* vol, int dx, int dy, int dz, const int32_t* centers,
+                            const float* atlas_rows, int64_t n, float* probs, int32_t* labels, void* stream) {
+    SCS_ARG(n == 0 || (vol && centers && atlas_rows), "null input pointer");
+    SCS_ARG(dx > 0 && dy > 0 && dz > 0, "volume dims must be positive");
+    return forward_common(h, nullptr, nullptr, nullptr, atlas_rows, vol, dx, dy, dz, centers, nullptr, n, probs, labels, stream);
 }
 
 int scs_forward_host(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, int64_t n,

@@ -104,6 +104,71 @@ def test_nifti_roundtrip_and_scaling(tmp_path):
         nifti.load(str(tmp_path / 'bad.nii'))
 
 
+@pytest.mark.parametrize('dt', [np.float32, np.float64, np.int16, np.uint8])
+@pytest.mark.parametrize('shape', [(17, 13, 11), (17, 13, 11, 5)])
+def test_nifti_streaming_rows_and_sparse(tmp_path, monkeypatch, dt, shape):
+    """load_rows == load()[x,y,z] and save_sparse == save(dense), across piece / member boundaries (the stream
+    sizes are shrunk so that a small file spans many of them and elements straddle the pieces)."""
+    import gzip
+    monkeypatch.setattr(nifti, '_MEMBER_BYTES', 1 << 12)
+    monkeypatch.setattr(nifti, '_STREAM_BYTES', 4999)
+    monkeypatch.setattr(nifti, '_FEED_BYTES', 777)
+    rng = np.random.default_rng(5)
+    a = (rng.random(shape) * 100).astype(dt)
+    vox = np.stack([rng.integers(0, shape[i], 200) for i in range(3)], 1)
+    vals = (rng.random((200,) + shape[3:]) * 50 + 1).astype(dt)
+    dense = np.zeros(shape, dt)
+    dense[vox[:, 0], vox[:, 1], vox[:, 2]] = vals                     # later duplicates win
+    for ext in ('.nii.gz', '.nii'):
+        fn = str(tmp_path / ('a' + ext))
+        nifti.save(a, fn)
+        b = nifti.load(fn).get_data()
+        assert b.dtype == a.dtype and np.array_equal(a, b) and b.flags.writeable
+        r = nifti.load_rows(fn, vox)
+        assert r.dtype == a.dtype and np.array_equal(r, a[vox[:, 0], vox[:, 1], vox[:, 2]])
+        nifti.save(dense, str(tmp_path / ('dense' + ext)))
+        nifti.save_sparse(str(tmp_path / ('sparse' + ext)), shape, dt, vox, vals)
+        opener = gzip.open if ext.endswith('.gz') else open
+        with opener(str(tmp_path / ('dense' + ext)), 'rb') as f1, opener(str(tmp_path / ('sparse' + ext)), 'rb') as f2:
+            assert f1.read() == f2.read()
+    # a single-member stream as an external tool writes it, and a truncated one
+    with gzip.open(str(tmp_path / 'a.nii.gz'), 'rb') as f:
+        raw = f.read()
+    with gzip.open(str(tmp_path / 'single.nii.gz'), 'wb') as f:
+        f.write(raw)
+    assert np.array_equal(nifti.load(str(tmp_path / 'single.nii.gz')).get_data(), a)
+    assert np.array_equal(nifti.load_rows(str(tmp_path / 'single.nii.gz'), vox[:7]), a[vox[:7, 0], vox[:7, 1], vox[:7, 2]])
+    blob = (tmp_path / 'single.nii.gz').read_bytes()
+    (tmp_path / 'trunc.nii.gz').write_bytes(blob[:len(blob) // 2])
+    with pytest.raises(IOError):
+        nifti.load(str(tmp_path / 'trunc.nii.gz'))
+    with pytest.raises(ValueError):
+        nifti.load_rows(str(tmp_path / 'a.nii'), [[shape[0], 0, 0]])
+
+
+def test_nifti_big_endian_and_scaled(tmp_path):
+    """Files from other tools: big-endian voxels and scl_slope/inter (get_data() scales to float64)."""
+    import struct
+    a = (np.random.RandomState(9).rand(6, 5, 4) * 200).astype(np.int16)
+    nifti.save(a, str(tmp_path / 'le.nii'))
+    raw = bytearray((tmp_path / 'le.nii').read_bytes())
+    struct.pack_into('<2f', raw, 112, 0.5, -3.0)
+    (tmp_path / 'scaled.nii').write_bytes(bytes(raw))
+    assert np.array_equal(nifti.load(str(tmp_path / 'scaled.nii')).get_data(), a.astype(np.float64) * 0.5 - 3.0)
+    vox = np.array([[0, 0, 0], [5, 4, 3], [2, 3, 1]])
+    assert np.array_equal(nifti.load_rows(str(tmp_path / 'scaled.nii'), vox), a[vox[:, 0], vox[:, 1], vox[:, 2]] * 0.5 - 3.0)
+    # byte-swap the header fields this reader uses and the voxel block
+    be = bytearray(raw)
+    be[0:4] = struct.pack('>i', 348)
+    be[40:56] = struct.pack('>8h', *struct.unpack('<8h', raw[40:56]))
+    be[70:72] = struct.pack('>h', *struct.unpack('<h', raw[70:72]))
+    be[108:120] = struct.pack('>3f', *struct.unpack('<3f', raw[108:120]))
+    be[352:] = a.T.astype('>i2').tobytes()
+    (tmp_path / 'be.nii').write_bytes(bytes(be))
+    got = nifti.load(str(tmp_path / 'be.nii')).get_data()
+    assert np.array_equal(got, a.astype(np.float64) * 0.5 - 3.0)
+
+
 def make_subject(folder, shape=(40, 40, 40), seed=0, with_labels=False):
     os.makedirs(os.path.join(folder, 'tmp'), exist_ok=True)
     vol = synth.smooth_volume(shape, sigma=3.0, seed=seed, as_int=True)

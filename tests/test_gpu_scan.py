@@ -84,3 +84,23 @@ def test_predict_api_accepts_numpy_and_device_tensors(weights):
         net.predict({'in1': g['ax'][:, :, :16], 'in2': g['co'], 'in3': g['sa'], 'in4': g['atlas']})
     with pytest.raises(IOError):
         build_model(str(os.path.join(PKG, 'csrc')), options('/nonexistent'))      # no weights there: loud failure
+
+
+def test_volume_rows_equals_volume_4d(weights):
+    """scs_forward_volume_rows (host-gathered prior rows) and scs_forward_volume (device gather from the 4-D prior)
+    are the same computation: identical labels and bit-identical probabilities, incl. zero-prior rows."""
+    from cnn_cort import synth
+    shape = (40, 36, 32)
+    vol = base._zscore(synth.smooth_volume(shape, sigma=3.0, seed=21, as_int=True), False).astype(np.float32)
+    atlas = synth.toy_atlas(shape, seed=22).astype(np.float32)
+    atlas[:6] = 0                                                   # a slab without any prior -> background rule
+    rng = np.random.RandomState(23)
+    centers = np.stack([rng.randint(0, s, 700) for s in shape], axis=1)
+    net = build_model(os.path.join(PKG, 'nets'), options('/nonexistent'))
+    la, pa = net.predict_volume(vol, centers, atlas4d=atlas, want_probs=True, batch=256)
+    lb, pb = net.predict_volume(vol, centers, atlas_rows=base.atlas_vectors_at(atlas, centers), want_probs=True, batch=300)
+    assert np.array_equal(la, lb) and np.array_equal(pa, pb)
+    with pytest.raises(ValueError):
+        net.predict_volume(vol, centers, want_probs=True)
+    with pytest.raises(ValueError):
+        net.predict_volume(vol, centers, atlas_rows=np.zeros((3, 15), np.float32))

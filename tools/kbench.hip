@@ -116,6 +116,13 @@ int main(int argc, char** argv) {
         run<ConvCfg<40, 40, 12, 4, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 1>>("conv4 G4 WPS1", n, rounds, c4);
         run<ConvCfg<40, 40, 12, 2, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 2>>("conv4 G2 WPS2", n, rounds, c4);
         run<ConvCfg<40, 40, 12, 1, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 4>>("conv4 G1 WPS4", n, rounds, c4);
+        run<ConvCfg<20, 40, 14, 4, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 1, 0, 12>>("conv3 G4 NW12", n, rounds, c3);
+        run<ConvCfg<20, 40, 14, 2, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 2, 0, 6>>("conv3 G2 NW6 WPS2", n, rounds, c3);
+        run<ConvCfg<20, 40, 14, 4, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 1, 0, 16>>("conv3 G4 NW16", n, rounds, c3);
+        run<ConvCfg<40, 40, 12, 4, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 1, 0, 16>>("conv4 G4 NW16", n, rounds, c4);
+        run<ConvCfg<40, 40, 12, 4, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 1, 0, 13>>("conv4 G4 NW13", n, rounds, c4);
+        run<ConvCfg<40, 40, 12, 2, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 2, 0, 7>>("conv4 G2 NW7 WPS2", n, rounds, c4);
+        run<ConvCfg<40, 40, 12, 2, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 2, 0, 8>>("conv4 G2 NW8 WPS2", n, rounds, c4);
         run<ConvCfg<40, 60, 5, 16, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 1>>("conv5 G16 WPS1", n, rounds, c5);
         run<ConvCfg<40, 60, 5, 8, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 2>>("conv5 G8 WPS2", n, rounds, c5);
         printf("\n");

@@ -10,6 +10,8 @@
 // BN statistics/gradients are per-channel reductions with double accumulators; weight gradients and the
 // dense-layer backward GEMMs are plain LDS-tiled vector-ALU kernels in this round.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -34,13 +36,13 @@ using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 544, 2, 3>;
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 constexpr bool kPool[kConvs] = {false, true, false, true, false};
 constexpr int kRedSplit = 16;     // batch slices per channel in the two-stage BN reductions
-constexpr int kWgSplit = 4;       // batch slices in the vector-ALU weight-gradient kernel (conv1, conv5)
-constexpr int kWgSlicesMax = 64;  // batch slices of the MFMA weight-gradient kernel (conv2..4)
-using WG2 = WgCfg<20, 20, 30>;
-using WG3 = WgCfg<20, 40, 14>;
-using WG4 = WgCfg<40, 40, 12>;
-using WG1 = WgCfg<1, 20, 32>;
-using WG5 = WgCfg<40, 60, 5>;
+// <CIN, COUT, HIN, row bands, workgroups per CU>
+using WG2 = WgCfg<20, 20, 30, 4, 3>;
+using WG3 = WgCfg<20, 40, 14, 2, 3>;
+using WG4 = WgCfg<40, 40, 12, 1, 3>;
+using WG1 = WgCfg<1, 20, 32, 3, 4>;
+using WG5 = WgCfg<40, 60, 5, 1, 2>;
+constexpr size_t kWgPartFloats = (size_t)256 * 60 * 40 * 9;   // per tower: room for 256 partials of the largest layer
 
 }  // namespace scs
 
@@ -65,7 +67,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* actT = nullptr;                     // transposed activations for the dense weight-gradient GEMMs [3][556][cap]
     float* wT = nullptr;                       // transposed dense weights for the dense data-gradient GEMMs
     double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN reductions
-    float* wg_part = nullptr;                  // [3][kWgSplit][60*40*9] partial weight gradients
+    float* wg_part = nullptr;                  // [3][kWgPartFloats] partial weight gradients
 };
 
 namespace scs {
@@ -103,7 +105,7 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
         SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540) * sizeof(float)));
         SCS_HIP(hipMalloc(&w->red_part, (size_t)kTowers * 64 * kRedSplit * 2 * sizeof(double)));
-        SCS_HIP(hipMalloc(&w->wg_part, (size_t)kTowers * kWgSlicesMax * 60 * 40 * 9 * sizeof(float)));
+        SCS_HIP(hipMalloc(&w->wg_part, (size_t)kTowers * kWgPartFloats * sizeof(float)));
     }
     if (n <= w->cap) return SCS_OK;
     if (w->base) { SCS_HIP(hipFree(w->base)); w->base = nullptr; }
@@ -557,59 +559,51 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, 
     }
 }
 
-// weight gradient of a true convolution: dW[o][c][2-dy][2-dx] = sum_{n,y,x} dz[n][o][y][x] * X[n][c][y+dy][x+dx].
-// One workgroup per (c, group of 4 output channels, tower x batch slice): the 9 taps of X are loaded once per pixel and
-// feed 36 FMAs; the (n, pixel) sum is spread over the threads; slices are summed in a fixed order by wgrad_final_kernel.
-__global__ __launch_bounds__(256) void wgrad_partial_kernel(CPtr3 X, CPtr3 dZ, int n, int Cin, int Cout, int HIN, float* part) {
-    __shared__ float s_red[4][36];
-    const int c = blockIdx.x, og = blockIdx.y, t = blockIdx.z / kWgSplit, sp = blockIdx.z % kWgSplit;
-    const float* __restrict__ x = sel3(X.p, t);
-    const float* __restrict__ dz = sel3(dZ.p, t);
-    const int HO = HIN - 2, pix = HO * HO;
-    const int per = (n + kWgSplit - 1) / kWgSplit, n0 = sp * per, n1 = min(n, n0 + per);
-    float acc[4][9] = {};
-    const long total = (long)max(0, n1 - n0) * pix;
-    for (long e = threadIdx.x; e < total; e += blockDim.x) {
-        const long ni = n0 + e / pix; const int p = (int)(e % pix), y = p / HO, xx = p - y * HO;
-        const float* xb = x + ((ni * Cin + c) * HIN + y) * HIN + xx;
-        float xv[9];
+// sum of the partial weight gradients in a fixed order (deterministic): 64 elements x 4 groups of partials per block,
+// 8 independent loads in flight per thread
+__global__ __launch_bounds__(256) void wgrad_final_kernel(const float* part, int nsplit, int Cin, int Cout, float* grads, int w_off0,
+                                                          int tower_stride) {
+    __shared__ float s_red[4][64];
+    const int t = blockIdx.y, tot = Cout * Cin * 9;
+    const int ex = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + ex;
+    const int per = (nsplit + 3) / 4, sp0 = grp * per, sp1 = min(nsplit, sp0 + per);
+    float v = 0.f;
+    if (e < tot) {
+        const float* __restrict__ base = part + (size_t)t * nsplit * tot + e;
+        int sp = sp0;
+        for (; sp + 8 <= sp1; sp += 8) {
+            float r[8];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) xv[k] = xb[(k / 3) * HIN + k % 3];
-        const float* dp = dz + (ni * Cout + og * 4) * pix + p;
+            for (int u = 0; u < 8; ++u) r[u] = base[(size_t)(sp + u) * tot];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float d = dp[(long)j * pix];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[j][k] = fmaf(d, xv[k], acc[j][k]);
+            for (int u = 0; u < 8; ++u) v += r[u];
         }
+        for (; sp < sp1; ++sp) v += base[(size_t)sp * tot];
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            float v = acc[j][k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if (lane == 0) s_red[wv][j * 9 + k] = v;
-        }
+    s_red[grp][ex] = v;
     __syncthreads();
-    if (threadIdx.x < 36) {
-        const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-        // part[t][sp][o][c][9]
-        const int j = threadIdx.x / 9, k = threadIdx.x % 9;
-        part[((((size_t)t * kWgSplit + sp) * Cout + og * 4 + j) * Cin + c) * 9 + k] = v;
+    if (grp == 0 && e < tot) {
+        v = (s_red[0][ex] + s_red[1][ex]) + (s_red[2][ex] + s_red[3][ex]);
+        const int o = e % Cout, j = e / Cout, c = j / 9, k = j - c * 9;        // partials are [c*9 + tap][o]
+        grads[w_off0 + t * tower_stride + (o * Cin + c) * 9 + (2 - k / 3) * 3 + (2 - k % 3)] = v;   // flip back to Lasagne's W
     }
 }
 
-__global__ void wgrad_final_kernel(const float* part, int nsplit, int Cin, int Cout, float* grads, int w_off0, int tower_stride) {
-    const int t = blockIdx.y, tot = Cout * Cin * 9;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) v += part[((size_t)t * nsplit + sp) * tot + e];
-        const int k = e % 9, oc = e / 9;
-        grads[w_off0 + t * tower_stride + oc * 9 + (2 - k / 3) * 3 + (2 - k % 3)] = v;     // flip back to Lasagne's W
+// batch slices of the weight-gradient kernels per conv layer (workgroups = slices x bands x 3 towers; partials to sum =
+// slices x bands x parts).  SCS_WG_SLICES="a,b,c,d,e" overrides for tuning runs.
+static const int* wg_slices() {
+    static int v[kConvs] = {64, 64, 128, 256, 64};
+    static bool done = false;
+    if (!done) {
+        done = true;
+        if (const char* e = getenv("SCS_WG_SLICES")) {
+            int x[kConvs];
+            if (sscanf(e, "%d,%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3], &x[4]) == kConvs)
+                for (int i = 0; i < kConvs; ++i) if (x[i] >= 1 && x[i] <= 256) v[i] = x[i];
+        }
     }
+    return v;
 }
 
 // lasagne.updates.adam over the arena
@@ -840,14 +834,15 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         {
             WgArgs wa{};
             for (int t = 0; t < kTowers; ++t) { wa.X[t] = Xi.p[t]; wa.dZ[t] = w->dZ[t]; }
-            wa.part = w->wg_part; wa.n = n; wa.slices = n < kWgSlicesMax ? n : kWgSlicesMax;
+            wa.part = w->wg_part; wa.n = n; wa.slices = n < wg_slices()[i] ? n : wg_slices()[i];
             if (i == 0) wgrad_launch<WG1>(wa, st);
             else if (i == 1) wgrad_launch<WG2>(wa, st);
             else if (i == 2) wgrad_launch<WG3>(wa, st);
             else if (i == 3) wgrad_launch<WG4>(wa, st);
             else wgrad_launch<WG5>(wa, st);
             const int tot = kCin[i] * C * 9;
-            hipLaunchKernelGGL(wgrad_final_kernel, dim3((tot + 255) / 256, kTowers), dim3(256), 0, st, w->wg_part, wa.slices * (i == 0 ? WG1::PARTS : 1), kCin[i], C, G,
+            constexpr int kParts[kConvs] = {WG1::NB * WG1::PARTS, WG2::NB * WG2::PARTS, WG3::NB * WG3::PARTS, WG4::NB * WG4::PARTS, WG5::NB * WG5::PARTS};
+            hipLaunchKernelGGL(wgrad_final_kernel, dim3((tot + 63) / 64, kTowers), dim3(256), 0, st, w->wg_part, wa.slices * kParts[i], kCin[i], C, G,
                                T0.convW[i], kTowerFloats);
         }
         if (i > 0) {

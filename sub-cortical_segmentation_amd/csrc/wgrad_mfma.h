@@ -12,14 +12,22 @@
 #pragma once
 #include "conv_mfma.h"
 
+#ifndef SCS_WG_ABLATE
+#define SCS_WG_ABLATE 0          // tools/wgbench.hip diagnostic builds only
+#endif
+
 namespace scs {
 
-template <int CIN_, int COUT_, int HIN_>
+template <int CIN_, int COUT_, int HIN_, int NB_ = 1, int WPC_ = 1>
 struct WgCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2;
+    // a workgroup owns band `b` of NB bands of output rows (HOB rows of dz, HOB + 2 rows of X) of the patches of its
+    // batch slice: smaller LDS footprint -> WPC workgroups share a CU and overlap staging with the matrix phase
+    static constexpr int NB = NB_, WPC = WPC_, HOB = HO / NB_, HXB = HOB + 2;
+    static_assert(HO % NB_ == 0, "bands must split the output rows evenly");
     static constexpr int WOP = (HO + 3) / 4 * 4;             // padded output row
-    static constexpr int XPL = HIN_ * HIN_ + 8;              // X plane stride (tail absorbs the padded-column reads)
-    static constexpr int ZPL = HO * WOP;                     // dz plane stride
+    static constexpr int XPL = HXB * HIN_ + 8;               // X plane stride (tail absorbs the padded-column reads)
+    static constexpr int ZPL = HOB * WOP;                    // dz plane stride
     static constexpr int J = CIN_ * 9;                       // (c,tap) rows
     static constexpr int MT = (J + 15) / 16;
     static constexpr int MTW = (MT + 3) / 4;                 // row tiles per wave
@@ -28,27 +36,28 @@ struct WgCfg {
     // each writes its own partial (the final reduction sums slices x 4 partials)
     static constexpr bool ROWSPLIT = (MT == 1);
     static constexpr int PARTS = ROWSPLIT ? 4 : 1;
-    static constexpr int X_FLOATS = CIN_ * XPL, Z_FLOATS = COUT_ * ZPL;
+    static constexpr int X_FLOATS = (CIN_ * XPL + 3) / 4 * 4, Z_FLOATS = COUT_ * ZPL;   // s_z 16-byte aligned
     static constexpr size_t LDS_BYTES = (size_t)(X_FLOATS + Z_FLOATS) * 4;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES * WPC_ <= 160 * 1024, "LDS budget");
 };
 
 struct WgArgs {
     const float* X[kTowers];      // [n][CIN][HIN][HIN]
     const float* dZ[kTowers];     // [n][COUT][HO][HO]
-    float* part;                  // [tower][slice][COUT][CIN][9]
+    float* part;                  // [tower][slice][band][part][CIN*9][COUT]
     int n, slices;
 };
 
 template <class C>
-__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_x = smem;
     float* s_z = smem + C::X_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
-    const int slice = blockIdx.x, tower = blockIdx.y;
+    const int slice = blockIdx.x / C::NB, band = blockIdx.x % C::NB, tower = blockIdx.y;
+    const int y0 = band * C::HOB;
     const float* __restrict__ X = pick3(a.X, tower);
     const float* __restrict__ dZ = pick3(a.dZ, tower);
     const int per = (a.n + a.slices - 1) / a.slices, n0 = slice * per, n1 = min(a.n, n0 + per);
@@ -78,29 +87,45 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
 
     for (int ni = n0; ni < n1; ++ni) {
         __syncthreads();                                                   // previous patch consumed (and the zero fill)
-        {
-            constexpr int HW = C::HIN * C::HIN;
-            const float* __restrict__ xs = X + (size_t)ni * C::CIN * HW;
-            if constexpr (HW % 4 == 0 && C::XPL % 4 == 0) {
-                const float4* __restrict__ x4 = reinterpret_cast<const float4*>(xs);
-                staged_copy<C::CIN * HW / 4, float4>(
-                    tid, [&](int e) { return x4[e]; },
-                    [&](int e, float4 v) { const int pl = e / (HW / 4), r = e - pl * (HW / 4);
+        if (SCS_WG_ABLATE != 2 || ni == n0) {
+            // rows y0 .. y0+HXB of every X plane are one contiguous run of XB floats
+            constexpr int HW = C::HIN * C::HIN, XB = C::HXB * C::HIN;
+            const float* __restrict__ xs = X + (size_t)ni * C::CIN * HW + y0 * C::HIN;
+            if constexpr (HW % 4 == 0 && C::XPL % 4 == 0 && XB % 4 == 0 && (C::HOB * C::HIN) % 4 == 0) {
+                staged_copy<C::CIN * XB / 4, float4>(
+                    tid, [&](int e) { const int pl = e / (XB / 4), r = e - pl * (XB / 4);
+                                      return reinterpret_cast<const float4*>(xs + pl * HW)[r]; },
+                    [&](int e, float4 v) { const int pl = e / (XB / 4), r = e - pl * (XB / 4);
                                            reinterpret_cast<float4*>(s_x)[pl * (C::XPL / 4) + r] = v; });
+            } else if constexpr (HW % 2 == 0 && C::XPL % 2 == 0 && XB % 2 == 0 && (C::HOB * C::HIN) % 2 == 0) {
+                staged_copy<C::CIN * XB / 2, float2>(
+                    tid, [&](int e) { const int pl = e / (XB / 2), r = e - pl * (XB / 2);
+                                      return reinterpret_cast<const float2*>(xs + pl * HW)[r]; },
+                    [&](int e, float2 v) { const int pl = e / (XB / 2), r = e - pl * (XB / 2);
+                                           reinterpret_cast<float2*>(s_x)[pl * (C::XPL / 2) + r] = v; });
             } else {
-                staged_copy<C::CIN * HW, float>(
-                    tid, [&](int e) { return xs[e]; },
-                    [&](int e, float v) { const int pl = e / HW, r = e - pl * HW; s_x[pl * C::XPL + r] = v; });
+                staged_copy<C::CIN * XB, float>(
+                    tid, [&](int e) { const int pl = e / XB, r = e - pl * XB; return xs[pl * HW + r]; },
+                    [&](int e, float v) { const int pl = e / XB, r = e - pl * XB; s_x[pl * C::XPL + r] = v; });
             }
-            constexpr int PZ = C::HO * C::HO;
-            const float* __restrict__ zs = dZ + (size_t)ni * C::COUT * PZ;
-            staged_copy<C::COUT * PZ, float>(
-                tid, [&](int e) { return zs[e]; },
-                [&](int e, float v) { const int pl = e / PZ, r = e - pl * PZ, y = r / C::HO, x = r - y * C::HO;
-                                      s_z[pl * C::ZPL + y * C::WOP + x] = v; });
+            constexpr int PZ = C::HO * C::HO, ZB = C::HOB * C::HO;
+            const float* __restrict__ zs = dZ + (size_t)ni * C::COUT * PZ + y0 * C::HO;
+            if constexpr (C::WOP == C::HO && PZ % 4 == 0 && ZB % 4 == 0) {
+                // no row padding: a band of a dz plane is one contiguous run, in global memory and in LDS
+                staged_copy<C::COUT * ZB / 4, float4>(
+                    tid, [&](int e) { const int pl = e / (ZB / 4), r = e - pl * (ZB / 4);
+                                      return reinterpret_cast<const float4*>(zs + pl * PZ)[r]; },
+                    [&](int e, float4 v) { const int pl = e / (ZB / 4), r = e - pl * (ZB / 4);
+                                           reinterpret_cast<float4*>(s_z)[pl * (C::ZPL / 4) + r] = v; });
+            } else {
+                staged_copy<C::COUT * ZB, float>(
+                    tid, [&](int e) { const int pl = e / ZB, r = e - pl * ZB; return zs[pl * PZ + r]; },
+                    [&](int e, float v) { const int pl = e / ZB, r = e - pl * ZB, y = r / C::HO, x = r - y * C::HO;
+                                          s_z[pl * C::ZPL + y * C::WOP + x] = v; });
+            }
         }
         __syncthreads();
-        for (int y = C::ROWSPLIT ? wave : 0; y < C::HO; y += C::PARTS) {
+        for (int y = C::ROWSPLIT ? wave : 0; y < C::HOB; y += C::PARTS) {
             const float* __restrict__ sxr = s_x + y * C::HIN;
             const float* __restrict__ szr = s_z + y * C::WOP;
 #pragma unroll
@@ -115,36 +140,42 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(WgArgs a) {
                 if (!C::ROWSPLIT && (3 + 4 * m) >= C::MT && (wave + 4 * m) >= C::MT) continue;   // wave-uniform: no such row tile
                     const float av = sxr[xbase[m] + 4 * xg];
 #pragma unroll
-                    for (int nt = 0; nt < C::NT16; ++nt)
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[m][nt], 0, 0, 0);
+                    for (int nt = 0; nt < C::NT16; ++nt) {
+                        if (SCS_WG_ABLATE == 1) acc[m][nt][0] += av * b[nt];
+                        else acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[m][nt], 0, 0, 0);
+                    }
 #pragma unroll
-                    for (int u = 0; u < C::NT4; ++u)
-                        acc4[m][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[m][u], 0, 0, 0);
+                    for (int u = 0; u < C::NT4; ++u) {
+                        if (SCS_WG_ABLATE == 1) acc4[m][u][0] += av * b4[u];
+                        else acc4[m][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[m][u], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 
-    // ---- partial dW of this slice: part[tower][slice][o][j = c*9 + tap]
-    float* __restrict__ out = a.part + ((size_t)tower * a.slices * C::PARTS + slice * C::PARTS + (C::ROWSPLIT ? wave : 0)) * C::COUT * C::J;
+    // ---- partial dW of this slice: part[tower][slice][j = c*9 + tap][o]  (output channel fastest: the 16 lanes of an
+    // accumulator column group store 64 contiguous bytes)
+    float* __restrict__ out = a.part + ((size_t)tower * a.slices * C::NB * C::PARTS + (size_t)blockIdx.x * C::PARTS + (C::ROWSPLIT ? wave : 0)) * C::COUT * C::J;
 #pragma unroll
     for (int m = 0; m < C::MTW; ++m) {
         const int t = (C::ROWSPLIT ? 0 : wave) + 4 * m;
         if (t >= C::MT) continue;
+        if (SCS_WG_ABLATE == 3 && a.n > 0) continue;
 #pragma unroll
         for (int nt = 0; nt < C::NT16; ++nt) {
             const int o = nt * 16 + lr;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = t * 16 + kq * 4 + r;
-                if (j < C::J) out[o * C::J + j] = acc[m][nt][r];
+                if (j < C::J) out[j * C::COUT + o] = acc[m][nt][r];
             }
         }
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
             const float val = ksub_reduce(acc4[m][u], kq, (lane ^ 32) << 2);
             const int o = C::NT16 * 16 + u * 4 + kq, j = t * 16 + lr;
-            if (j < C::J) out[o * C::J + j] = val;
+            if (j < C::J) out[j * C::COUT + o] = val;
         }
     }
 }
@@ -157,7 +188,7 @@ inline hipError_t wgrad_set_attr() {
 
 template <class C>
 inline void wgrad_launch(const WgArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(wgrad_mfma_kernel<C>, dim3(a.slices, kTowers), dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(wgrad_mfma_kernel<C>, dim3(a.slices * C::NB, kTowers), dim3(256), C::LDS_BYTES, st, a);
 }
 
 }  // namespace scs

@@ -24,7 +24,9 @@ namespace scs {
 constexpr int kW1Floats = 12 * 16 + 12 * 4 + 20;   // conv1 operands: [12][16] + [12][4] + bias[20]
 static_assert(kW1Floats > 256 && kW1Floats <= 512, "conv1 operand staging assumes two loads per thread");
 
-enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2 };
+// EPI_RAW_STATS: raw outputs plus, per (patch, band, channel), their sum and sum of squares (batch-norm statistics
+// of the training forward pass without a second pass over the activations)
+enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2, EPI_RAW_STATS = 3 };
 enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3 };
 
 template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4>
@@ -36,6 +38,7 @@ struct ConvCfg {
     static constexpr int HSRC = (SRC_ == SRC_NCHW_PAD2) ? HIN_ - 4 : HIN_;
     static constexpr int HO = HIN_ - 2;
     static constexpr bool POOL = (EPI_ == EPI_BIAS_RELU_POOL);
+    static constexpr bool RAW = (EPI_ == EPI_RAW || EPI_ == EPI_RAW_STATS);
     static constexpr int HP = HO / 2;
     static constexpr int PIX = HO * HO;                 // conv outputs per patch
     static constexpr int OUTPIX = POOL ? HP * HP : PIX; // stored outputs per patch and channel
@@ -85,6 +88,7 @@ struct ConvArgs {
     const int32_t* centers;       // SRC_VOLUME: [n][3]
     int dimx, dimy, dimz;
     int n;                        // patches
+    float* stats;                 // EPI_RAW_STATS: [tower][n * NB][COUT][2] (sum, sum of squares) per patch band
     unsigned long long* stamps;   // diagnostic builds only (STAMP): [workgroup][8] s_memtime values
 };
 
@@ -235,12 +239,12 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 #pragma unroll
     for (int nt = 0; nt < C::NT16; ++nt) {
         bvs[nt] = 0.f;
-        if constexpr (C::EPI != EPI_RAW) bvs[nt] = pick3(a.bias, tower)[nt * 16 + lr];
+        if constexpr (!C::RAW) bvs[nt] = pick3(a.bias, tower)[nt * 16 + lr];
     }
 #pragma unroll
     for (int u = 0; u < C::NT4; ++u) {
         bv4[u] = 0.f;
-        if constexpr (C::EPI != EPI_RAW) bv4[u] = pick3(a.bias, tower)[C::NT16 * 16 + u * 4 + kq];
+        if constexpr (!C::RAW) bv4[u] = pick3(a.bias, tower)[C::NT16 * 16 + u * 4 + kq];
     }
 
     // ---- stage the input planes of this workgroup's patches
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                         const int g = m / C::PIXB;
                         const int r = m - g * C::PIXB;
                         float v = acc[j][nt][r4];
-                        if constexpr (C::EPI != EPI_RAW) v = fmaxf(v + bv, 0.f);
+                        if constexpr (!C::RAW) v = fmaxf(v + bv, 0.f);
                         s_o[(g * C::COUT + co) * C::OSTR + r] = v;
                     }
                 }
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                 if (m < C::MTOT) {
                     const int g = m / C::PIXB;
                     const int r = m - g * C::PIXB;
-                    if constexpr (C::EPI != EPI_RAW) val = fmaxf(val + bv, 0.f);
+                    if constexpr (!C::RAW) val = fmaxf(val + bv, 0.f);
                     s_o[(g * C::COUT + co) * C::OSTR + r] = val;
                 }
             }
@@ -533,6 +537,30 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                     const int gc = e / C::OUTB, r = e - gc * C::OUTB;
                     outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
                 }
+            }
+        }
+    }
+    if constexpr (C::EPI == EPI_RAW_STATS) {
+        // rows of s_o are (patch, channel); LPR lanes share a row, then combine through the crossbar
+        constexpr int ROWS = C::G * C::COUT;
+        constexpr int LPR = ROWS * 16 <= C::NTH ? 16 : ROWS * 8 <= C::NTH ? 8 : ROWS * 4 <= C::NTH ? 4 : ROWS * 2 <= C::NTH ? 2 : 1;
+        constexpr int RPI = C::NTH / LPR;                    // rows per iteration
+        float* __restrict__ sp = a.stats + ((size_t)tower * a.n * C::NB) * C::COUT * 2;
+        const int sub = tid % LPR;
+#pragma unroll
+        for (int row0 = 0; row0 < ROWS; row0 += RPI) {
+            const int row = row0 + tid / LPR;
+            float sm = 0.f, sq = 0.f;
+            if (row < ng * C::COUT) {
+                const float* __restrict__ rp = s_o + row * C::OSTR;
+                for (int i = sub; i < C::OUTB; i += LPR) { const float v = rp[i]; sm += v; sq = fmaf(v, v, sq); }
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+            if (sub == 0 && row < ng * C::COUT) {
+                const int g = row / C::COUT, c = row - g * C::COUT;
+                float2* dst = reinterpret_cast<float2*>(sp + (((size_t)(g0 + g) * C::NB + band) * C::COUT + c) * 2);
+                *dst = make_float2(sm, sq);
             }
         }
     }

@@ -23,10 +23,10 @@
 namespace scs {
 
 // ------------------------------------------------------------------------------------------- configurations
-using TF2 = ConvCfg<20, 20, 30, 1, EPI_RAW, SRC_NCHW, 496, 2, 2>;
-using TF3 = ConvCfg<20, 40, 14, 2, EPI_RAW, SRC_NCHW, 208, 1, 2>;
-using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW, SRC_NCHW, 144, 1, 4>;
-using TF5 = ConvCfg<40, 60, 5, 8, EPI_RAW, SRC_NCHW, 27, 1, 2>;
+using TF2 = ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_NCHW, 496, 2, 2>;
+using TF3 = ConvCfg<20, 40, 14, 2, EPI_RAW_STATS, SRC_NCHW, 208, 1, 2>;
+using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_NCHW, 144, 1, 4>;
+using TF5 = ConvCfg<40, 60, 5, 8, EPI_RAW_STATS, SRC_NCHW, 27, 1, 2>;
 // data gradients: input = dZ_i zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i
 using DG5 = ConvCfg<60, 40, 7, 8, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 1>;
 using DG4 = ConvCfg<40, 40, 14, 1, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 3>;
@@ -66,6 +66,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     double* eval_acc = nullptr;                // [2]: loss sum, correct count
     float* actT = nullptr;                     // transposed activations for the dense weight-gradient GEMMs [3][556][cap]
     float* wT = nullptr;                       // transposed dense weights for the dense data-gradient GEMMs
+    float* stat_part = nullptr;                // [3][n * bands][C][2] per-patch-band (sum, sum of squares) left by the forward convs
     double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN reductions
     float* wg_part = nullptr;                  // [3][kWgPartFloats] partial weight gradients
 };
@@ -127,7 +128,8 @@ static int train_ensure(scs_ctx* h, int n) {
     const size_t o_feat = take(c * kFlat), o_featd = take(c * kFlat), o_R1 = take(c * kFC1), o_cat2 = take(c * kFC1ld),
                  o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
-                 o_st = take((size_t)kTowers * kConvs * 4 * 64), o_at = take((size_t)kTowers * kFC1ld * c);
+                 o_st = take((size_t)kTowers * kConvs * 4 * 64), o_at = take((size_t)kTowers * kFC1ld * c),
+                 o_sp = take((size_t)kTowers * c * 2 * 64 * 2);
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
     for (int t = 0; t < kTowers; ++t) {
@@ -138,7 +140,7 @@ static int train_ensure(scs_ctx* h, int n) {
     w->feat = w->base + o_feat; w->featd = w->base + o_featd; w->R1 = w->base + o_R1; w->cat2 = w->base + o_cat2;
     w->R2 = w->base + o_R2; w->probs = w->base + o_probs; w->dlog = w->base + o_dlog; w->dR2 = w->base + o_dR2;
     w->dcat = w->base + o_dcat; w->dfeat = w->base + o_dfeat; w->loss_rows = w->base + o_lr; w->loss_dev = w->base + o_ld;
-    w->stats = w->base + o_st;
+    w->stats = w->base + o_st; w->stat_part = w->base + o_sp;
     w->actT = w->base + o_at;
     SCS_HIP(hipMalloc(&w->masks, c * kFlat * 5));
     w->cap = (int)c;
@@ -195,8 +197,10 @@ __global__ void dropout_mask_kernel(uint8_t* m, size_t total, uint64_t seed) {
 }
 
 // conv1, raw (no BN): [n][32][32] -> Z1 [n][20][30][30]; weights [20][10] (bias slot 0) via scalar loads
-__global__ __launch_bounds__(256) void conv1_raw_kernel(CPtr3 in, CPtr3 w, Ptr3 out) {
+// also writes, per patch and channel, the sum and sum of squares of the outputs (BN statistics): stat [tower][n][20][2]
+__global__ __launch_bounds__(256) void conv1_raw_kernel(CPtr3 in, CPtr3 w, Ptr3 out, float* stat) {
     __shared__ __attribute__((aligned(16))) float s_x[1024];
+    __shared__ float s_st[4][40];
     const int t = blockIdx.y, tid = threadIdx.x;
     const float* __restrict__ src = sel3(in.p, t) + (size_t)blockIdx.x * 1024;
     reinterpret_cast<float4*>(s_x)[tid] = reinterpret_cast<const float4*>(src)[tid];
@@ -210,17 +214,25 @@ __global__ __launch_bounds__(256) void conv1_raw_kernel(CPtr3 in, CPtr3 w, Ptr3 
 #pragma unroll
         for (int k = 0; k < 9; ++k) inr[r][k] = s_x[(y + k / 3) * 32 + x + k % 3];
     }
+    const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int c = 0; c < 20; ++c) {
+        float sm = 0.f, sq = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc = fmaf(inr[r][k], w1[c * 10 + k], acc);
             const int p = tid + 256 * r;
-            if (p < 900) o[c * 900 + p] = acc;
+            if (p < 900) { o[c * 900 + p] = acc; sm += acc; sq = fmaf(acc, acc, sq); }
         }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) { sm += __shfl_xor(sm, ofs); sq += __shfl_xor(sq, ofs); }
+        if (lane == 0) { s_st[wv][2 * c] = sm; s_st[wv][2 * c + 1] = sq; }
     }
+    __syncthreads();
+    if (tid < 40)
+        stat[((size_t)t * gridDim.x + blockIdx.x) * 40 + tid] = (s_st[0][tid] + s_st[1][tid]) + (s_st[2][tid] + s_st[3][tid]);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* s_red) {
@@ -236,31 +248,19 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 }
 
 
-// BN batch statistics, stage 1: per (channel, tower, batch slice) partial sum / sum of squares in double
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(CPtr3 Z, int n, int C, int pix, double* part) {
+// BN batch statistics from the per-(patch band, channel) float sums the conv kernels leave behind: one block per
+// (channel, tower) adds the `units` partials in double in a fixed order, then mean, inv_std = 1/sqrt(var + eps) and the
+// running averages in the arena (alpha 0.1)
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, int units, int n, int C, int pix, float* stats, int layer,
+                                                             float* params, int bn_off0, int tower_stride) {
     __shared__ double s_red[4];
-    const int c = blockIdx.x, t = blockIdx.y, sp = blockIdx.z;
-    const float* __restrict__ z = sel3(Z.p, t);
-    const int per = (n + kRedSplit - 1) / kRedSplit, n0 = sp * per, n1 = min(n, n0 + per);
+    const int c = blockIdx.x, t = blockIdx.y;
+    const float2* __restrict__ p = reinterpret_cast<const float2*>(part) + (size_t)t * units * C + c;
     double s = 0, q = 0;
-    for (int ni = n0; ni < n1; ++ni) {
-        const float* __restrict__ zp = z + ((size_t)ni * C + c) * pix;
-        float fs = 0.f, fq = 0.f;                                  // per-patch partials in float, accumulated in double
-        for (int p = threadIdx.x; p < pix; p += 256) { const float v = zp[p]; fs += v; fq = fmaf(v, v, fq); }
-        s += fs; q += fq;
-    }
+    for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; s += v.x; q += v.y; }
     s = block_sum(s, s_red);
     q = block_sum(q, s_red);
-    if (threadIdx.x == 0) { double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; o[0] = s; o[1] = q; }
-}
-
-// stage 2: mean, inv_std = 1/sqrt(var + eps); running averages updated in the arena (alpha 0.1)
-__global__ void bn_stats_final_kernel(const double* part, int n, int C, int pix, float* stats, int layer, float* params,
-                                      int bn_off0, int tower_stride) {
-    const int c = threadIdx.x, t = blockIdx.x;
-    if (c >= C) return;
-    double s = 0, q = 0;
-    for (int sp = 0; sp < kRedSplit; ++sp) { const double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; s += o[0]; q += o[1]; }
+    if (threadIdx.x) return;
     const double total = (double)n * pix;
     const double mean = s / total, var = fmax(q / total - mean * mean, 0.0);
     const double inv = 1.0 / sqrt(var + (double)kBnEps);
@@ -683,19 +683,21 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     for (int i = 0; i < kConvs; ++i) {
         if (i == 0) {
             CPtr3 in{{ax, co, sa}}, wp{{w->wpk[0][0], w->wpk[1][0], w->wpk[2][0]}};
-            hipLaunchKernelGGL(conv1_raw_kernel, dim3(n, kTowers), dim3(256), 0, st, in, wp, p3(w->Z, 0));
+            hipLaunchKernelGGL(conv1_raw_kernel, dim3(n, kTowers), dim3(256), 0, st, in, wp, p3(w->Z, 0), w->stat_part);
         } else {
             ConvArgs a{};
             a.n = n;
             for (int t = 0; t < kTowers; ++t) { a.in[t] = w->X[t][i]; a.w[t] = w->wpk[t][i]; a.bias[t] = nullptr; a.out[t] = w->Z[t][i]; }
+            a.stats = w->stat_part;
             if (i == 1) conv_launch<TF2>(a, st);
             else if (i == 2) conv_launch<TF3>(a, st);
             else if (i == 3) conv_launch<TF4>(a, st);
             else conv_launch<TF5>(a, st);
         }
         const int C = kCout[i], Hh = kHout[i];
-        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, kTowers, kRedSplit), dim3(256), 0, st, c3(w->Z, i), n, C, Hh * Hh, w->red_part);
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(kTowers), dim3(64), 0, st, w->red_part, n, C, Hh * Hh, w->stats, i, P, T0.bn[i], kTowerFloats);
+        constexpr int kStatBands[kConvs] = {1, TF2::NB, TF3::NB, TF4::NB, TF5::NB};
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, n * kStatBands[i], n, C, Hh * Hh, w->stats, i, P,
+                           T0.bn[i], kTowerFloats);
         Ptr3 out;
         for (int t = 0; t < kTowers; ++t) out.p[t] = (i == kConvs - 1) ? w->H5[t] : w->X[t][i + 1];
         const long tot = (long)n * C * (kPool[i] ? (Hh / 2) * (Hh / 2) : Hh * Hh);

@@ -484,20 +484,61 @@ static void sgemm(const SgemmArgs& g, int nprob, hipStream_t st) {
 }
 
 // ---- BN backward.  dy(n,c,y,x) = dOut routed through max-pool (every tied maximum receives it, as Theano's
-// MaxPoolGrad does) and ReLU.
-template <bool POOL>
-__device__ __forceinline__ float bn_dy(const float* __restrict__ z, const float* __restrict__ dout, long nc, int H, int y, int x,
-                                      float sc, float sh, float* xhat_out, float mean, float inv) {
-    const float zv = z[nc * H * H + y * H + x];
-    const float yv = fmaf(zv, sc, sh);
-    *xhat_out = (zv - mean) * inv;
-    if (POOL) {
-        const int HO = H / 2, wy = y >> 1, wx = x >> 1;
-        const float* zp = z + nc * H * H + (2 * wy) * H + 2 * wx;
-        const float m = fmaxf(fmaxf(fmaf(zp[0], sc, sh), fmaf(zp[1], sc, sh)), fmaxf(fmaf(zp[H], sc, sh), fmaf(zp[H + 1], sc, sh)));
-        return (yv == m && m > 0.f) ? dout[nc * HO * HO + wy * HO + wx] : 0.f;
+// MaxPoolGrad does) and ReLU; then  dbeta = sum dy,  dgamma = sum dy*xhat,
+//   dz = gamma*inv_std * (dy - dbeta/M - xhat*dgamma/M),   M = n*H*H.
+// Two passes over (Z, dOut), both as one workgroup per (channel, tower, batch slice): pass 1 leaves per-slice partial
+// sums in double, pass 2 adds them in a fixed order and writes dz.  With pooling a thread owns one 2x2 window (4 z
+// values as two 8-byte loads + one dOut); without, 4 consecutive pixels (16-byte loads) when the plane allows.
+struct BnCh { float mean, inv, sc, sh; };
+__device__ __forceinline__ BnCh bn_channel(const float* stats, int layer, const float* params, int bn_off0, int tower_stride, int t, int C, int c) {
+    const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+    const float* bn = params + bn_off0 + t * tower_stride;
+    BnCh r;
+    r.mean = st[c]; r.inv = st[64 + c]; r.sc = bn[C + c] * r.inv; r.sh = bn[c] - r.mean * r.sc;
+    return r;
+}
+
+// F(z, dy_routed, element index within the (ni, c) plane) for every element of patches [n0, n1) of channel c
+template <bool POOL, int H, class F>
+__device__ __forceinline__ void bn_for_each(const float* __restrict__ z, const float* __restrict__ d, int C, int c, int n0, int n1,
+                                            const BnCh& b, F&& f) {
+    constexpr int pix = H * H;
+    if constexpr (POOL) {
+        constexpr int HO = H / 2, W = HO * HO;
+        const int total = (n1 - n0) * W;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int ni = n0 + idx / W, wdx = idx % W, wy = wdx / HO, wx = wdx - wy * HO;
+            const size_t plane = (size_t)ni * C + c;
+            const int e0 = (2 * wy) * H + 2 * wx;
+            const float* zp = z + plane * pix + e0;
+            const float2 r0 = *reinterpret_cast<const float2*>(zp), r1 = *reinterpret_cast<const float2*>(zp + H);
+            const float dv = d[plane * W + wdx];
+            const float y0 = fmaf(r0.x, b.sc, b.sh), y1 = fmaf(r0.y, b.sc, b.sh), y2 = fmaf(r1.x, b.sc, b.sh), y3 = fmaf(r1.y, b.sc, b.sh);
+            const float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+            const bool on = m > 0.f;
+            f(plane, e0, r0.x, (on && y0 == m) ? dv : 0.f, r0.y, (on && y1 == m) ? dv : 0.f,
+              e0 + H, r1.x, (on && y2 == m) ? dv : 0.f, r1.y, (on && y3 == m) ? dv : 0.f);
+        }
+    } else if constexpr (pix % 4 == 0) {
+        constexpr int Q = pix / 4;
+        const int total = (n1 - n0) * Q;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int ni = n0 + idx / Q, q = idx % Q;
+            const size_t plane = (size_t)ni * C + c;
+            const float4 zv = reinterpret_cast<const float4*>(z + plane * pix)[q];
+            const float4 dv = reinterpret_cast<const float4*>(d + plane * pix)[q];
+            f(plane, 4 * q, zv.x, fmaf(zv.x, b.sc, b.sh) > 0.f ? dv.x : 0.f, zv.y, fmaf(zv.y, b.sc, b.sh) > 0.f ? dv.y : 0.f,
+              4 * q + 2, zv.z, fmaf(zv.z, b.sc, b.sh) > 0.f ? dv.z : 0.f, zv.w, fmaf(zv.w, b.sc, b.sh) > 0.f ? dv.w : 0.f);
+        }
+    } else {
+        const int total = (n1 - n0) * pix;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int ni = n0 + idx / pix, e = idx % pix;
+            const size_t plane = (size_t)ni * C + c;
+            const float zv = z[plane * pix + e];
+            f.one(plane, e, zv, fmaf(zv, b.sc, b.sh) > 0.f ? d[plane * pix + e] : 0.f);
+        }
     }
-    return yv > 0.f ? dout[nc * H * H + y * H + x] : 0.f;
 }
 
 template <bool POOL, int H>
@@ -507,56 +548,59 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(CPtr3 Z, CPtr3 dOut
     const int c = blockIdx.x, t = blockIdx.y, sp = blockIdx.z;
     const float* __restrict__ z = sel3(Z.p, t);
     const float* __restrict__ d = sel3(dOut.p, t);
-    const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
-    const float* bn = params + bn_off0 + t * tower_stride;
-    const float mean = st[c], inv = st[64 + c], sc = bn[C + c] * inv, sh = bn[c] - mean * sc;
-    constexpr int pix = H * H;
-    const int per = (n + kRedSplit - 1) / kRedSplit, n0 = sp * per, n1 = min(n, n0 + per);
-    double sb = 0, sg = 0;
-    for (int ni = n0; ni < n1; ++ni) {
-        float fb = 0.f, fg = 0.f;
-        for (int p = threadIdx.x; p < pix; p += 256) {
-            float xh;
-            const float dy = bn_dy<POOL>(z, d, (long)ni * C + c, H, p / H, p % H, sc, sh, &xh, mean, inv);
-            fb += dy; fg = fmaf(dy, xh, fg);
+    const BnCh b = bn_channel(stats, layer, params, bn_off0, tower_stride, t, C, c);
+    const int per = (n + kRedSplit - 1) / kRedSplit, n0 = min(n, sp * per), n1 = min(n, n0 + per);
+    struct Acc {
+        float fb = 0.f, fg = 0.f; BnCh b;
+        __device__ void one(size_t, int, float zv, float dy) { fb += dy; fg = fmaf(dy, (zv - b.mean) * b.inv, fg); }
+        __device__ void operator()(size_t pl, int e0, float z0, float d0, float z1, float d1, int e1, float z2, float d2, float z3, float d3) {
+            one(pl, e0, z0, d0); one(pl, e0, z1, d1); one(pl, e1, z2, d2); one(pl, e1, z3, d3);
         }
-        sb += fb; sg += fg;
-    }
-    sb = block_sum(sb, s_red);
-    sg = block_sum(sg, s_red);
+    } acc;
+    acc.b = b;
+    bn_for_each<POOL, H>(z, d, C, c, n0, n1, b, acc);
+    const double sb = block_sum((double)acc.fb, s_red);
+    const double sg = block_sum((double)acc.fg, s_red);
     if (threadIdx.x == 0) { double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; o[0] = sb; o[1] = sg; }
 }
 
-__global__ void bn_bwd_final_kernel(const double* part, int C, float* stats, int layer, float* grads, int bn_off0, int tower_stride) {
-    const int c = threadIdx.x, t = blockIdx.x;
-    if (c >= C) return;
-    double sb = 0, sg = 0;
-    for (int sp = 0; sp < kRedSplit; ++sp) { const double* o = part + (((size_t)t * 64 + c) * kRedSplit + sp) * 2; sb += o[0]; sg += o[1]; }
-    float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
-    st[128 + c] = (float)sb; st[192 + c] = (float)sg;
-    float* gb = grads + bn_off0 + t * tower_stride;
-    gb[c] = (float)sb; gb[C + c] = (float)sg;                  // d beta, d gamma (mean / inv_std stay 0)
-}
-
+// pass 2; `split` batch slices (gridDim.z).  Slice 0 also stores d beta / d gamma into the gradient arena.
 template <bool POOL, int H>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, Ptr3 dZ, int n, int C, const float* stats,
-                                                          int layer, const float* params, int bn_off0, int tower_stride) {
-    const int t = blockIdx.y;
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(CPtr3 Z, CPtr3 dOut, Ptr3 dZ, int n, int C, const float* stats, int layer,
+                                                          const float* params, int bn_off0, int tower_stride, const double* part,
+                                                          float* grads) {
+    __shared__ float s_sum[2];
+    const int c = blockIdx.x, t = blockIdx.y, sp = blockIdx.z, split = gridDim.z;
     const float* __restrict__ z = sel3(Z.p, t);
     const float* __restrict__ d = sel3(dOut.p, t);
     float* __restrict__ dz = sel3(dZ.p, t);
-    const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
-    const float* bn = params + bn_off0 + t * tower_stride;
+    const BnCh b = bn_channel(stats, layer, params, bn_off0, tower_stride, t, C, c);
+    if (threadIdx.x == 0) {
+        double sb = 0, sg = 0;
+        for (int k = 0; k < kRedSplit; ++k) { const double* o = part + (((size_t)t * 64 + c) * kRedSplit + k) * 2; sb += o[0]; sg += o[1]; }
+        s_sum[0] = (float)sb; s_sum[1] = (float)sg;
+        if (sp == 0) { float* gb = grads + bn_off0 + t * tower_stride; gb[c] = (float)sb; gb[C + c] = (float)sg; }   // mean / inv_std stay 0
+    }
+    __syncthreads();
     constexpr int pix = H * H;
     const float invM = 1.f / ((float)n * pix);
-    const long total = (long)n * C * pix;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long nc = e / pix; const int p = (int)(e - nc * pix), c = (int)(nc % C);
-        const float mean = st[c], inv = st[64 + c], sc = bn[C + c] * inv, sh = bn[c] - mean * sc;
-        float xh;
-        const float dy = bn_dy<POOL>(z, d, nc, H, p / H, p % H, sc, sh, &xh, mean, inv);
-        dz[e] = sc * (dy - st[128 + c] * invM - xh * st[192 + c] * invM);
-    }
+    const int per = (n + split - 1) / split, n0 = min(n, sp * per), n1 = min(n, n0 + per);
+    struct Wr {
+        float* dz; BnCh b; float mb, mg;
+        __device__ float val(float zv, float dy) const { return b.sc * (dy - mb - (zv - b.mean) * b.inv * mg); }
+        __device__ void one(size_t pl, int e, float zv, float dy) { dz[pl * pix + e] = val(zv, dy); }
+        __device__ void operator()(size_t pl, int e0, float z0, float d0, float z1, float d1, int e1, float z2, float d2, float z3, float d3) {
+            float* p = dz + pl * pix;
+            if constexpr (POOL) {
+                *reinterpret_cast<float2*>(p + e0) = make_float2(val(z0, d0), val(z1, d1));
+                *reinterpret_cast<float2*>(p + e1) = make_float2(val(z2, d2), val(z3, d3));
+            } else {
+                *reinterpret_cast<float4*>(p + e0) = make_float4(val(z0, d0), val(z1, d1), val(z2, d2), val(z3, d3));
+            }
+        }
+    } wr;
+    wr.dz = dz; wr.b = b; wr.mb = s_sum[0] * invM; wr.mg = s_sum[1] * invM;
+    bn_for_each<POOL, H>(z, d, C, c, n0, n1, b, wr);
 }
 
 // sum of the partial weight gradients in a fixed order (deterministic): 64 elements x 4 groups of partials per block,
@@ -820,9 +864,9 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
             constexpr int HH = decltype(h_tag)::value;
             hipLaunchKernelGGL((bn_bwd_partial_kernel<PL, HH>), dim3(C, kTowers, kRedSplit), dim3(256), 0, st, Zi, dOut, n, C, w->stats, i, P,
                                T0.bn[i], kTowerFloats, w->red_part);
-            hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(kTowers), dim3(64), 0, st, w->red_part, C, w->stats, i, G, T0.bn[i], kTowerFloats);
-            hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, HH>), dim3(ew_grid(tot).x, kTowers), dim3(256), 0, st, Zi, dOut, dZ, n, C, w->stats, i, P,
-                               T0.bn[i], kTowerFloats);
+            const int split = max(1, min(n, (int)(tot / C / 8192)));           // ~8k elements of a channel per workgroup
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, HH>), dim3(C, kTowers, split), dim3(256), 0, st, Zi, dOut, dZ, n, C, w->stats, i, P,
+                               T0.bn[i], kTowerFloats, w->red_part, G);
         };
         using std::integral_constant;
         if (i == 0) bn_bwd(integral_constant<bool, false>{}, integral_constant<int, 30>{});

@@ -64,7 +64,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* wdg[kTowers][kConvs]{};             // data-gradient packs (i >= 1)
     float* pack_base = nullptr;
     double* eval_acc = nullptr;                // [2]: loss sum, correct count
-    float* actT = nullptr;                     // transposed activations for the dense weight-gradient GEMMs [3][556][cap]
+    float* actT = nullptr;                     // transposed activations for the dense weight-gradient GEMMs [5][556][cap]: H5 x3, featd, cat2
     float* wT = nullptr;                       // transposed dense weights for the dense data-gradient GEMMs
     float* stat_part = nullptr;                // [3][n * bands][C][2] per-patch-band (sum, sum of squares) left by the forward convs
     double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN reductions
@@ -128,7 +128,7 @@ static int train_ensure(scs_ctx* h, int n) {
     const size_t o_feat = take(c * kFlat), o_featd = take(c * kFlat), o_R1 = take(c * kFC1), o_cat2 = take(c * kFC1ld),
                  o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
-                 o_st = take((size_t)kTowers * kConvs * 4 * 64), o_at = take((size_t)kTowers * kFC1ld * c),
+                 o_st = take((size_t)kTowers * kConvs * 4 * 64), o_at = take((size_t)5 * kFC1ld * c),
                  o_sp = take((size_t)kTowers * c * 2 * 64 * 2);
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
@@ -368,6 +368,84 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     (void)py;
 }
 
+// Training head in one pass per row: out_layer (270 -> 15) + softmax + cross-entropy, d logits = (p - onehot)/n, and
+// the gradient that flows back through fc_2's ReLU:  dR2[row][k] = (R2[row][k] > 0) * sum_c dlog[c] * W[k][c].
+// 16 lanes per row (lane = class), 16 rows per workgroup.
+__global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict__ R2, const float* __restrict__ W,
+                                                        const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
+                                                        float* __restrict__ probs /*[n][16]*/, float* __restrict__ dlog /*[n][16]*/,
+                                                        float* __restrict__ loss_rows /*[n]*/, float* __restrict__ dR2 /*[n][kFC2ld]*/) {
+    __shared__ float s_w[kFC2 * 15 + 16];
+    __shared__ float s_x[16][kFC2ld];
+    __shared__ float s_d[16][16];
+    for (int e = threadIdx.x; e < kFC2 * 15; e += 256) s_w[e] = W[e];
+    if (threadIdx.x < 15) s_w[kFC2 * 15 + threadIdx.x] = b[threadIdx.x];
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const int row0 = blockIdx.x * 16, row = row0 + r;
+    for (int e = threadIdx.x; e < 16 * kFC2ld; e += 256) {
+        const int rr = e / kFC2ld, k = e - rr * kFC2ld;
+        s_x[rr][k] = (row0 + rr < n) ? R2[(size_t)(row0 + rr) * kFC2ld + k] : 0.f;
+    }
+    __syncthreads();
+    const int cc = c < 15 ? c : 14;                                // lane 15 shadows class 14, its results are dropped
+    float z = s_w[kFC2 * 15 + cc];
+    for (int k = 0; k < kFC2; ++k) z = fmaf(s_x[r][k], s_w[k * 15 + cc], z);
+    float mx = z;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = c < 15 ? expf(z - mx) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float pr = e / sum;
+    const int yi = row < n ? y[row] : 0;
+    const float dl = (c < 15 && row < n) ? (pr - (c == yi ? 1.f : 0.f)) / (float)n : 0.f;
+    s_d[r][c] = dl;
+    if (row < n) {
+        probs[(size_t)row * 16 + c] = c < 15 ? pr : 0.f;
+        dlog[(size_t)row * 16 + c] = dl;
+        if (c == yi) loss_rows[row] = -(z - mx - logf(sum));       // -log softmax, stable
+    }
+    __syncthreads();
+    if (row < n) {
+        for (int k = c; k < kFC2ld; k += 16) {
+            float g = 0.f;
+            if (k < kFC2 && s_x[r][k] > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 15; ++j) g = fmaf(s_d[r][j], s_w[k * 15 + j], g);
+            }
+            dR2[(size_t)row * kFC2ld + k] = g;
+        }
+    }
+}
+
+// d out_layer.W[k][c] = sum_rows R2[row][k] * dlog[row][c]  and  d out_layer.b[c] = sum_rows dlog[row][c].
+// 16 outputs x 16 row groups per workgroup (output index 4050 + c = the bias gradient), fixed-order combination.
+__global__ __launch_bounds__(256) void outw_grad_kernel(const float* __restrict__ R2, const float* __restrict__ dlog, int n,
+                                                       float* __restrict__ gW /*[270][15]*/, float* __restrict__ gb /*[15]*/) {
+    __shared__ float s_p[16][17];
+    const int ex = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + ex;
+    const bool isw = e < kFC2 * 15, isb = !isw && e < kFC2 * 15 + 15;
+    const int k = isw ? e / 15 : 0, c = isw ? e - k * 15 : (isb ? e - kFC2 * 15 : 0);
+    float s = 0.f;
+    if (isw || isb) {
+#pragma unroll 4
+        for (int row = rg; row < n; row += 16) {
+            const float x = isw ? R2[(size_t)row * kFC2ld + k] : 1.f;
+            s = fmaf(x, dlog[(size_t)row * 16 + c], s);
+        }
+    }
+    s_p[rg][ex] = s;
+    __syncthreads();
+    if (rg == 0 && (isw || isb)) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += s_p[i][ex];
+        if (isw) gW[e] = v; else gb[c] = v;
+    }
+}
+
 __global__ void mean_kernel(const float* v, int n, float* out) {
     __shared__ double s_red[4];
     double s = 0;
@@ -397,90 +475,55 @@ __global__ void dropout_bwd_kernel(Ptr3 g, const uint8_t* mask, int n) {
 }
 
 // out[j] = sum_r g[r][ldg + j]   (64 columns x 4 row groups per block, fixed summation order)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* g, int ldg, int n, int cols, float* out) {
+struct ColProblem { const float* g; int ldg, cols; float* out; };
+constexpr int kColProblems = 5;
+struct ColArgs { ColProblem p[kColProblems]; int n; };
+// out[j] = sum_rows g[row][j] for up to 5 matrices in one launch (the bias gradients of the dense layers); blockIdx.y = problem
+__global__ __launch_bounds__(256) void colsum_kernel(ColArgs a) {
     __shared__ double s_p[4][64];
+    ColProblem P = a.p[0];
+#pragma unroll
+    for (int i = 1; i < kColProblems; ++i) if ((int)blockIdx.y == i) P = a.p[i];
     const int cj = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + cj;
+    if (blockIdx.x * 64 >= P.cols) return;
     double s = 0;
-    if (j < cols)
-        for (int r = rg; r < n; r += 4) s += g[(size_t)r * ldg + j];
+    if (j < P.cols)
+        for (int r = rg; r < a.n; r += 4) s += P.g[(size_t)r * P.ldg + j];
     s_p[rg][cj] = s;
     __syncthreads();
-    if (rg == 0 && j < cols) out[j] = (float)(s_p[0][cj] + s_p[1][cj] + s_p[2][cj] + s_p[3][cj]);
+    if (rg == 0 && j < P.cols) P.out[j] = (float)(s_p[0][cj] + s_p[1][cj] + s_p[2][cj] + s_p[3][cj]);
 }
 
-// out[c][r] (ldo) = in[r][c] (ldi), r < rows, c < cols; blockIdx.z selects one of up to 3 problems
-struct TrProblem { const float* in; int ldi; float* out; int ldo; };
-struct TrArgs { TrProblem p[kTowers]; int rows, cols; };
+// out[c][r] (ldo) = in[r][c] (ldi), r < rows, c < cols; blockIdx.z selects one of up to 10 problems of different sizes
+struct TrProblem { const float* in; int ldi; float* out; int ldo; int rows, cols; };
+constexpr int kTrProblems = 10;
+struct TrArgs { TrProblem p[kTrProblems]; };
 __global__ __launch_bounds__(256) void transpose_kernel(TrArgs a) {
     __shared__ float tile[32][33];
-    const int z = blockIdx.z;
-    const TrProblem P = z == 0 ? a.p[0] : (z == 1 ? a.p[1] : a.p[2]);
+    TrProblem P = a.p[0];
+#pragma unroll
+    for (int i = 1; i < kTrProblems; ++i) if ((int)blockIdx.z == i) P = a.p[i];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    if (r0 >= P.rows || c0 >= P.cols) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < a.rows && c < a.cols) ? P.in[(size_t)r * P.ldi + c] : 0.f;
+        tile[ty + 8 * i][tx] = (r < P.rows && c < P.cols) ? P.in[(size_t)r * P.ldi + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < a.cols && r < a.rows) P.out[(size_t)c * P.ldo + r] = tile[tx][ty + 8 * i];
+        if (c < P.cols && r < P.rows) P.out[(size_t)c * P.ldo + r] = tile[tx][ty + 8 * i];
     }
 }
+
 static void transpose(const TrArgs& a, int nprob, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((a.cols + 31) / 32, (a.rows + 31) / 32, nprob), dim3(256), 0, st, a);
-}
-
-// ---- generic strided SGEMM on the vector ALU: C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]
-struct SgemmProblem { const float* A; long sam, sak; const float* B; long sbk, sbn; float* C; long ldc; };
-struct SgemmArgs { SgemmProblem p[kTowers]; int M, N, K; };
-
-__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
-    __shared__ float sA[16][65], sB[16][65];
-    const int z = blockIdx.z;
-    const SgemmProblem P = z == 0 ? g.p[0] : (z == 1 ? g.p[1] : g.p[2]);
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    float acc[4][4] = {};
-    const bool a_kfast = P.sak == 1, b_nfast = P.sbn == 1;
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-            // consecutive threads walk whichever index is contiguous in memory (wave-uniform choice)
-            const int kk = a_kfast ? (e & 15) : (e >> 6), mm = a_kfast ? (e >> 4) : (e & 63);
-            const int m = m0 + mm, k = k0 + kk;
-            sA[kk][mm] = (m < g.M && k < g.K) ? P.A[m * P.sam + k * P.sak] : 0.f;
-            const int nn = b_nfast ? (e & 63) : (e >> 4), kb = b_nfast ? (e >> 6) : (e & 15);
-            const int n = n0 + nn, k2 = k0 + kb;
-            sB[kb][nn] = (n < g.N && k2 < g.K) ? P.B[k2 * P.sbk + n * P.sbn] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty * 4 + i]; b[i] = sB[kk][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < g.M && n < g.N) P.C[m * P.ldc + n] = acc[i][j];
-        }
-}
-
-static void sgemm(const SgemmArgs& g, int nprob, hipStream_t st) {
-    dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, nprob);
-    hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, st, g);
+    int mr = 0, mc = 0;
+    for (int i = 0; i < nprob; ++i) { mr = a.p[i].rows > mr ? a.p[i].rows : mr; mc = a.p[i].cols > mc ? a.p[i].cols : mc; }
+    hipLaunchKernelGGL(transpose_kernel, dim3((mc + 31) / 32, (mr + 31) / 32, nprob), dim3(256), 0, st, a);
 }
 
 // ---- BN backward.  dy(n,c,y,x) = dOut routed through max-pool (every tied maximum receives it, as Theano's
@@ -769,81 +812,72 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     g.K4 = kFC1ld; g.K = kFC1 + kAtlas; g.N = kFC2;
     g.p[0] = GemmProblem{w->cat2, kFC1ld, P + H.fc2W, kFC2, P + H.fc2b, w->R2, kFC2ld};
     gemm_launch(g, 1, st);
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, y, n, w->probs,
-                       w->dlog, w->loss_rows, (double*)nullptr);
+    hipLaunchKernelGGL(head_train_kernel, dim3((n + 15) / 16), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, y, n, w->probs, w->dlog,
+                       w->loss_rows, w->dR2);
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, w->loss_rows, n, w->loss_dev);
 
-    // ---- backward: dense head
-    SgemmArgs s{};
-    // out_layer
-    s.M = kFC2; s.N = kClasses; s.K = n;
-    s.p[0] = SgemmProblem{w->R2, 1, kFC2ld, w->dlog, 16, 1, G + H.outW, kClasses};
-    sgemm(s, 1, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, st, w->dlog, 16, n, kClasses, G + H.outb);
-    s.M = n; s.N = kFC2; s.K = kClasses;
-    s.p[0] = SgemmProblem{w->dlog, 16, 1, P + H.outW, 1, kClasses, w->dR2, kFC2ld};
-    sgemm(s, 1, st);
-    hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC2), dim3(256), 0, st, w->dR2, kFC2ld, w->R2, kFC2ld, (const uint8_t*)nullptr, n, kFC2);
+    // ---- backward: dense head.  d out_layer and dR2 (through fc_2's ReLU) came out of head_train_kernel's pass.
+    hipLaunchKernelGGL(outw_grad_kernel, dim3((kFC2 * 15 + 15 + 15) / 16), dim3(256), 0, st, w->R2, w->dlog, n, G + H.outW, G + H.outb);
     // The remaining dense gradients run on the MFMA GEMM: weight gradients take the transposed activation as A
-    // ([in][n]) and the upstream gradient as W ([n][out]); data gradients take the transposed weight as W.
+    // ([in][n]) and the upstream gradient as W ([n][out]); data gradients take the transposed weight as W.  All ten
+    // transposes (5 weights, 5 activations) are one launch.
     const int ldT = w->cap;
     float* wT2 = w->wT;                       // [270][540]  = fc_2.W[:540]^T
     float* wT1 = wT2 + 270 * 540;             // [540][540]  = FC1.W^T
     float* wTd = wT1 + 540 * 540;             // [3][180][540] = d1.W^T
+    float* aT5 = w->actT;                                         // [3][540][ldT]  H5^T per tower
+    float* aTf = w->actT + (size_t)3 * kFC1ld * ldT;              // [540][ldT]     featd^T
+    float* aTc = w->actT + (size_t)4 * kFC1ld * ldT;              // [555][ldT]     cat2^T
     {
         TrArgs tr{};
-        tr.rows = kFC1; tr.cols = kFC2; tr.p[0] = TrProblem{P + H.fc2W, kFC2, wT2, kFC1};
-        transpose(tr, 1, st);
-        tr.rows = kFlat; tr.cols = kFC1; tr.p[0] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat};
-        transpose(tr, 1, st);
-        tr.rows = kFlat; tr.cols = kD1;
-        for (int t = 0; t < kTowers; ++t) { const TowerOff T = tower_off(t * kTowerFloats); tr.p[t] = TrProblem{P + T.d1W, kD1, wTd + t * kD1 * kFlat, kFlat}; }
-        transpose(tr, kTowers, st);
+        tr.p[0] = TrProblem{P + H.fc2W, kFC2, wT2, kFC1, kFC1, kFC2};
+        tr.p[1] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat, kFlat, kFC1};
+        for (int t = 0; t < kTowers; ++t) {
+            const TowerOff T = tower_off(t * kTowerFloats);
+            tr.p[2 + t] = TrProblem{P + T.d1W, kD1, wTd + t * kD1 * kFlat, kFlat, kFlat, kD1};
+            tr.p[5 + t] = TrProblem{w->H5[t], kFlat, aT5 + (size_t)t * kFC1ld * ldT, ldT, n, kFlat};
+        }
+        tr.p[8] = TrProblem{w->featd, kFlat, aTf, ldT, n, kFlat};
+        tr.p[9] = TrProblem{w->cat2, kFC1ld, aTc, ldT, n, kFC1 + kAtlas};
+        transpose(tr, kTrProblems, st);
     }
     GemmArgs bg{};
     bg.relu = 0;
-    // fc_2: dW2 = cat2^T dPre2, db2, dcat = dPre2 W2[:540]^T
-    {
-        TrArgs tr{}; tr.rows = n; tr.cols = kFC1 + kAtlas; tr.p[0] = TrProblem{w->cat2, kFC1ld, w->actT, ldT};
-        transpose(tr, 1, st);
-    }
+    // fc_2: dW2 = cat2^T dPre2, dcat = dPre2 W2[:540]^T
     bg.M = kFC1 + kAtlas; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kFC2;
-    bg.p[0] = GemmProblem{w->actT, ldT, w->dR2, kFC2ld, nullptr, G + H.fc2W, kFC2};
+    bg.p[0] = GemmProblem{aTc, ldT, w->dR2, kFC2ld, nullptr, G + H.fc2W, kFC2};
     gemm_launch(bg, 1, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3((kFC2 + 63) / 64), dim3(256), 0, st, w->dR2, kFC2ld, n, kFC2, G + H.fc2b);
     bg.M = n; bg.K4 = kFC2ld; bg.K = kFC2; bg.N = kFC1;
     bg.p[0] = GemmProblem{w->dR2, kFC2ld, wT2, kFC1, nullptr, w->dcat, kFC1};
     gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC1), dim3(256), 0, st, w->dcat, kFC1, w->R1, kFC1, mask2, n, kFC1);
     // FC1
-    {
-        TrArgs tr{}; tr.rows = n; tr.cols = kFlat; tr.p[0] = TrProblem{w->featd, kFlat, w->actT, ldT};
-        transpose(tr, 1, st);
-    }
     bg.M = kFlat; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kFC1;
-    bg.p[0] = GemmProblem{w->actT, ldT, w->dcat, kFC1, nullptr, G + H.fc1W, kFC1};
+    bg.p[0] = GemmProblem{aTf, ldT, w->dcat, kFC1, nullptr, G + H.fc1W, kFC1};
     gemm_launch(bg, 1, st);
-    hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64), dim3(256), 0, st, w->dcat, kFC1, n, kFC1, G + H.fc1b);
     bg.M = n; bg.K4 = kFC1; bg.K = kFC1; bg.N = kFlat;
     bg.p[0] = GemmProblem{w->dcat, kFC1, wT1, kFlat, nullptr, w->dfeat, kFlat};
     gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFlat), dim3(256), 0, st, w->dfeat, kFlat, w->feat, kFlat, mask1, n, kFlat);
-    // d1 x3
+    // bias gradients of fc_2, FC1 and the three d1 layers: column sums of the (masked) upstream gradients, one launch
     {
-        TrArgs tr{}; tr.rows = n; tr.cols = kFlat;
-        for (int t = 0; t < kTowers; ++t) tr.p[t] = TrProblem{w->H5[t], kFlat, w->actT + (size_t)t * kFC1ld * ldT, ldT};
-        transpose(tr, kTowers, st);
+        ColArgs ca{};
+        ca.n = n;
+        ca.p[0] = ColProblem{w->dR2, kFC2ld, kFC2, G + H.fc2b};
+        ca.p[1] = ColProblem{w->dcat, kFC1, kFC1, G + H.fc1b};
+        for (int t = 0; t < kTowers; ++t) {
+            const TowerOff T = tower_off(t * kTowerFloats);
+            ca.p[2 + t] = ColProblem{w->dfeat + t * kD1, kFlat, kD1, G + T.d1b};
+        }
+        hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64, kColProblems), dim3(256), 0, st, ca);
     }
+    // d1 x3
     bg.M = kFlat; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kD1;
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
-        bg.p[t] = GemmProblem{w->actT + (size_t)t * kFC1ld * ldT, ldT, w->dfeat + t * kD1, kFlat, nullptr, G + T.d1W, kD1};
+        bg.p[t] = GemmProblem{aT5 + (size_t)t * kFC1ld * ldT, ldT, w->dfeat + t * kD1, kFlat, nullptr, G + T.d1W, kD1};
     }
     gemm_launch(bg, kTowers, st);
-    for (int t = 0; t < kTowers; ++t) {
-        const TowerOff T = tower_off(t * kTowerFloats);
-        hipLaunchKernelGGL(colsum_kernel, dim3((kD1 + 63) / 64), dim3(256), 0, st, w->dfeat + t * kD1, kFlat, n, kD1, G + T.d1b);
-    }
     bg.M = n; bg.K4 = kD1; bg.K = kD1; bg.N = kFlat;
     for (int t = 0; t < kTowers; ++t) bg.p[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kFlat, kFlat, nullptr, w->dX[t][0], kFlat};
     gemm_launch(bg, kTowers, st);

@@ -24,19 +24,20 @@ struct GemmArgs {
     int relu;
 };
 
-constexpr int kGemmBK = 32, kGemmAS = 34;
-
-// MT = 16-row tiles per wave, NT = 16-column tiles per workgroup: workgroup tile (64*MT) x (16*NT)
-template <int MT, int NT>
+// MT = 16-row tiles per wave, NT = 16-column tiles per workgroup: workgroup tile (64*MT) x (16*NT); BK = K slab.
+template <int MT, int NT, int BK = 32>
 struct GemmTile {
     static constexpr int BM = 64 * MT, BN = 16 * NT, BS = (BN % 32 == 16) ? BN : BN + 16;
-    static constexpr int A_PER = BM * kGemmBK / 256, B_PER = (kGemmBK * BN + 255) / 256;
-    static constexpr size_t LDS = (size_t)(2 * BM * kGemmAS + 2 * kGemmBK * BS) * 4;
+    static constexpr int AS = BK + 2;                    // bank = 2*row + k
+    static constexpr int A_PER = BM * BK / 256, B_PER = (BK * BN + 255) / 256;
+    static constexpr size_t LDS = (size_t)(2 * BM * AS + 2 * BK * BS) * 4;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int MT, int NT>
+template <int MT, int NT, int BK = 32>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
-    using T = GemmTile<MT, NT>;
+    using T = GemmTile<MT, NT, BK>;
+    constexpr int kGemmBK = BK, kGemmAS = T::AS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_a = smem;                                  // [2][BM][34]
     float* s_b = smem + 2 * T::BM * kGemmAS;            // [2][32][BS]
@@ -49,11 +50,12 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
 
     const int kmax = g.K ? g.K : g.K4;
     float ra[T::A_PER], rb[T::B_PER];
-    const int a_col = tid & 31, a_row = tid >> 5;       // A slab: rows a_row + 8*i, column a_col
+    constexpr int RSTEP = 256 / BK;                     // A slab: rows a_row + RSTEP*i, column a_col
+    const int a_col = tid % BK, a_row = tid / BK;
     auto load_slab = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < T::A_PER; ++i) {
-            const int row = m0 + a_row + 8 * i, k = k0 + a_col;
+            const int row = m0 + a_row + RSTEP * i, k = k0 + a_col;
             ra[i] = (row < g.M && k < g.K4) ? P.A[(size_t)row * P.lda + k] : 0.f;
         }
 #pragma unroll
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
         float* da = s_a + buf * T::BM * kGemmAS;
         float* db = s_b + buf * kGemmBK * T::BS;
 #pragma unroll
-        for (int i = 0; i < T::A_PER; ++i) da[(a_row + 8 * i) * kGemmAS + a_col] = ra[i];
+        for (int i = 0; i < T::A_PER; ++i) da[(a_row + RSTEP * i) * kGemmAS + a_col] = ra[i];
 #pragma unroll
         for (int i = 0; i < T::B_PER; ++i) {
             const int e = tid + 256 * i;
@@ -127,18 +129,137 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
         }
 }
 
-// big tile (128 x 96) when it fills the chip, small tile (64 x 48) for the short-M / short-N training GEMMs
+// Latency configuration for the training batches (M = 256: a few dozen 64-row tiles on 256 CUs, one wave per SIMD, every
+// k-step waiting for its own LDS reads): workgroup tile 16 rows x 48 columns, and the FOUR WAVES SPLIT K - wave w takes
+// k-steps [8w, 8w+8) of every 128-wide slab - so there are 4x more workgroups and each wave walks a quarter of the
+// reduction; the four partial accumulators are added through LDS in a fixed order (deterministic).
+struct GemmSplitK {
+    static constexpr int BK = 128, BM = 16, NT = 3, BN = 48, BS = 48 + 16, AS = BK + 2;
+    static constexpr int A_PER = BM * BK / 256, B_PER = BK * BN / 256;
+    static constexpr int MAIN = 2 * BM * AS + 2 * BK * BS, RED = 4 * NT * 256;
+    static constexpr size_t LDS = (size_t)(MAIN > RED ? MAIN : RED) * 4;
+};
+
+inline __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
+    using T = GemmSplitK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_a = smem;                                  // [2][16][130]
+    float* s_b = smem + 2 * T::BM * T::AS;              // [2][128][64]
+    const int z = blockIdx.z;
+    const GemmProblem P = z == 0 ? g.p[0] : (z == 1 ? g.p[1] : g.p[2]);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
+    const int kmax = g.K ? g.K : g.K4;
+    float ra[T::A_PER], rb[T::B_PER];
+    const int a_col = tid % T::BK, a_row = tid / T::BK;
+    auto load_slab = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < T::A_PER; ++i) {
+            const int row = m0 + a_row + 2 * i, k = k0 + a_col;
+            ra[i] = (row < g.M && k < g.K4) ? P.A[(size_t)row * P.lda + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < T::B_PER; ++i) {
+            const int e = tid + 256 * i;
+            const int kr = e / T::BN, c = e - kr * T::BN;
+            const int k = k0 + kr, n = n0 + c;
+            rb[i] = (k < kmax && n < P.NS) ? P.W[(size_t)k * P.NS + n] : 0.f;
+        }
+    };
+    auto store_slab = [&](int buf) {
+        float* da = s_a + buf * T::BM * T::AS;
+        float* db = s_b + buf * T::BK * T::BS;
+#pragma unroll
+        for (int i = 0; i < T::A_PER; ++i) da[(a_row + 2 * i) * T::AS + a_col] = ra[i];
+#pragma unroll
+        for (int i = 0; i < T::B_PER; ++i) {
+            const int e = tid + 256 * i;
+            const int kr = e / T::BN, c = e - kr * T::BN;
+            db[kr * T::BS + c] = rb[i];
+        }
+    };
+    f32x4 acc[T::NT];
+#pragma unroll
+    for (int j = 0; j < T::NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nslab = (g.K4 + T::BK - 1) / T::BK;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        if (s + 1 < nslab) load_slab((s + 1) * T::BK);
+        const float* sa = s_a + (s & 1) * T::BM * T::AS + lr * T::AS + kq + wave * 32;
+        const float* sb = s_b + (s & 1) * T::BK * T::BS + (kq + wave * 32) * T::BS + lr;
+        float av[8], bv[8][T::NT];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            av[ks] = sa[ks * 4];
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) bv[ks][j] = sb[ks * 4 * T::BS + j * 16];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int j = 0; j < T::NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks][j], acc[j], 0, 0, 0);
+        if (s + 1 < nslab) store_slab((s + 1) & 1);
+        __syncthreads();
+    }
+    // partial accumulators -> LDS [wave][tile][lane] (the operand buffers are free after the last barrier)
+    f32x4* s_r = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int j = 0; j < T::NT; ++j) s_r[(wave * T::NT + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wave < T::NT) {
+        const int j = wave;
+        f32x4 v = s_r[(0 * T::NT + j) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { const f32x4 u = s_r[(q * T::NT + j) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        const int col = n0 + j * 16 + lr;
+        if (col < g.N) {
+            const float bvv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + kq * 4 + r;
+                if (row < g.M) {
+                    float o = v[r] + bvv;
+                    if (g.relu) o = fmaxf(o, 0.f);
+                    P.C[(size_t)row * P.ldc + col] = o;
+                }
+            }
+        }
+    }
+}
+
+inline hipError_t gemm_set_attrs() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<2, 6, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)GemmTile<2, 6, 32>::LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<1, 3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)GemmTile<1, 3, 32>::LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_splitk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)GemmSplitK::LDS);
+}
+
+// big tile (128 x 96) when it fills the chip, small tile (64 x 48) for the short-M / short-N GEMMs, and the split-K
+// latency configuration when even that leaves most CUs without a workgroup (training batches)
 inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
     if (g.M <= 0) return;
-    using Big = GemmTile<2, 6>;
-    using Small = GemmTile<1, 3>;
+    using Big = GemmTile<2, 6, 32>;
+    using Small = GemmTile<1, 3, 32>;
+    using Lat = GemmSplitK;
     const long big_wgs = (long)((g.M + Big::BM - 1) / Big::BM) * ((g.N + Big::BN - 1) / Big::BN) * nproblems;
+    const long small_wgs = (long)((g.M + Small::BM - 1) / Small::BM) * ((g.N + Small::BN - 1) / Small::BN) * nproblems;
     if (big_wgs >= 192) {
         dim3 grid((g.M + Big::BM - 1) / Big::BM, (g.N + Big::BN - 1) / Big::BN, nproblems);
-        hipLaunchKernelGGL((gemm_mfma_kernel<2, 6>), grid, dim3(256), Big::LDS, st, g);
-    } else {
+        hipLaunchKernelGGL((gemm_mfma_kernel<2, 6, 32>), grid, dim3(256), Big::LDS, st, g);
+    } else if (small_wgs > 256) {
         dim3 grid((g.M + Small::BM - 1) / Small::BM, (g.N + Small::BN - 1) / Small::BN, nproblems);
-        hipLaunchKernelGGL((gemm_mfma_kernel<1, 3>), grid, dim3(256), Small::LDS, st, g);
+        hipLaunchKernelGGL((gemm_mfma_kernel<1, 3, 32>), grid, dim3(256), Small::LDS, st, g);
+    } else {
+        dim3 grid((g.M + Lat::BM - 1) / Lat::BM, (g.N + Lat::BN - 1) / Lat::BN, nproblems);
+        hipLaunchKernelGGL(gemm_splitk_kernel, grid, dim3(256), Lat::LDS, st, g);
     }
 }
 

@@ -325,8 +325,7 @@ static int set_kernel_attrs() {
     SCS_HIP(conv_set_attr<CfgConv3>());
     SCS_HIP(conv_set_attr<CfgConv4>());
     SCS_HIP(conv_set_attr<CfgConv5>());
-    SCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmTile<2, 6>::LDS));
-    SCS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GemmTile<1, 3>::LDS));
+    SCS_HIP(gemm_set_attrs());
     return SCS_OK;
 }
 

@@ -248,55 +248,75 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
 }
 
 
-// BN batch statistics from the per-(patch band, channel) float sums the conv kernels leave behind: one block per
-// (channel, tower) adds the `units` partials in double in a fixed order, then mean, inv_std = 1/sqrt(var + eps) and the
-// running averages in the arena (alpha 0.1)
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* part, int units, int n, int C, int pix, float* stats, int layer,
-                                                             float* params, int bn_off0, int tower_stride) {
+// Training-mode BN + ReLU (+ 2x2 max-pool, + dropout) in one pass per (channel, tower, batch slice) workgroup.
+// Every workgroup first finishes the channel's batch statistics from the per-(patch band, channel) float sums the conv
+// kernels left behind - `units` partials added in double, in a fixed order - then applies
+//   y = gamma*(z-mean)*inv_std + beta,  inv_std = 1/sqrt(var + eps)   (Lasagne BatchNormLayer, nets.py:172-177)
+// to its slice.  Slice 0 also publishes mean / inv_std for the backward pass and moves the running averages in the
+// arena (alpha 0.1).
+template <bool POOL, int H>
+__global__ __launch_bounds__(256) void bn_relu_kernel(CPtr3 Z, Ptr3 out, int n, int C, const float* part, int units, float* stats, int layer,
+                                                     float* params, int bn_off0, int tower_stride, const uint8_t* mask) {
     __shared__ double s_red[4];
-    const int c = blockIdx.x, t = blockIdx.y;
-    const float2* __restrict__ p = reinterpret_cast<const float2*>(part) + (size_t)t * units * C + c;
-    double s = 0, q = 0;
-    for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; s += v.x; q += v.y; }
-    s = block_sum(s, s_red);
-    q = block_sum(q, s_red);
-    if (threadIdx.x) return;
-    const double total = (double)n * pix;
-    const double mean = s / total, var = fmax(q / total - mean * mean, 0.0);
-    const double inv = 1.0 / sqrt(var + (double)kBnEps);
-    float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
-    st[c] = (float)mean; st[64 + c] = (float)inv;
-    float* bn = params + bn_off0 + t * tower_stride;           // beta, gamma, mean, inv_std
-    bn[2 * C + c] = (1.f - kBnAlpha) * bn[2 * C + c] + kBnAlpha * (float)mean;
-    bn[3 * C + c] = (1.f - kBnAlpha) * bn[3 * C + c] + kBnAlpha * (float)inv;
-}
-
-// y = gamma*(z-mean)*inv_std + beta; ReLU; optional 2x2 max-pool; optional dropout (x * mask * 2) -> next input
-template <bool POOL>
-__global__ __launch_bounds__(256) void bn_relu_kernel(CPtr3 Z, Ptr3 out, int n, int C, int H, const float* stats, int layer,
-                                                     const float* params, int bn_off0, int tower_stride, const uint8_t* mask) {
-    const int t = blockIdx.y;
+    __shared__ float s_mi[2];
+    const int c = blockIdx.x, t = blockIdx.y, sp = blockIdx.z, split = gridDim.z;
+    constexpr int pix = H * H;
+    {
+        const float2* __restrict__ p = reinterpret_cast<const float2*>(part) + (size_t)t * units * C + c;
+        double s = 0, q = 0;
+        for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; s += v.x; q += v.y; }
+        s = block_sum(s, s_red);
+        q = block_sum(q, s_red);
+        if (threadIdx.x == 0) {
+            const double total = (double)n * pix;
+            const double mean = s / total, var = fmax(q / total - mean * mean, 0.0);
+            const double inv = 1.0 / sqrt(var + (double)kBnEps);
+            s_mi[0] = (float)mean; s_mi[1] = (float)inv;
+            if (sp == 0) {
+                float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
+                st[c] = (float)mean; st[64 + c] = (float)inv;
+                float* bn = params + bn_off0 + t * tower_stride;           // beta, gamma, mean, inv_std
+                bn[2 * C + c] = (1.f - kBnAlpha) * bn[2 * C + c] + kBnAlpha * (float)mean;
+                bn[3 * C + c] = (1.f - kBnAlpha) * bn[3 * C + c] + kBnAlpha * (float)inv;
+            }
+        }
+        __syncthreads();
+    }
+    const float* bn = params + bn_off0 + t * tower_stride;
+    const float sc = bn[C + c] * s_mi[1], sh = bn[c] - s_mi[0] * sc;
     const float* __restrict__ z = sel3(Z.p, t);
     float* __restrict__ o = sel3(out.p, t);
-    const float* st = stats + ((size_t)(t * kConvs + layer) * 4) * 64;
-    const float* bn = params + bn_off0 + t * tower_stride;
-    const int HO = POOL ? H / 2 : H, opix = HO * HO, pix = H * H;
-    const long total = (long)n * C * opix;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long nc = e / opix;
-        const int r = (int)(e - nc * opix), c = (int)(nc % C);
-        const float sc = bn[C + c] * st[64 + c], sh = bn[c] - st[c] * sc;
-        float v;
-        if (POOL) {
-            const int wy = r / HO, wx = r - wy * HO;
-            const float* zp = z + nc * pix + (2 * wy) * H + 2 * wx;
-            v = fmaxf(fmaxf(fmaf(zp[0], sc, sh), fmaf(zp[1], sc, sh)), fmaxf(fmaf(zp[H], sc, sh), fmaf(zp[H + 1], sc, sh)));
-        } else {
-            v = fmaf(z[nc * pix + r], sc, sh);
+    const int per = (n + split - 1) / split, n0 = min(n, sp * per), n1 = min(n, n0 + per);
+    if constexpr (POOL) {
+        constexpr int HO = H / 2, W = HO * HO;
+        const int total = (n1 - n0) * W;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int ni = n0 + idx / W, wdx = idx % W, wy = wdx / HO, wx = wdx - wy * HO;
+            const size_t plane = (size_t)ni * C + c;
+            const float* zp = z + plane * pix + (2 * wy) * H + 2 * wx;
+            const float2 r0 = *reinterpret_cast<const float2*>(zp), r1 = *reinterpret_cast<const float2*>(zp + H);
+            const float m = fmaxf(fmaxf(fmaf(r0.x, sc, sh), fmaf(r0.y, sc, sh)), fmaxf(fmaf(r1.x, sc, sh), fmaf(r1.y, sc, sh)));
+            o[plane * W + wdx] = fmaxf(m, 0.f);
         }
-        v = fmaxf(v, 0.f);
-        if (mask) v = mask[(size_t)t * n * kFlat + e] ? v * 2.f : 0.f;
-        o[e] = v;
+    } else if constexpr (pix % 4 == 0) {
+        constexpr int Q = pix / 4;
+        const int total = (n1 - n0) * Q;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int ni = n0 + idx / Q, q = idx % Q;
+            const size_t plane = (size_t)ni * C + c;
+            const float4 v = reinterpret_cast<const float4*>(z + plane * pix)[q];
+            reinterpret_cast<float4*>(o + plane * pix)[q] = make_float4(fmaxf(fmaf(v.x, sc, sh), 0.f), fmaxf(fmaf(v.y, sc, sh), 0.f),
+                                                                      fmaxf(fmaf(v.z, sc, sh), 0.f), fmaxf(fmaf(v.w, sc, sh), 0.f));
+        }
+    } else {
+        const int total = (n1 - n0) * pix;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int ni = n0 + idx / pix, e = idx % pix;
+            const size_t at = ((size_t)ni * C + c) * pix + e;
+            float v = fmaxf(fmaf(z[at], sc, sh), 0.f);
+            if (mask) v = mask[(size_t)t * n * kFlat + at] ? v * 2.f : 0.f;     // dropout in front of d1 (conv5: C*pix = 540)
+            o[at] = v;
+        }
     }
 }
 
@@ -783,17 +803,21 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         }
         const int C = kCout[i], Hh = kHout[i];
         constexpr int kStatBands[kConvs] = {1, TF2::NB, TF3::NB, TF4::NB, TF5::NB};
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, n * kStatBands[i], n, C, Hh * Hh, w->stats, i, P,
-                           T0.bn[i], kTowerFloats);
         Ptr3 out;
         for (int t = 0; t < kTowers; ++t) out.p[t] = (i == kConvs - 1) ? w->H5[t] : w->X[t][i + 1];
-        const long tot = (long)n * C * (kPool[i] ? (Hh / 2) * (Hh / 2) : Hh * Hh);
-        dim3 g(ew_grid(tot).x, kTowers);
-        if (kPool[i])
-            hipLaunchKernelGGL(bn_relu_kernel<true>, g, dim3(256), 0, st, c3(w->Z, i), out, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats, (const uint8_t*)nullptr);
-        else
-            hipLaunchKernelGGL(bn_relu_kernel<false>, g, dim3(256), 0, st, c3(w->Z, i), out, n, C, Hh, w->stats, i, P, T0.bn[i], kTowerFloats,
-                               (i == kConvs - 1) ? mask5 : (const uint8_t*)nullptr);
+        const int split = max(1, min(n, (int)((long)n * Hh * Hh / 8192)));
+        auto bn_fwd = [&](auto pool_tag, auto h_tag) {
+            constexpr bool PL = decltype(pool_tag)::value;
+            constexpr int HH = decltype(h_tag)::value;
+            hipLaunchKernelGGL((bn_relu_kernel<PL, HH>), dim3(C, kTowers, split), dim3(256), 0, st, c3(w->Z, i), out, n, C, w->stat_part,
+                               n * kStatBands[i], w->stats, i, P, T0.bn[i], kTowerFloats, (i == kConvs - 1) ? mask5 : (const uint8_t*)nullptr);
+        };
+        using std::integral_constant;
+        if (i == 0) bn_fwd(integral_constant<bool, false>{}, integral_constant<int, 30>{});
+        else if (i == 1) bn_fwd(integral_constant<bool, true>{}, integral_constant<int, 28>{});
+        else if (i == 2) bn_fwd(integral_constant<bool, false>{}, integral_constant<int, 12>{});
+        else if (i == 3) bn_fwd(integral_constant<bool, true>{}, integral_constant<int, 10>{});
+        else bn_fwd(integral_constant<bool, false>{}, integral_constant<int, 3>{});
     }
     // dense head (weights straight from the arena: [K][N] row-major)
     GemmArgs g{};

@@ -168,3 +168,67 @@ def test_full_size_properties(handle):
     idx = np.arange(0, n, n // 16)[:16]
     ref = O.forward(P.load_params(WEIGHTS), ax[idx], co[idx], sa[idx], at[idx])
     assert np.abs(p1.cpu().numpy()[idx] - ref).max() < PROB_TOL
+
+
+def test_error_codes_and_call_order(handle):
+    """C-ABI error behaviour (include/scs.h): negative status + text, never an abort; the handle stays usable."""
+    import ctypes
+    from cnn_cort import _hip
+    lib = handle.lib
+    g = gold('g1_random.npz')
+    d = [dev(g[k][:4]) for k in ('ax', 'co', 'sa', 'atlas')]
+    lab = torch.empty((4,), dtype=torch.int32, device='cuda:0')
+    # call order: a fresh handle has no parameters
+    h2 = _hip.Handle(0)
+    try:
+        rc = lib.scs_forward(h2.h, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 4, None, lab.data_ptr(), None)
+        assert rc == -3 and b'scs_set_params' in lib.scs_last_error()
+        with pytest.raises(_hip.ScsError):
+            h2.get_params()
+        # wrong arena size
+        bad = np.zeros(100, np.float32)
+        assert lib.scs_set_params(h2.h, bad.ctypes.data, bad.size) == -1
+    finally:
+        h2.close()
+    # bad arguments on a good handle
+    assert lib.scs_forward(handle.h, None, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 4, None, lab.data_ptr(), None) == -1
+    assert lib.scs_forward(handle.h, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), -1, None, lab.data_ptr(), None) == -1
+    assert lib.scs_forward(None, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 4, None, lab.data_ptr(), None) == -1
+    assert lib.scs_forward_volume(handle.h, d[0].data_ptr(), 0, 4, 4, d[1].data_ptr(), d[2].data_ptr(), 4, None, lab.data_ptr(), None) == -1
+    assert lib.scs_last_error() != b''
+    # ... and it still computes
+    _, labels = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'], want_probs=False)
+    check_labels(labels, g['probs'])
+
+
+def test_two_handles_on_two_streams(handle, weights):
+    """The library is re-entrant per handle: two handles driven from two HIP streams (and two host threads) at the
+    same time give the same bits as one handle alone."""
+    import threading
+    from cnn_cort import _hip, params as P
+    g = gold('g2_volume.npz')
+    ref_p, ref_l = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+    other = _hip.Handle(0)
+    other.set_params(P.params_to_flat(weights))
+    outs = {}
+
+    def work(name, h):
+        s = torch.cuda.Stream(device='cuda:0')
+        with torch.cuda.stream(s):
+            ins = [dev(g[k]) for k in ('ax', 'co', 'sa', 'atlas')]
+            n = ins[0].shape[0]
+            pr = torch.empty((n, 15), device='cuda:0')
+            lb = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+            for _ in range(5):
+                h.forward(ins[0], ins[1], ins[2], ins[3], n, pr, lb, s.cuda_stream)
+            s.synchronize()
+            outs[name] = (pr.cpu().numpy(), lb.cpu().numpy())
+
+    try:
+        th = [threading.Thread(target=work, args=('a', handle)), threading.Thread(target=work, args=('b', other))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    finally:
+        other.close()
+    for name in ('a', 'b'):
+        assert np.array_equal(outs[name][0], ref_p) and np.array_equal(outs[name][1], ref_l)

@@ -125,6 +125,11 @@ int scs_train_step(scs_handle h, const float* ax_dev, const float* co_dev, const
 int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n);
 int scs_grad_arena(scs_handle h, float** dev_ptr, size_t* n);
 
+/* Device address of the mean loss of the most recent scs_train_step (one float, valid once that step's work on its
+ * stream has completed).  Lets a training loop collect the per-batch losses with device-side copies and read them back
+ * once per epoch instead of synchronising every step (nolearn's train_loss = mean of the batch losses). */
+int scs_train_loss(scs_handle h, float** dev_ptr);
+
 /* lasagne.updates.adam over the whole arena (nets.py:236-237): t += 1, bias-corrected step size,
  * p -= a_t * m / (sqrt(v) + eps).  grad_scale multiplies the gradient first (1/world_size after a
  * sum all-reduce).  Then refreshes the inference operands. */

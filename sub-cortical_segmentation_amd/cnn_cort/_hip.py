@@ -37,6 +37,7 @@ SIGNATURES = {
     'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
     'scs_train_step': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
     'scs_param_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
+    'scs_train_loss': (_c.c_int, [_vp, _c.POINTER(_c.c_void_p)]),
     'scs_grad_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
     'scs_adam_apply': (_c.c_int, [_vp, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
     'scs_eval_batch': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.POINTER(_c.c_double),
@@ -157,6 +158,12 @@ class Handle:
                                        ctypes.addressof(loss) if want_loss else None, stream or None),
                'scs_train_step')
         return float(loss.value) if want_loss else None
+
+    def train_loss_ptr(self):
+        """Device address of the last train step's mean loss (float32)."""
+        p = ctypes.c_void_p()
+        _check(self.lib.scs_train_loss(self.h, ctypes.byref(p)), 'scs_train_loss')
+        return p.value
 
     def adam_apply(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0, stream=0):
         _check(self.lib.scs_adam_apply(self.h, lr, b1, b2, eps, grad_scale, stream or None), 'scs_adam_apply')

@@ -310,19 +310,23 @@ class Net:
         try:
             for ep in range(epochs or self.max_epochs):
                 t0 = time.time()
-                losses = []
                 starts = list(range(0, ntr, bs))
+                # batch losses are collected on the device and read back once per epoch (no per-step synchronisation)
+                loss_buf = torch.zeros((max(1, (len(starts) + world - 1) // world),), dtype=torch.float32, device=dev)
+                n_loss, loss_view = 0, None
                 for step, (lo, active) in enumerate(dist.shard_steps(starts, world, rank)):
-                    loss = None
                     if active:
                         hi = min(ntr, lo + bs)
                         self._step += 1
-                        loss = h.train_step(Xtr[0][lo:hi], Xtr[1][lo:hi], Xtr[2][lo:hi], Xtr[3][lo:hi], Xtr[4][lo:hi],
-                                            hi - lo, seed=(self.seed << 32) + self._step * 131 + rank, stream=stream)
+                        h.train_step(Xtr[0][lo:hi], Xtr[1][lo:hi], Xtr[2][lo:hi], Xtr[3][lo:hi], Xtr[4][lo:hi], hi - lo,
+                                     seed=(self.seed << 32) + self._step * 131 + rank, want_loss=False, stream=stream)
+                        if loss_view is None:
+                            loss_view = dist.wrap_device_floats(h.train_loss_ptr(), 1, self._dev())
+                        loss_buf[n_loss:n_loss + 1].copy_(loss_view, non_blocking=True)
+                        n_loss += 1
                     scale = dist.allreduce_grads(h, active, stream, n_active=dist.active_ranks(len(starts), step, world))
                     h.adam_apply(lr=self.update_learning_rate, grad_scale=scale, stream=stream)
-                    if loss is not None:
-                        losses.append(loss)
+                losses = loss_buf[:n_loss].cpu().numpy().astype(np.float64).tolist()
                 self._dev_newer = True
                 dist.sync_params(h)            # reconcile per-rank BN running statistics (no-op on one GPU)
                 vloss, vcorrect = 0.0, 0

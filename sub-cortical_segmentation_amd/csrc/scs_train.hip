@@ -763,7 +763,8 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     constexpr TowerOff T0 = tower_off(0);
     const float* xin[kTowers] = {ax, co, sa};
 
-    SCS_HIP(hipMemsetAsync(G, 0, (size_t)SCS_N_PARAMS * sizeof(float), st));
+    // every trainable entry of the gradient arena is overwritten below; the rest (BN running statistics, PReLU alphas)
+    // has been zero since the arena was allocated
 
     // ---- masks
     const uint8_t* masks = masks_dev;
@@ -966,6 +967,13 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         SCS_HIP(hipMemcpyAsync(loss_host, w->loss_dev, sizeof(float), hipMemcpyDeviceToHost, st));
         SCS_HIP(hipStreamSynchronize(st));
     }
+    return SCS_OK;
+}
+
+int scs_train_loss(scs_handle h, float** dev_ptr) {
+    SCS_ARG(h && dev_ptr, "null pointer");
+    if (!h->tws || !h->tws->loss_dev) { set_error("scs_train_loss before scs_train_step"); return SCS_ERR_STATE; }
+    *dev_ptr = h->tws->loss_dev;
     return SCS_OK;
 }
 

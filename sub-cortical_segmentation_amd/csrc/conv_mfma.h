@@ -76,7 +76,7 @@ struct ConvCfg {
     static_assert(NB_ == 1 || G_ == 1, "bands: one patch per workgroup");
     static_assert(PLANE_ >= HINB * HIN_, "plane stride too small");
     static_assert(LDS_BYTES * WPS_ <= 160 * 1024, "LDS budget (WPS workgroups per CU)");
-    static_assert(NW_ == 4 || (SRC_ != SRC_CONV1 && SRC_ != SRC_VOLUME), "the fused conv1 stage is written for 4 waves");
+    static_assert(NTH >= 8 * XROWS || (SRC_ != SRC_CONV1 && SRC_ != SRC_VOLUME), "raw patch rows are staged in one pass");
 };
 
 struct ConvArgs {
@@ -135,7 +135,7 @@ __device__ __forceinline__ float max_quad(float v) {     // max over the 4 lanes
 // conv1 (1 -> 20 channels, 9 taps) on the matrix cores as well: K = 9 padded to 12 (3 k-steps, tap index on the
 // k axis), N = 20 = 16 + 4, M = ROWS*30 pixels.  Raw tile rows in LDS -> 20 planes of ROWS x 30 in LDS with bias +
 // ReLU (nets.py:171).  w1p: [12][16] main weights, [12][4] leftover weights, [20] bias (rows 9..11 are zero).
-template <int PLANE, int ROWS>
+template <int PLANE, int ROWS, int NW = 4>
 __device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, const float* __restrict__ s_w1,
                                              float* __restrict__ s_out, int wave, int lane) {
     constexpr int NPIX = ROWS * 30, T1 = (NPIX + 15) / 16;
@@ -152,10 +152,10 @@ __device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, cons
     const float bias_m = s_w1[240 + lr], bias_l = s_w1[240 + 16 + kq];
     // all of a wave's tiles are independent straight-line chains (clamped indices, predicated stores), so the
     // scheduler overlaps their LDS-read -> MFMA -> lane-exchange -> LDS-write latencies
-    constexpr int TW = (T1 + 3) / 4;
+    constexpr int TW = (T1 + NW - 1) / NW;
 #pragma unroll
     for (int jj = 0; jj < TW; ++jj) {
-        const int t = wave + 4 * jj;
+        const int t = wave + NW * jj;
         const int tc = min(t, T1 - 1);
         const int p = min(tc * 16 + lr, NPIX - 1), y = p / 30, x = p - y * 30;
         f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         // conv1 operands and the raw rows are fetched together: one global round trip, not two
         const float* __restrict__ w1g = pick3(a.w1, tower);
         const float w1a = w1g[min(tid, kW1Floats - 1)];
-        const float w1b = w1g[min(tid + 256, kW1Floats - 1)];
+        const float w1b = w1g[min(tid + C::NTH, kW1Floats - 1)];
         if constexpr (C::SRC == SRC_CONV1) {
             const float4* __restrict__ src = reinterpret_cast<const float4*>(insrc + (size_t)g0 * 1024 + band * C::HOB * 32);
             if (tid < C::XROWS * 8) reinterpret_cast<float4*>(s_x)[tid] = src[tid];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             // [x-16+i][y][z-16+j], sagittal [x][y-16+i][z-16+j]
             const int cx = a.centers[(size_t)g0 * 3 + 0], cy = a.centers[(size_t)g0 * 3 + 1], cz = a.centers[(size_t)g0 * 3 + 2];
             const float* __restrict__ vol = insrc;
-            for (int e = tid; e < C::XROWS * 32; e += 256) {
+            for (int e = tid; e < C::XROWS * 32; e += C::NTH) {
                 const int i = band * C::HOB + (e >> 5), j = e & 31;
                 int vx, vy, vz;
                 if (tower == 0) { vx = cx - 16 + i; vy = cy - 16 + j; vz = cz; }
@@ -315,12 +315,12 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             }
         }
         float* s_w1 = s_x + C::XS_ROWS_FLOATS + 4;
-        s_w1[tid] = w1a;                                   // kW1Floats = 260: 256 + 4
-        if (tid + 256 < kW1Floats) s_w1[tid + 256] = w1b;
+        if (tid < kW1Floats) s_w1[tid] = w1a;              // kW1Floats = 260: two loads per lane at 256 threads
+        if (tid + C::NTH < kW1Floats) s_w1[tid + C::NTH] = w1b;
         __syncthreads();
         if constexpr (C::STAMP) { if (tid == 0) stp[5] = __builtin_amdgcn_s_memtime(); }
 #if !(defined(SCS_ABLATE) && SCS_ABLATE == 3)
-        conv1_to_lds<C::PLANE, C::HINB>(s_x, s_w1, s_in, wave, lane);
+        conv1_to_lds<C::PLANE, C::HINB, C::NW>(s_x, s_w1, s_in, wave, lane);
 #endif
     }
 

@@ -355,6 +355,9 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             x = r - y * C::HO;
         }
         abase[j] = (g * C::CIN + kq) * C::PLANE + y * C::WIN + x;
+#if defined(SCS_ABLATE) && SCS_ABLATE == 6
+        abase[j] = (g * C::CIN + kq) * C::PLANE + lr + 16 * j;      // conflict-free A reads (wrong data): what would it buy?
+#endif
     }
 
     f32x4 acc[C::TPW][C::NT16 > 0 ? C::NT16 : 1], acc4[C::TPW][C::NT4 > 0 ? C::NT4 : 1];

@@ -2,7 +2,7 @@
 // per-phase s_memtime stamps of diagnostic (STAMP) instantiations.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I sub-cortical_segmentation_amd/csrc tools/kbench.hip -o build/kbench
 // Ablation builds: add -DSCS_ABLATE=1 (no MFMA) / 2 (no activation reads) / 3 (no conv1) / 4 (no 4-wide epilogue) /
-// 5 (no copy-out); their outputs are wrong on purpose, only the timings mean something.
+// 5 (no copy-out) / 6 (conflict-free activation reads); their outputs are wrong on purpose, only the timings mean something.
 // Inputs are random (rule 25); outputs are not checked here (tests/ do that through the C ABI).
 #include <cstdio>
 #include <cstdlib>

@@ -193,6 +193,57 @@ class Net:
                 raise ValueError('inputs disagree on the number of samples')
         return n
 
+    def _device_slices(self, X, n):
+        """Yield (lo, hi, [ax, co, sa, atlas] on the device) in slices of _SUPER patches.  Host arrays are uploaded
+        by a helper thread on its own stream, one slice ahead, so that the transfer of slice i+1 runs under the
+        kernels of slice i (1.23 GB cross PCIe per 100 000 patches)."""
+        torch = self._torch()
+        bounds = [(lo, min(n, lo + _SUPER)) for lo in range(0, n, _SUPER)]
+        if len(bounds) <= 1 or not any(isinstance(X[k], np.ndarray) for k in ('in1', 'in2', 'in3', 'in4')):
+            for lo, hi in bounds:
+                yield lo, hi, self._as_device_inputs(X, lo, hi)
+            return
+        import queue
+        import threading
+        dev = self._dev()
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        q = queue.Queue(maxsize=2)
+
+        def uploader():
+            try:
+                with torch.cuda.stream(side):
+                    for lo, hi in bounds:
+                        ts = self._as_device_inputs(X, lo, hi)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        q.put((lo, hi, ts, ev))
+                q.put(None)
+            except BaseException as e:            # surfaced in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=uploader, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                lo, hi, ts, ev = item
+                main.wait_event(ev)
+                for t in ts:
+                    t.record_stream(main)
+                yield lo, hi, ts
+        finally:
+            while th.is_alive():                  # drain so that the helper can finish if the consumer stopped early
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+
     def _forward(self, X, want_probs):
         torch = self._torch()
         n = self._check_X(X)
@@ -201,16 +252,24 @@ class Net:
         probs = np.empty((n, 15), np.float32) if want_probs else None
         labels = np.empty((n,), np.int64)
         stream = torch.cuda.current_stream(self._dev()).cuda_stream
-        for lo in range(0, n, _SUPER):
-            hi = min(n, lo + _SUPER)
-            ax, co, sa, at = self._as_device_inputs(X, lo, hi)
+        pending = None                                  # outputs of the previous slice, copied back one slice late
+        for lo, hi, (ax, co, sa, at) in self._device_slices(X, n):
             d_probs = torch.empty((hi - lo, 15), dtype=torch.float32, device=dev) if want_probs else None
             d_lab = torch.empty((hi - lo,), dtype=torch.int32, device=dev)
             h.forward(ax, co, sa, at, hi - lo, d_probs, d_lab, stream)
-            if want_probs:
-                probs[lo:hi] = d_probs.cpu().numpy()
-            labels[lo:hi] = d_lab.cpu().numpy()
+            if pending is not None:
+                self._collect(pending, probs, labels)
+            pending = (lo, hi, d_probs, d_lab)
+        if pending is not None:
+            self._collect(pending, probs, labels)
         return probs, labels
+
+    @staticmethod
+    def _collect(pending, probs, labels):
+        lo, hi, d_probs, d_lab = pending
+        if d_probs is not None:
+            probs[lo:hi] = d_probs.cpu().numpy()
+        labels[lo:hi] = d_lab.cpu().numpy()
 
     def predict_proba(self, X):
         """float32 [N,15] softmax outputs (deterministic forward) - base.py:435-438."""

@@ -254,22 +254,20 @@ def load_patch_batch(scan_name, options, datatype=np.float32):
         yield views[0], views[1], views[2], atlas_rows[i:i + bs], centers
 
 
-def test_scan(net, test_scan, options):
-    """Segment one T1 volume; writes out_subcortical_{prob,seg_prec,rawseg}.nii.gz next to it and returns the
-    elapsed minutes (base.py:401-458)."""
-    s_time = time.time()
-    image_path = os.path.dirname(test_scan)
-    t1, raw, image_norm, centers, atlas_rows = _scan_inputs(test_scan, options)
+def _scan_predict(net, inputs, options):
+    t1, raw, image_norm, centers, atlas_rows = inputs
     want_probs = is_true(options.get('out_probabilities'))
-    image = np.zeros_like(raw)
-
     # the priors stay on the host; only the ROI rows travel (base.py:388-394 rule already applied)
-    labels, probs = net.predict_volume(np.ascontiguousarray(image_norm, dtype=np.float32), centers,
-                                       atlas_rows=atlas_rows, want_probs=want_probs,
-                                       batch=options['test_batch_size'])
+    return net.predict_volume(np.ascontiguousarray(image_norm, dtype=np.float32), centers, atlas_rows=atlas_rows,
+                              want_probs=want_probs, batch=options['test_batch_size'])
+
+
+def _scan_outputs(image_path, inputs, labels, probs, options):
+    t1, raw, _, centers, _ = inputs
+    image = np.zeros_like(raw)
     x, y, z = centers[:, 0], centers[:, 1], centers[:, 2]
     image[x, y, z] = labels
-    if want_probs:
+    if probs is not None:
         # the reference fills a dense float64 [X,Y,Z,15] array (base.py:417,438) and saves it; the same file is
         # written here from the ROI rows alone (1.5 GB dense for a 256x256x192 subject, ~99 % zeros)
         nifti.save_sparse(os.path.join(image_path, 'out_subcortical_prob.nii.gz'), tuple(raw.shape) + (15,),
@@ -278,7 +276,50 @@ def test_scan(net, test_scan, options):
         nifti.save(post_process_segmentation(image_path, image), os.path.join(image_path, 'out_subcortical_seg_prec.nii.gz'), like=t1)
     else:
         nifti.save(image, os.path.join(image_path, 'out_subcortical_rawseg.nii.gz'), like=t1)
+
+
+def test_scan(net, test_scan, options):
+    """Segment one T1 volume; writes out_subcortical_{prob,seg_prec,rawseg}.nii.gz next to it and returns the
+    elapsed minutes (base.py:401-458)."""
+    s_time = time.time()
+    inputs = _scan_inputs(test_scan, options)
+    labels, probs = _scan_predict(net, inputs, options)
+    _scan_outputs(os.path.dirname(test_scan), inputs, labels, probs, options)
     return (time.time() - s_time) / 60.0
+
+
+def test_cohort(net, scan_paths, options, shard=True):
+    """test_scan over a list of T1 paths (the loop of train_model.py:74-78) as a three-stage pipeline: while the
+    GPU segments subject i, helper threads already read subjects i+1 and i+2 (gunzip of the prior is the longest
+    stage) and another writes the files of subject i-1.  Same files as calling test_scan per path.  Under torchrun every
+    rank takes every world_size-th subject (no collective).  Returns [(path, minutes)] for this rank's subjects,
+    minutes = that subject's own load + predict + write time."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import dist
+    paths = dist.shard_list(list(scan_paths)) if shard else list(scan_paths)
+    out = []
+    if not paths:
+        return out
+
+    def timed(fn, *a):
+        t0 = time.time()
+        r = fn(*a)
+        return r, time.time() - t0
+
+    ahead = 2                                      # subjects being read while one is on the GPU
+    with ThreadPoolExecutor(ahead) as loader, ThreadPoolExecutor(1) as writer:
+        pending = [loader.submit(timed, _scan_inputs, p, options) for p in paths[:ahead]]
+        writes = []
+        for i, p in enumerate(paths):
+            inputs, t_load = pending.pop(0).result()
+            if i + ahead < len(paths):
+                pending.append(loader.submit(timed, _scan_inputs, paths[i + ahead], options))
+            (labels, probs), t_gpu = timed(_scan_predict, net, inputs, options)
+            writes.append((p, t_load + t_gpu, writer.submit(timed, _scan_outputs, os.path.dirname(p), inputs, labels, probs, options)))
+        for p, t, fut in writes:
+            _, t_write = fut.result()
+            out.append((p, (t + t_write) / 60.0))
+    return out
 
 
 def post_process_mask(input_mask, atlas):

@@ -270,3 +270,41 @@ def test_early_stopping_reproduces_the_shipped_history():
             stopped = hist[i]['epoch']
             break
     assert hook.best_valid_epoch == 42 and stopped == 62 and net.restored
+
+
+class _StubNet:
+    """Deterministic stand-in for the GPU net: labels / probabilities are functions of the centre and the prior row."""
+
+    def predict_volume(self, volume, centers, atlas4d=None, want_probs=False, batch=None, atlas_rows=None):
+        c = np.asarray(centers)
+        labels = (c.sum(1) + np.round(volume[c[:, 0], c[:, 1], c[:, 2]] * 3).astype(np.int64)) % 15
+        probs = None
+        if want_probs:
+            probs = (atlas_rows + 0.01 * (labels[:, None] == np.arange(15)[None, :])).astype(np.float32)
+        return labels.astype(np.int64), probs
+
+
+def test_cohort_pipeline_writes_the_same_files_as_the_loop(tmp_path):
+    """test_cohort (loader / GPU / writer stages overlapped) == calling test_scan per subject, file for file."""
+    import gzip
+    opts = {'crop': 'True', 'debug': 'False', 'test_batch_size': 5000, 'out_probabilities': 'True', 'post_process': 'True',
+            'patch_size': [32, 32]}
+    paths = []
+    for i in range(3):
+        make_subject(str(tmp_path / 'a' / ('s%d' % i)), shape=(24, 22, 20), seed=40 + i)
+        make_subject(str(tmp_path / 'b' / ('s%d' % i)), shape=(24, 22, 20), seed=40 + i)
+        paths.append(('a/s%d/T1.nii.gz' % i, 'b/s%d/T1.nii.gz' % i))
+    net = _StubNet()
+    for a, _ in paths:
+        assert base.test_scan(net, str(tmp_path / a), opts) >= 0
+    res = base.test_cohort(net, [str(tmp_path / b) for _, b in paths], opts)
+    assert [p for p, _ in res] == [str(tmp_path / b) for _, b in paths] and all(m >= 0 for _, m in res)
+    for a, b in paths:
+        for f in ('out_subcortical_prob.nii.gz', 'out_subcortical_seg_prec.nii.gz'):
+            with gzip.open(str(tmp_path / os.path.dirname(a) / f)) as fa, gzip.open(str(tmp_path / os.path.dirname(b) / f)) as fb:
+                assert fa.read() == fb.read()
+    # a failing subject surfaces as an exception, not as a silently missing file
+    os.remove(str(tmp_path / 'b' / 's1' / 'tmp' / 'MNI_sub_probabilities.nii.gz'))
+    with pytest.raises(FileNotFoundError):
+        base.test_cohort(net, [str(tmp_path / b) for _, b in paths], opts)
+    assert base.test_cohort(net, [], opts) == []

@@ -58,6 +58,7 @@ def main():
     ap.add_argument('--no-gpu', action='store_true')
     ap.add_argument('--repeat', type=int, default=2)
     ap.add_argument('--post', action='store_true', help='also run post_process (largest-overlap component filter)')
+    ap.add_argument('--cohort', type=int, default=0, help='also time test_cohort (pipelined) against the test_scan loop on N subjects')
     args = ap.parse_args()
     shape = tuple(args.shape)
     opts = {'experiment': 'miccai2012_v1', 'net_verbose': 0, 'train_split': 0.25, 'max_epochs': 1, 'patience': 20,
@@ -103,6 +104,22 @@ def main():
             print('    %-55s %7.3f s  %5.1f %%' % ('other host work (allocation, scatter, casts)', rest, 100 * rest / total))
             sizes = {f: os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith('out_')}
             print('    outputs:', sizes)
+        if args.cohort:
+            import shutil
+            scans = [scan]
+            for i in range(1, args.cohort):
+                sub = os.path.join(d, 'subj%d' % i)
+                shutil.copytree(d, sub, ignore=shutil.ignore_patterns('subj*', 'out_*'))
+                scans.append(os.path.join(sub, 'T1.nii.gz'))
+            t0 = time.perf_counter()
+            for sc in scans:
+                base.test_scan(net, sc, opts)
+            t_loop = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            base.test_cohort(net, scans, opts)
+            t_pipe = time.perf_counter() - t0
+            print('--- cohort of %d subjects: test_scan loop %.2f s (%.2f s/subject), test_cohort %.2f s (%.2f s/subject)'
+                  % (len(scans), t_loop, t_loop / len(scans), t_pipe, t_pipe / len(scans)))
 
 
 if __name__ == '__main__':

@@ -23,15 +23,15 @@
 namespace scs {
 
 // ------------------------------------------------------------------------------------------- configurations
-using TF2 = ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_NCHW, 496, 2, 2>;
-using TF3 = ConvCfg<20, 40, 14, 2, EPI_RAW_STATS, SRC_NCHW, 208, 1, 2>;
+using TF2 = ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_NCHW, 180, 7, 4>;
+using TF3 = ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_NCHW, 208, 1, 4>;
 using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_NCHW, 144, 1, 4>;
-using TF5 = ConvCfg<40, 60, 5, 8, EPI_RAW_STATS, SRC_NCHW, 27, 1, 2>;
+using TF5 = ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_NCHW, 27, 1, 4>;
 // data gradients: input = dZ_i zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i
-using DG5 = ConvCfg<60, 40, 7, 8, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 1>;
+using DG5 = ConvCfg<60, 40, 7, 2, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 3>;
 using DG4 = ConvCfg<40, 40, 14, 1, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 3>;
 using DG3 = ConvCfg<40, 20, 16, 1, EPI_RAW, SRC_NCHW_PAD2, 144, 2, 4>;
-using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 544, 2, 3>;
+using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 256, 5, 4>;
 
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 constexpr bool kPool[kConvs] = {false, true, false, true, false};
@@ -129,7 +129,7 @@ static int train_ensure(scs_ctx* h, int n) {
                  o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
                  o_st = take((size_t)kTowers * kConvs * 4 * 64), o_at = take((size_t)5 * kFC1ld * c),
-                 o_sp = take((size_t)kTowers * c * 2 * 64 * 2);
+                 o_sp = take((size_t)kTowers * c * 8 * 64 * 2);      // up to 8 bands x 64 channels x (sum, sumsq)
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
     for (int t = 0; t < kTowers; ++t) {

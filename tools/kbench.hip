@@ -6,6 +6,7 @@
 // Inputs are random (rule 25); outputs are not checked here (tests/ do that through the C ABI).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "conv_mfma.h"
@@ -94,9 +95,43 @@ static void stamps(const char* name, int n) {
            epi_lds / nwg, epi_bar / nwg, (d[3] - epi_lds - epi_bar) / nwg);
 }
 
+// training-batch view: the forward (EPI_RAW_STATS) and data-gradient (SRC_NCHW_PAD2) configurations at n = batch size,
+// where a launch is only a few rounds of workgroups and latency per workgroup matters more than steady-state rate
+static void train_configs(int n, int rounds) {
+    const double c2 = 2822400.0, c3 = 1036800.0, c4 = 1440000.0, c5 = 194400.0;
+    for (int rep = 0; rep < 2; ++rep) {
+        run<ConvCfg<20, 20, 30, 1, EPI_RAW, SRC_NCHW, 496, 2, 2>>("TF2 NB2 WPS2 (shipped)", n, rounds, c2);
+        run<ConvCfg<20, 20, 30, 1, EPI_RAW, SRC_NCHW, 496, 2, 3>>("TF2 NB2 WPS3", n, rounds, c2);
+        run<ConvCfg<20, 20, 30, 1, EPI_RAW, SRC_NCHW, 272, 4, 4>>("TF2 NB4 WPS4", n, rounds, c2);
+        run<ConvCfg<20, 20, 30, 1, EPI_RAW, SRC_NCHW, 180, 7, 4>>("TF2 NB7 WPS4", n, rounds, c2);
+        run<ConvCfg<20, 40, 14, 2, EPI_RAW, SRC_NCHW, 208, 1, 2>>("TF3 G2 WPS2 (shipped)", n, rounds, c3);
+        run<ConvCfg<20, 40, 14, 1, EPI_RAW, SRC_NCHW, 208, 1, 4>>("TF3 G1 WPS4", n, rounds, c3);
+        run<ConvCfg<20, 40, 14, 1, EPI_RAW, SRC_NCHW, 112, 2, 4>>("TF3 G1 NB2 WPS4", n, rounds, c3);
+        run<ConvCfg<40, 40, 12, 1, EPI_RAW, SRC_NCHW, 144, 1, 4>>("TF4 G1 WPS4 (shipped)", n, rounds, c4);
+        run<ConvCfg<40, 40, 12, 1, EPI_RAW, SRC_NCHW, 112, 2, 4>>("TF4 G1 NB2 WPS4", n, rounds, c4);
+        run<ConvCfg<40, 60, 5, 8, EPI_RAW, SRC_NCHW, 27, 1, 2>>("TF5 G8 WPS2 (shipped)", n, rounds, c5);
+        run<ConvCfg<40, 60, 5, 2, EPI_RAW, SRC_NCHW, 27, 1, 4>>("TF5 G2 WPS4", n, rounds, c5);
+        run<ConvCfg<40, 60, 5, 1, EPI_RAW, SRC_NCHW, 27, 1, 4>>("TF5 G1 WPS4", n, rounds, c5);
+        run<ConvCfg<60, 40, 7, 8, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 1>>("DG5 G8 WPS1 (shipped)", n, rounds, c5);
+        run<ConvCfg<60, 40, 7, 2, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 3>>("DG5 G2 WPS3", n, rounds, c5);
+        run<ConvCfg<60, 40, 7, 1, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 4>>("DG5 G1 WPS4", n, rounds, c5);
+        run<ConvCfg<40, 40, 14, 1, EPI_RAW, SRC_NCHW_PAD2, 208, 1, 3>>("DG4 NB1 WPS3 (shipped)", n, rounds, c4);
+        run<ConvCfg<40, 40, 14, 1, EPI_RAW, SRC_NCHW_PAD2, 112, 2, 4>>("DG4 NB2 WPS4", n, rounds, c4);
+        run<ConvCfg<40, 40, 14, 1, EPI_RAW, SRC_NCHW_PAD2, 84, 3, 4>>("DG4 NB3 WPS4", n, rounds, c4);
+        run<ConvCfg<40, 20, 16, 1, EPI_RAW, SRC_NCHW_PAD2, 144, 2, 4>>("DG3 NB2 WPS4 (shipped)", n, rounds, c3);
+        run<ConvCfg<40, 20, 16, 1, EPI_RAW, SRC_NCHW_PAD2, 80, 7, 4>>("DG3 NB7 WPS4", n, rounds, c3);
+        run<ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 544, 2, 3>>("DG2 NB2 WPS3 (shipped)", n, rounds, c2);
+        run<ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 384, 3, 4>>("DG2 NB3 WPS4", n, rounds, c2);
+        run<ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 256, 5, 4>>("DG2 NB5 WPS4", n, rounds, c2);
+        run<ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 224, 6, 4>>("DG2 NB6 WPS4", n, rounds, c2);
+        printf("\n");
+    }
+}
+
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 4096;
     const int rounds = argc > 2 ? atoi(argv[2]) : 10;
+    if (argc > 3 && !strcmp(argv[3], "train")) { train_configs(n, rounds); return 0; }
     const double c12 = 162000.0 + 2822400.0, c3 = 1036800.0, c4 = 1440000.0, c5 = 194400.0;
     stamps<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 912, 1, 1, 1>>("conv12 NB1 WPS1", n);
     stamps<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 2, 1>>("conv12 NB2 WPS2", n);

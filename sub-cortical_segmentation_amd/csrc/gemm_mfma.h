@@ -130,21 +130,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
 }
 
 // Latency configuration for the training batches (M = 256: a few dozen 64-row tiles on 256 CUs, one wave per SIMD, every
-// k-step waiting for its own LDS reads): workgroup tile 16 rows x 48 columns, and the FOUR WAVES SPLIT K - wave w takes
-// k-steps [8w, 8w+8) of every 128-wide slab - so there are 4x more workgroups and each wave walks a quarter of the
-// reduction; the four partial accumulators are added through LDS in a fixed order (deterministic).
+// k-step waiting for its own operands): workgroup tile 16 rows x 48 columns, and the FOUR WAVES SPLIT K - wave w owns a
+// contiguous quarter of the k-steps.  Since no operand is shared between the waves there is nothing to stage: every lane
+// loads its own MFMA operands straight from global memory, up to 36 k-steps (36 + 108 loads) in flight at once, so a
+// K = 540 layer is ONE global round trip per wave instead of a slab pipeline.  The four partial accumulators are added
+// through LDS in a fixed order (deterministic).
 struct GemmSplitK {
-    static constexpr int BK = 128, BM = 16, NT = 3, BN = 48, BS = 48 + 16, AS = BK + 2;
-    static constexpr int A_PER = BM * BK / 256, B_PER = BK * BN / 256;
-    static constexpr int MAIN = 2 * BM * AS + 2 * BK * BS, RED = 4 * NT * 256;
-    static constexpr size_t LDS = (size_t)(MAIN > RED ? MAIN : RED) * 4;
+    static constexpr int BM = 16, NT = 3, BN = 48, CH = 36;      // CH = k-steps in flight per wave
+    static constexpr size_t LDS = (size_t)4 * NT * 256 * 4;
 };
 
 inline __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
     using T = GemmSplitK;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_a = smem;                                  // [2][16][130]
-    float* s_b = smem + 2 * T::BM * T::AS;              // [2][128][64]
+    __shared__ f32x4 s_r[4 * T::NT * 64];
     const int z = blockIdx.z;
     const GemmProblem P = z == 0 ? g.p[0] : (z == 1 ? g.p[1] : g.p[2]);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -152,61 +150,34 @@ inline __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) 
     const int lr = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
     const int kmax = g.K ? g.K : g.K4;
-    float ra[T::A_PER], rb[T::B_PER];
-    const int a_col = tid % T::BK, a_row = tid / T::BK;
-    auto load_slab = [&](int k0) {
+    const int steps = g.K4 / 4, per = (steps + 3) / 4;
+    const int s_beg = min(steps, wave * per), s_end = min(steps, s_beg + per);
+    const int row = m0 + lr;
+    const bool row_ok = row < g.M;
+    const float* __restrict__ arow = P.A + (size_t)(row_ok ? row : 0) * P.lda + kq;
+    const float* __restrict__ wcol = P.W + (size_t)kq * P.NS + n0 + lr;
+    bool col_ok[T::NT];
 #pragma unroll
-        for (int i = 0; i < T::A_PER; ++i) {
-            const int row = m0 + a_row + 2 * i, k = k0 + a_col;
-            ra[i] = (row < g.M && k < g.K4) ? P.A[(size_t)row * P.lda + k] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < T::B_PER; ++i) {
-            const int e = tid + 256 * i;
-            const int kr = e / T::BN, c = e - kr * T::BN;
-            const int k = k0 + kr, n = n0 + c;
-            rb[i] = (k < kmax && n < P.NS) ? P.W[(size_t)k * P.NS + n] : 0.f;
-        }
-    };
-    auto store_slab = [&](int buf) {
-        float* da = s_a + buf * T::BM * T::AS;
-        float* db = s_b + buf * T::BK * T::BS;
-#pragma unroll
-        for (int i = 0; i < T::A_PER; ++i) da[(a_row + 2 * i) * T::AS + a_col] = ra[i];
-#pragma unroll
-        for (int i = 0; i < T::B_PER; ++i) {
-            const int e = tid + 256 * i;
-            const int kr = e / T::BN, c = e - kr * T::BN;
-            db[kr * T::BS + c] = rb[i];
-        }
-    };
+    for (int j = 0; j < T::NT; ++j) col_ok[j] = n0 + j * 16 + lr < P.NS;
     f32x4 acc[T::NT];
 #pragma unroll
     for (int j = 0; j < T::NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nslab = (g.K4 + T::BK - 1) / T::BK;
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        if (s + 1 < nslab) load_slab((s + 1) * T::BK);
-        const float* sa = s_a + (s & 1) * T::BM * T::AS + lr * T::AS + kq + wave * 32;
-        const float* sb = s_b + (s & 1) * T::BK * T::BS + (kq + wave * 32) * T::BS + lr;
-        float av[8], bv[8][T::NT];
+    for (int s0 = s_beg; s0 < s_end; s0 += T::CH) {
+        float av[T::CH], bv[T::CH][T::NT];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            av[ks] = sa[ks * 4];
+        for (int i = 0; i < T::CH; ++i) {
+            const int ks = s0 + i, k = 4 * ks + kq;
+            const bool on = ks < s_end;
+            av[i] = (on && row_ok) ? arow[4 * ks] : 0.f;
 #pragma unroll
-            for (int j = 0; j < T::NT; ++j) bv[ks][j] = sb[ks * 4 * T::BS + j * 16];
+            for (int j = 0; j < T::NT; ++j) bv[i][j] = (on && k < kmax && col_ok[j]) ? wcol[(size_t)4 * ks * P.NS + j * 16] : 0.f;
         }
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+        for (int i = 0; i < T::CH; ++i)
 #pragma unroll
-            for (int j = 0; j < T::NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks][j], acc[j], 0, 0, 0);
-        if (s + 1 < nslab) store_slab((s + 1) & 1);
-        __syncthreads();
+            for (int j = 0; j < T::NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][j], acc[j], 0, 0, 0);
     }
-    // partial accumulators -> LDS [wave][tile][lane] (the operand buffers are free after the last barrier)
-    f32x4* s_r = reinterpret_cast<f32x4*>(smem);
+    // partial accumulators -> LDS [wave][tile][lane], summed in wave order by the wave that owns the column tile
 #pragma unroll
     for (int j = 0; j < T::NT; ++j) s_r[(wave * T::NT + j) * 64 + lane] = acc[j];
     __syncthreads();
@@ -220,11 +191,11 @@ inline __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) 
             const float bvv = P.bias ? P.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + kq * 4 + r;
-                if (row < g.M) {
+                const int orow = m0 + kq * 4 + r;
+                if (orow < g.M) {
                     float o = v[r] + bvv;
                     if (g.relu) o = fmaxf(o, 0.f);
-                    P.C[(size_t)row * P.ldc + col] = o;
+                    P.C[(size_t)orow * P.ldc + col] = o;
                 }
             }
         }
@@ -238,8 +209,7 @@ inline hipError_t gemm_set_attrs() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<1, 3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)GemmTile<1, 3, 32>::LDS);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_splitk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)GemmSplitK::LDS);
+    return hipSuccess;                                  // gemm_splitk_kernel uses static LDS only
 }
 
 // big tile (128 x 96) when it fills the chip, small tile (64 x 48) for the short-M / short-N GEMMs, and the split-K
@@ -259,7 +229,7 @@ inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
         hipLaunchKernelGGL((gemm_mfma_kernel<1, 3, 32>), grid, dim3(256), Small::LDS, st, g);
     } else {
         dim3 grid((g.M + Lat::BM - 1) / Lat::BM, (g.N + Lat::BN - 1) / Lat::BN, nproblems);
-        hipLaunchKernelGGL(gemm_splitk_kernel, grid, dim3(256), Lat::LDS, st, g);
+        hipLaunchKernelGGL(gemm_splitk_kernel, grid, dim3(256), 0, st, g);
     }
 }
 

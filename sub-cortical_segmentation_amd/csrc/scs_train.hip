@@ -69,6 +69,10 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* stat_part = nullptr;                // [3][n * bands][C][2] per-patch-band (sum, sum of squares) left by the forward convs
     double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN reductions
     float* wg_part = nullptr;                  // [3][kWgPartFloats] partial weight gradients
+    // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
+    // data-gradient kernels (fork / join with events; the caller still sees one stream)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace scs {
@@ -85,6 +89,9 @@ void train_free(scs_ctx* h) {
     if (w->red_part) (void)hipFree(w->red_part);
     if (w->wT) (void)hipFree(w->wT);
     if (w->wg_part) (void)hipFree(w->wg_part);
+    if (w->side) (void)hipStreamDestroy(w->side);
+    if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+    if (w->ev_join) (void)hipEventDestroy(w->ev_join);
     delete w;
     h->tws = nullptr;
 }
@@ -107,6 +114,9 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540) * sizeof(float)));
         SCS_HIP(hipMalloc(&w->red_part, (size_t)kTowers * 64 * kRedSplit * 2 * sizeof(double)));
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)kTowers * kWgPartFloats * sizeof(float)));
+        SCS_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+        SCS_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+        SCS_HIP(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
     }
     if (n <= w->cap) return SCS_OK;
     if (w->base) { SCS_HIP(hipFree(w->base)); w->base = nullptr; }
@@ -842,7 +852,10 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, w->loss_rows, n, w->loss_dev);
 
     // ---- backward: dense head.  d out_layer and dR2 (through fc_2's ReLU) came out of head_train_kernel's pass.
-    hipLaunchKernelGGL(outw_grad_kernel, dim3((kFC2 * 15 + 15 + 15) / 16), dim3(256), 0, st, w->R2, w->dlog, n, G + H.outW, G + H.outb);
+    // Weight / bias gradients go to the side stream (sd), data gradients stay on the caller's stream (st).
+    hipStream_t sd = w->side;
+    auto fork = [&]() { (void)hipEventRecord(w->ev_fork, st); (void)hipStreamWaitEvent(sd, w->ev_fork, 0); };   // sd sees what st has done
+    auto join = [&]() { (void)hipEventRecord(w->ev_join, sd); (void)hipStreamWaitEvent(st, w->ev_join, 0); };   // st waits for sd
     // The remaining dense gradients run on the MFMA GEMM: weight gradients take the transposed activation as A
     // ([in][n]) and the upstream gradient as W ([n][out]); data gradients take the transposed weight as W.  All ten
     // transposes (5 weights, 5 activations) are one launch.
@@ -868,22 +881,26 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     }
     GemmArgs bg{};
     bg.relu = 0;
-    // fc_2: dW2 = cat2^T dPre2, dcat = dPre2 W2[:540]^T
+    fork();                                   // dR2, dlog, the transposes are complete for sd
+    hipLaunchKernelGGL(outw_grad_kernel, dim3((kFC2 * 15 + 15 + 15) / 16), dim3(256), 0, sd, w->R2, w->dlog, n, G + H.outW, G + H.outb);
+    // fc_2: dW2 = cat2^T dPre2 (sd), dcat = dPre2 W2[:540]^T (st)
     bg.M = kFC1 + kAtlas; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kFC2;
     bg.p[0] = GemmProblem{aTc, ldT, w->dR2, kFC2ld, nullptr, G + H.fc2W, kFC2};
-    gemm_launch(bg, 1, st);
+    gemm_launch(bg, 1, sd);
     bg.M = n; bg.K4 = kFC2ld; bg.K = kFC2; bg.N = kFC1;
     bg.p[0] = GemmProblem{w->dR2, kFC2ld, wT2, kFC1, nullptr, w->dcat, kFC1};
     gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC1), dim3(256), 0, st, w->dcat, kFC1, w->R1, kFC1, mask2, n, kFC1);
-    // FC1
+    // FC1: dW1 (sd) needs the masked dcat; dfeat (st)
+    fork();
     bg.M = kFlat; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kFC1;
     bg.p[0] = GemmProblem{aTf, ldT, w->dcat, kFC1, nullptr, G + H.fc1W, kFC1};
-    gemm_launch(bg, 1, st);
+    gemm_launch(bg, 1, sd);
     bg.M = n; bg.K4 = kFC1; bg.K = kFC1; bg.N = kFlat;
     bg.p[0] = GemmProblem{w->dcat, kFC1, wT1, kFlat, nullptr, w->dfeat, kFlat};
     gemm_launch(bg, 1, st);
     hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFlat), dim3(256), 0, st, w->dfeat, kFlat, w->feat, kFlat, mask1, n, kFlat);
+    fork();                                   // the masked dfeat is final
     // bias gradients of fc_2, FC1 and the three d1 layers: column sums of the (masked) upstream gradients, one launch
     {
         ColArgs ca{};
@@ -894,15 +911,15 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
             const TowerOff T = tower_off(t * kTowerFloats);
             ca.p[2 + t] = ColProblem{w->dfeat + t * kD1, kFlat, kD1, G + T.d1b};
         }
-        hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64, kColProblems), dim3(256), 0, st, ca);
+        hipLaunchKernelGGL(colsum_kernel, dim3((kFC1 + 63) / 64, kColProblems), dim3(256), 0, sd, ca);
     }
-    // d1 x3
+    // d1 x3: dW (sd), dX (st)
     bg.M = kFlat; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kD1;
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
         bg.p[t] = GemmProblem{aT5 + (size_t)t * kFC1ld * ldT, ldT, w->dfeat + t * kD1, kFlat, nullptr, G + T.d1W, kD1};
     }
-    gemm_launch(bg, kTowers, st);
+    gemm_launch(bg, kTowers, sd);
     bg.M = n; bg.K4 = kD1; bg.K = kD1; bg.N = kFlat;
     for (int t = 0; t < kTowers; ++t) bg.p[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kFlat, kFlat, nullptr, w->dX[t][0], kFlat};
     gemm_launch(bg, kTowers, st);
@@ -913,6 +930,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
 
     // ---- backward: conv blocks 5..1 (dX ping-pongs between the two buffers)
     int cur = 0;
+    bool dz_busy = false;                     // a weight-gradient kernel on the side stream still reads dZ
     for (int i = kConvs - 1; i >= 0; --i) {
         const int C = kCout[i], Hh = kHout[i];
         CPtr3 Zi = c3(w->Z, i), dOut{{w->dX[0][cur], w->dX[1][cur], w->dX[2][cur]}};
@@ -924,6 +942,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
             hipLaunchKernelGGL((bn_bwd_partial_kernel<PL, HH>), dim3(C, kTowers, kRedSplit), dim3(256), 0, st, Zi, dOut, n, C, w->stats, i, P,
                                T0.bn[i], kTowerFloats, w->red_part);
             const int split = max(1, min(n, (int)(tot / C / 8192)));           // ~8k elements of a channel per workgroup
+            if (dz_busy) (void)hipStreamWaitEvent(st, w->ev_join, 0);          // previous layer's weight gradient has read dZ
             hipLaunchKernelGGL((bn_bwd_apply_kernel<PL, HH>), dim3(C, kTowers, split), dim3(256), 0, st, Zi, dOut, dZ, n, C, w->stats, i, P,
                                T0.bn[i], kTowerFloats, w->red_part, G);
         };
@@ -935,19 +954,22 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
         else bn_bwd(integral_constant<bool, false>{}, integral_constant<int, 3>{});
         CPtr3 Xi;
         for (int t = 0; t < kTowers; ++t) Xi.p[t] = (i == 0) ? xin[t] : w->X[t][i];
-        CPtr3 dZc{{w->dZ[0], w->dZ[1], w->dZ[2]}};
         {
+            // weight gradient of this layer on the side stream, beside the data gradient below; the next layer's
+            // bn_bwd_apply overwrites dZ, so the caller's stream re-joins before it (top of the next iteration)
+            fork();
             WgArgs wa{};
             for (int t = 0; t < kTowers; ++t) { wa.X[t] = Xi.p[t]; wa.dZ[t] = w->dZ[t]; }
             wa.part = w->wg_part; wa.n = n; wa.slices = n < wg_slices()[i] ? n : wg_slices()[i];
-            if (i == 0) wgrad_launch<WG1>(wa, st);
-            else if (i == 1) wgrad_launch<WG2>(wa, st);
-            else if (i == 2) wgrad_launch<WG3>(wa, st);
-            else if (i == 3) wgrad_launch<WG4>(wa, st);
-            else wgrad_launch<WG5>(wa, st);
+            if (i == 0) wgrad_launch<WG1>(wa, sd);
+            else if (i == 1) wgrad_launch<WG2>(wa, sd);
+            else if (i == 2) wgrad_launch<WG3>(wa, sd);
+            else if (i == 3) wgrad_launch<WG4>(wa, sd);
+            else wgrad_launch<WG5>(wa, sd);
+            (void)hipEventRecord(w->ev_join, sd);               // dZ has been consumed
             const int tot = kCin[i] * C * 9;
             constexpr int kParts[kConvs] = {WG1::NB * WG1::PARTS, WG2::NB * WG2::PARTS, WG3::NB * WG3::PARTS, WG4::NB * WG4::PARTS, WG5::NB * WG5::PARTS};
-            hipLaunchKernelGGL(wgrad_final_kernel, dim3((tot + 63) / 64, kTowers), dim3(256), 0, st, w->wg_part, wa.slices * kParts[i], kCin[i], C, G,
+            hipLaunchKernelGGL(wgrad_final_kernel, dim3((tot + 63) / 64, kTowers), dim3(256), 0, sd, w->wg_part, wa.slices * kParts[i], kCin[i], C, G,
                                T0.convW[i], kTowerFloats);
         }
         if (i > 0) {
@@ -960,7 +982,9 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
             else conv_launch<DG2>(a, st);
             cur ^= 1;
         }
+        dz_busy = true;
     }
+    join();                                   // every gradient is in the arena before the caller's stream goes on
     SCS_HIP(hipGetLastError());
     h->packed_dirty = true;          // BN running statistics moved
     if (loss_host) {

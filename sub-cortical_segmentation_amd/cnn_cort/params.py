@@ -20,7 +20,6 @@ Array order inside a layer follows Lasagne's ``get_params()``:
   ParametricRectifierLayer (prelu)                          -> [alpha]
   DenseLayer                                                -> [W (in,out), b]
 """
-import io
 import json
 import os
 import pickle

@@ -140,7 +140,8 @@ struct GemmSplitK {
     static constexpr size_t LDS = (size_t)4 * NT * 256 * 4;
 };
 
-inline __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
+template <int CH_ = GemmSplitK::CH>     // a template so that both translation units may instantiate it
+__global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
     using T = GemmSplitK;
     __shared__ f32x4 s_r[4 * T::NT * 64];
     const int z = blockIdx.z;
@@ -229,7 +230,7 @@ inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
         hipLaunchKernelGGL((gemm_mfma_kernel<1, 3, 32>), grid, dim3(256), Small::LDS, st, g);
     } else {
         dim3 grid((g.M + Lat::BM - 1) / Lat::BM, (g.N + Lat::BN - 1) / Lat::BN, nproblems);
-        hipLaunchKernelGGL(gemm_splitk_kernel, grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL(gemm_splitk_kernel<>, grid, dim3(256), 0, st, g);
     }
 }
 

@@ -34,7 +34,6 @@ using DG3 = ConvCfg<40, 20, 16, 1, EPI_RAW, SRC_NCHW_PAD2, 144, 2, 4>;
 using DG2 = ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 256, 5, 4>;
 
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
-constexpr bool kPool[kConvs] = {false, true, false, true, false};
 constexpr int kRedSplit = 16;     // batch slices per channel in the two-stage BN reductions
 // <CIN, COUT, HIN, row bands, workgroups per CU>
 using WG2 = WgCfg<20, 20, 30, 4, 3>;
@@ -67,7 +66,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* actT = nullptr;                     // transposed activations for the dense weight-gradient GEMMs [5][556][cap]: H5 x3, featd, cat2
     float* wT = nullptr;                       // transposed dense weights for the dense data-gradient GEMMs
     float* stat_part = nullptr;                // [3][n * bands][C][2] per-patch-band (sum, sum of squares) left by the forward convs
-    double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN reductions
+    double* red_part = nullptr;                // [3][64][kRedSplit][2] partial sums of the BN backward reductions
     float* wg_part = nullptr;                  // [3][kWgPartFloats] partial weight gradients
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
@@ -516,7 +515,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColArgs a) {
     for (int i = 1; i < kColProblems; ++i) if ((int)blockIdx.y == i) P = a.p[i];
     const int cj = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + cj;
-    if (blockIdx.x * 64 >= P.cols) return;
+    if ((int)blockIdx.x * 64 >= P.cols) return;
     double s = 0;
     if (j < P.cols)
         for (int r = rg; r < a.n; r += 4) s += P.g[(size_t)r * P.ldg + j];

@@ -1,5 +1,4 @@
 """The C-ABI library loads and exports every symbol include/scs.h declares (no compute without a GPU)."""
-import ctypes
 import os
 import re
 

@@ -3,8 +3,6 @@
 Tolerances (BASELINE.json north_star): softmax probabilities within 1e-4 absolute of the oracle; argmax labels
 identical wherever the oracle's own top-2 margin exceeds float32 noise (1e-5) and, for closer calls, one of the
 oracle's top two classes."""
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -172,7 +170,6 @@ def test_full_size_properties(handle):
 
 def test_error_codes_and_call_order(handle):
     """C-ABI error behaviour (include/scs.h): negative status + text, never an abort; the handle stays usable."""
-    import ctypes
     from cnn_cort import _hip
     lib = handle.lib
     g = gold('g1_random.npz')

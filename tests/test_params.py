@@ -1,5 +1,4 @@
 """Parameter store: layer inventory, file formats, arena layout (CPU)."""
-import io
 import os
 import pickle
 
@@ -7,7 +6,6 @@ import numpy as np
 import pytest
 
 from cnn_cort import params as P
-from conftest import WEIGHTS
 
 
 def test_layer_inventory_matches_shipped_weights(weights):

@@ -288,10 +288,10 @@ def test_scan(net, test_scan, options):
     return (time.time() - s_time) / 60.0
 
 
-def test_cohort(net, scan_paths, options, shard=True):
+def test_cohort(net, scan_paths, options, shard=True, readers=4):
     """test_scan over a list of T1 paths (the loop of train_model.py:74-78) as a three-stage pipeline: while the
-    GPU segments subject i, helper threads already read subjects i+1 and i+2 (gunzip of the prior is the longest
-    stage) and another writes the files of subject i-1.  Same files as calling test_scan per path.  Under torchrun every
+    GPU segments subject i, `readers` helper threads already read the next subjects (gunzip of the prior is the
+    longest stage) and another writes the files of subject i-1.  Same files as calling test_scan per path.  Under torchrun every
     rank takes every world_size-th subject (no collective).  Returns [(path, minutes)] for this rank's subjects,
     minutes = that subject's own load + predict + write time."""
     from concurrent.futures import ThreadPoolExecutor
@@ -306,7 +306,7 @@ def test_cohort(net, scan_paths, options, shard=True):
         r = fn(*a)
         return r, time.time() - t0
 
-    ahead = 2                                      # subjects being read while one is on the GPU
+    ahead = max(1, int(readers))                   # subjects being read while one is on the GPU
     with ThreadPoolExecutor(ahead) as loader, ThreadPoolExecutor(1) as writer:
         pending = [loader.submit(timed, _scan_inputs, p, options) for p in paths[:ahead]]
         writes = []

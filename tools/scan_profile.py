@@ -115,11 +115,12 @@ def main():
             for sc in scans:
                 base.test_scan(net, sc, opts)
             t_loop = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            base.test_cohort(net, scans, opts)
-            t_pipe = time.perf_counter() - t0
-            print('--- cohort of %d subjects: test_scan loop %.2f s (%.2f s/subject), test_cohort %.2f s (%.2f s/subject)'
-                  % (len(scans), t_loop, t_loop / len(scans), t_pipe, t_pipe / len(scans)))
+            print('--- cohort of %d subjects: test_scan loop %.2f s (%.2f s/subject)' % (len(scans), t_loop, t_loop / len(scans)))
+            for readers in (1, 2, 3, 4):
+                t0 = time.perf_counter()
+                base.test_cohort(net, scans, opts, readers=readers)
+                t_pipe = time.perf_counter() - t0
+                print('    test_cohort, %d reader thread(s): %.2f s (%.2f s/subject)' % (readers, t_pipe, t_pipe / len(scans)))
 
 
 if __name__ == '__main__':

@@ -87,11 +87,32 @@ class EarlyStopping:
             raise StopIteration()
 
 
+def rotate_flip_views(views, indices, choices):
+    """The on-the-fly augmentation of the reference's Rotate_batch_Iterator.transform (nets.py:41-124; defined there
+    but never attached to the net, so it is opt-in here: options['augment']).  For the samples `indices` (half of the
+    batch, the same for all three views) each view [B,1,32,32] is replaced by one of three variants, chosen per
+    sample and per view by `choices[v][i]` in {0,1,2}: 0 = rotated by 180 degrees, 1 = flipped left-right,
+    2 = rotated by 180 degrees then flipped left-right (= flipped up-down).  torch tensors on any device; returns new
+    tensors, the inputs are not modified."""
+    out = []
+    for v, x in enumerate(views):
+        x = x.clone()
+        sel = x[indices]
+        r = choices[v].to(sel.device).view(-1, 1, 1, 1)
+        aug = sel.flip(2, 3)                                    # rotate_180
+        aug = aug.where(r != 1, sel.flip(3))                    # rotate_0_flipped
+        aug = aug.where(r != 2, sel.flip(2))                    # rotate_180_flipped
+        x[indices] = aug
+        out.append(x)
+    return out
+
+
 class Net:
     """Drop-in for the nolearn NeuralNet the reference builds at nets.py:233-246."""
 
     def __init__(self, weights_file=None, history_file=None, max_epochs=100, patience=20, eval_size=0.25,
-                 batch_size=128, verbose=0, device=None, update_learning_rate=0.001, seed=0):
+                 batch_size=128, verbose=0, device=None, update_learning_rate=0.001, seed=0, augment=False):
+        self.augment = bool(augment)
         self.weights_file = weights_file
         self.history_file = history_file
         self.max_epochs = int(max_epochs)
@@ -361,6 +382,7 @@ class Net:
         bs = self.batch_size
         world, rank = dist.world_size(), dist.rank()
         hooks = [self._hook_save_weights, self._hook_save_history, EarlyStopping(self.patience)]
+        aug_rng = torch.Generator(device=dev) if self.augment else None
         best_train, best_valid = np.inf, np.inf
         first_epoch = len(self.train_history_)
         if self.verbose:
@@ -377,7 +399,13 @@ class Net:
                     if active:
                         hi = min(ntr, lo + bs)
                         self._step += 1
-                        h.train_step(Xtr[0][lo:hi], Xtr[1][lo:hi], Xtr[2][lo:hi], Xtr[3][lo:hi], Xtr[4][lo:hi], hi - lo,
+                        views = [Xtr[0][lo:hi], Xtr[1][lo:hi], Xtr[2][lo:hi]]
+                        if self.augment and hi - lo > 1:
+                            aug_rng.manual_seed((self.seed << 20) + self._step * 8 + rank)
+                            idx = torch.randperm(hi - lo, generator=aug_rng, device=dev)[:(hi - lo) // 2]
+                            views = rotate_flip_views(views, idx, [torch.randint(0, 3, (idx.numel(),), generator=aug_rng, device=dev)
+                                                                   for _ in range(3)])
+                        h.train_step(views[0], views[1], views[2], Xtr[3][lo:hi], Xtr[4][lo:hi], hi - lo,
                                      seed=(self.seed << 32) + self._step * 131 + rank, want_loss=False, stream=stream)
                         if loss_view is None:
                             loss_view = dist.wrap_device_floats(h.train_loss_ptr(), 1, self._dev())
@@ -446,7 +474,7 @@ def build_model(weights_path, options):
     net = Net(weights_file=net_weights, history_file=net_history,
               max_epochs=options['max_epochs'], patience=options['patience'], eval_size=options['train_split'],
               batch_size=options.get('batch_size') or 128, verbose=options['net_verbose'],
-              device=options.get('device'))
+              device=options.get('device'), augment=is_true(options.get('augment')))
     if is_true(options['load_weights']):
         if net.verbose:
             print("    --> loading weights from ", net_weights)

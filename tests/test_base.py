@@ -308,3 +308,25 @@ def test_cohort_pipeline_writes_the_same_files_as_the_loop(tmp_path):
     with pytest.raises(FileNotFoundError):
         base.test_cohort(net, [str(tmp_path / b) for _, b in paths], opts)
     assert base.test_cohort(net, [], opts) == []
+
+
+def test_rotate_flip_augmentation_equals_the_reference_formulas():
+    """nets.rotate_flip_views == the three variants Rotate_batch_Iterator.transform builds (nets.py:64-84), with the
+    random draws injected."""
+    import torch
+    from cnn_cort.nets import rotate_flip_views
+    rng = np.random.RandomState(8)
+    views = [rng.rand(10, 1, 32, 32).astype(np.float32) for _ in range(3)]
+    indices = rng.choice(10, 5, replace=False)
+    choices = [rng.randint(0, 3, size=5) for _ in range(3)]
+    got = rotate_flip_views([torch.from_numpy(v) for v in views], torch.from_numpy(indices),
+                            [torch.from_numpy(c) for c in choices])
+    for v in range(3):
+        x = views[v][indices]
+        rotate_90 = x[:, :, ::-1, :].transpose(0, 1, 3, 2)
+        rotate_180 = rotate_90[:, :, ::-1, :].transpose(0, 1, 3, 2)
+        augmented = np.stack([rotate_180, x[:, :, :, ::-1], rotate_180[:, :, :, ::-1]], axis=1)
+        want = views[v].copy()
+        want[indices] = np.stack([augmented[i, choices[v][i]] for i in range(5)])
+        assert np.array_equal(got[v].numpy(), want)
+        assert not np.array_equal(want, views[v])

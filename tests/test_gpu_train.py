@@ -129,6 +129,25 @@ def test_fit_learns_and_keeps_the_history_schema(tmp_path):
     assert np.array_equal(net2.predict(X), p.argmax(1))
 
 
+def test_fit_with_the_opt_in_augmentation(tmp_path):
+    """options['augment'] (the reference's unattached Rotate_batch_Iterator): training still converges on the toy
+    problem, whose labels do not depend on patch orientation, and differs from the un-augmented run."""
+    from cnn_cort.nets import Net
+    from cnn_cort import synth
+    n = 512
+    ax, co, sa, at = synth.patch_batch(n, seed=6)
+    y = at.argmax(1).astype(np.uint8)
+    at = (0.1 * at + 0.9 * np.eye(15, dtype=np.float32)[y]).astype(np.float32)
+    X = {'in1': ax, 'in2': co, 'in3': sa, 'in4': at}
+    hist = {}
+    for aug in (False, True):
+        net = Net(max_epochs=4, patience=20, eval_size=0.25, batch_size=128, verbose=0, device=0, seed=3, augment=aug)
+        net.fit(X, y)
+        hist[aug] = [r['train_loss'] for r in net.train_history_]
+        assert all(np.isfinite(hist[aug])) and hist[aug][-1] < hist[aug][0]
+    assert hist[True] != hist[False]
+
+
 def test_two_rank_gradient_exchange(tmp_path):
     """Two ranks (gloo rehearsal, both on cuda:0): each back-propagates its half of the g5 batch, the gradient arenas
     are summed through cnn_cort.dist and Adam applies the 1/world scale: replicas end identical and the exchanged

@@ -330,3 +330,23 @@ def test_rotate_flip_augmentation_equals_the_reference_formulas():
         want[indices] = np.stack([augmented[i, choices[v][i]] for i in range(5)])
         assert np.array_equal(got[v].numpy(), want)
         assert not np.array_equal(want, views[v])
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_post_processing_fast_path_equals_the_literal_procedure(seed):
+    """Bounding-box labelling vs the literal whole-volume procedure on random label maps, including classes that are
+    absent, classes without any atlas overlap (quirk: they paint their complement) and single-class volumes."""
+    rng = np.random.RandomState(100 + seed)
+    shape = (18, 16, 14)
+    if seed == 5:
+        seg = np.full(shape, 3, np.int16)                      # one class fills the volume
+    else:
+        seg = np.zeros(shape, np.int16)
+        for _ in range(30):
+            c = rng.randint(1, 15 if seed % 2 else 11)          # even seeds leave classes 11..14 empty
+            x, y, z = [rng.randint(0, s - 3) for s in shape]
+            seg[x:x + rng.randint(1, 4), y:y + rng.randint(1, 4), z:z + rng.randint(1, 4)] = c
+    atlas = rng.rand(*shape) < (0.0 if seed == 4 else 0.3)       # seed 4: no overlap at all
+    want = R.post_process_segmentation(seg, atlas)
+    got = base.post_process_mask(seg, atlas)
+    assert got.dtype == want.dtype and np.array_equal(got, want)

@@ -143,6 +143,10 @@ int main(int argc, char** argv) {
         run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 912, 1, 1>>("conv12 NB1 WPS1 (912)", n, rounds, c12);
         run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 1>>("conv12 NB2 WPS1", n, rounds, c12);
         run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 2>>("conv12 NB2 WPS2", n, rounds, c12);
+        run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 180, 7, 4>>("conv12 NB7 WPS4", n, rounds, c12);
+        run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 180, 7, 5>>("conv12 NB7 WPS5", n, rounds, c12);
+        run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 180, 7, 6>>("conv12 NB7 WPS6", n, rounds, c12);
+        run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 3>>("conv12 NB2 WPS3", n, rounds, c12);
         run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 3, 0, 5>>("conv12 NB2 WPS3 NW5", n, rounds, c12);
         run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 2, 0, 5>>("conv12 NB2 WPS2 NW5", n, rounds, c12);
         run<ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 2, 0, 7>>("conv12 NB2 WPS2 NW7", n, rounds, c12);

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "conv_mfma.h"
@@ -378,6 +379,8 @@ int scs_destroy(scs_handle h) {
     if (h->packed) (void)hipFree(h->packed);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage_dev) (void)hipFree(h->stage_dev);
+    if (h->host_compute) (void)hipStreamDestroy(h->host_compute);
+    if (h->host_copy) (void)hipStreamDestroy(h->host_copy);
     delete h;
     return SCS_OK;
 }
@@ -465,6 +468,9 @@ int scs_forward_volume_rows(scs_handle h, const float* vol, int dx, int dy, int 
     return forward_common(h, nullptr, nullptr, nullptr, atlas_rows, vol, dx, dy, dz, centers, nullptr, n, probs, labels, stream);
 }
 
+// Host-pointer entry.  The chunks are double buffered on the device: a helper thread uploads chunk i+1 on the
+// handle's copy stream (the runtime stages pageable memory and blocks the thread that issued the copy, not the device)
+// while the kernels of chunk i run on the compute stream; results come back per chunk.
 int scs_forward_host(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, int64_t n,
                      float* probs, int32_t* labels) {
     SCS_ARG(h != nullptr, "null handle");
@@ -476,27 +482,57 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
     const int hstep = balanced_chunk(n, h->chunk);
     int rc = ensure_workspace(h, hstep);
     if (rc != SCS_OK) return rc;
-    if (h->packed_dirty) { rc = repack_inference(h, nullptr); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
+    if (!h->host_compute) {
+        SCS_HIP(hipStreamCreateWithFlags(&h->host_compute, hipStreamNonBlocking));
+        SCS_HIP(hipStreamCreateWithFlags(&h->host_copy, hipStreamNonBlocking));
+    }
+    hipStream_t sc = h->host_compute, su = h->host_copy;
+    if (h->packed_dirty) { rc = repack_inference(h, sc); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
     const size_t c = (size_t)h->ws_chunk;
     const size_t per = 3 * 1024 + 15 + 15 + 1;                  // views, atlas, probs, label
-    if (!h->stage_dev || h->stage_floats < c * per) {
+    if (!h->stage_dev || h->stage_floats < 2 * c * per) {
         if (h->stage_dev) SCS_HIP(hipFree(h->stage_dev));
-        SCS_HIP(hipMalloc(&h->stage_dev, c * per * sizeof(float)));
-        h->stage_floats = c * per;
+        h->stage_dev = nullptr; h->stage_floats = 0;
+        SCS_HIP(hipMalloc(&h->stage_dev, 2 * c * per * sizeof(float)));
+        h->stage_floats = 2 * c * per;
     }
-    float* d_ax = h->stage_dev; float* d_co = d_ax + c * 1024; float* d_sa = d_co + c * 1024;
-    float* d_at = d_sa + c * 1024; float* d_pr = d_at + c * 15; int32_t* d_lb = reinterpret_cast<int32_t*>(d_pr + c * 15);
-    for (int64_t s = 0; s < n; s += hstep) {
+    struct Buf { float *ax, *co, *sa, *at, *pr; int32_t* lb; } buf[2];
+    for (int i = 0; i < 2; ++i) {
+        float* base = h->stage_dev + (size_t)i * c * per;
+        buf[i] = Buf{base, base + c * 1024, base + 2 * c * 1024, base + 3 * c * 1024, base + 3 * c * 1024 + c * 15,
+                     reinterpret_cast<int32_t*>(base + 3 * c * 1024 + 2 * c * 15)};
+    }
+    const int device = h->device;
+    auto upload = [&](int64_t s, int which, hipError_t* err) {
+        *err = hipSetDevice(device);
         const size_t m = (size_t)((n - s < hstep) ? (n - s) : hstep);
-        SCS_HIP(hipMemcpyAsync(d_ax, ax + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
-        SCS_HIP(hipMemcpyAsync(d_co, co + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
-        SCS_HIP(hipMemcpyAsync(d_sa, sa + s * 1024, m * 4096, hipMemcpyHostToDevice, nullptr));
-        SCS_HIP(hipMemcpyAsync(d_at, atlas + s * 15, m * 60, hipMemcpyHostToDevice, nullptr));
-        rc = forward_chunk(h, d_ax, d_co, d_sa, d_at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d_pr, d_lb, nullptr, nullptr);
+        const Buf& d = buf[which];
+        if (*err == hipSuccess) *err = hipMemcpyAsync(d.ax, ax + s * 1024, m * 4096, hipMemcpyHostToDevice, su);
+        if (*err == hipSuccess) *err = hipMemcpyAsync(d.co, co + s * 1024, m * 4096, hipMemcpyHostToDevice, su);
+        if (*err == hipSuccess) *err = hipMemcpyAsync(d.sa, sa + s * 1024, m * 4096, hipMemcpyHostToDevice, su);
+        if (*err == hipSuccess) *err = hipMemcpyAsync(d.at, atlas + s * 15, m * 60, hipMemcpyHostToDevice, su);
+        if (*err == hipSuccess) *err = hipStreamSynchronize(su);
+    };
+    hipError_t uerr = hipSuccess;
+    upload(0, 0, &uerr);
+    SCS_HIP(uerr);
+    int which = 0;
+    for (int64_t s = 0; s < n; s += hstep, which ^= 1) {
+        const size_t m = (size_t)((n - s < hstep) ? (n - s) : hstep);
+        const bool more = s + hstep < n;
+        std::thread next;
+        hipError_t nerr = hipSuccess;
+        if (more) next = std::thread(upload, s + hstep, which ^ 1, &nerr);       // the other buffer: its results were read back
+        const Buf& d = buf[which];
+        rc = forward_chunk(h, d.ax, d.co, d.sa, d.at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d.pr, d.lb, sc, nullptr);
+        hipError_t e = hipSuccess;
+        if (rc == SCS_OK && probs) e = hipMemcpyAsync(probs + s * 15, d.pr, m * 60, hipMemcpyDeviceToHost, sc);
+        if (rc == SCS_OK && e == hipSuccess && labels) e = hipMemcpyAsync(labels + s, d.lb, m * 4, hipMemcpyDeviceToHost, sc);
+        if (e == hipSuccess) e = hipStreamSynchronize(sc);
+        if (more) next.join();
         if (rc != SCS_OK) return rc;
-        if (probs) SCS_HIP(hipMemcpyAsync(probs + s * 15, d_pr, m * 60, hipMemcpyDeviceToHost, nullptr));
-        if (labels) SCS_HIP(hipMemcpyAsync(labels + s, d_lb, m * 4, hipMemcpyDeviceToHost, nullptr));
-        SCS_HIP(hipStreamSynchronize(nullptr));
+        SCS_HIP(e);
+        SCS_HIP(nerr);
     }
     return SCS_OK;
 }

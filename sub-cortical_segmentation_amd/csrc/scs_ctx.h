@@ -38,6 +38,7 @@ struct scs_ctx {
     // host staging for the *_host entry points
     float* stage_dev = nullptr;       // [chunk] x (3*1024 + 15 + 15) floats + labels
     size_t stage_floats = 0;
+    hipStream_t host_compute = nullptr, host_copy = nullptr;    // scs_forward_host: kernels / uploads of the next chunk
 
     // training state (scs_train.hip)
     TrainWs* tws = nullptr;

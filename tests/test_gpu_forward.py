@@ -117,6 +117,17 @@ def test_host_pointer_entry_matches_device_entry(handle):
     hl = np.empty((n,), np.int32)
     handle.forward_host(g['ax'], g['co'], g['sa'], g['atlas'], n, hp, hl)
     assert np.array_equal(hp, probs) and np.array_equal(hl, labels)
+    # several chunks: the upload of chunk i+1 overlaps the kernels of chunk i (double-buffered staging)
+    old = handle.set_chunk(0)
+    try:
+        handle.set_chunk(48)
+        hp2 = np.full((n, 15), -1, np.float32)
+        hl2 = np.full((n,), -1, np.int32)
+        handle.forward_host(g['ax'], g['co'], g['sa'], g['atlas'], n, hp2, hl2)
+        handle.forward_host(g['ax'], g['co'], g['sa'], g['atlas'], n, None, hl2)     # labels only
+    finally:
+        handle.set_chunk(old)
+    assert np.array_equal(hp2, probs) and np.array_equal(hl2, labels)
 
 
 def test_gather_fused_volume_path_equals_patch_path(handle):

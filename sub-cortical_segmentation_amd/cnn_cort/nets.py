@@ -424,8 +424,10 @@ class Net:
                 self._dev_newer = True
                 dist.sync_params(h)            # reconcile per-rank BN running statistics (no-op on one GPU)
                 vloss, vcorrect = 0.0, 0
-                for lo in range(0, nva, bs):
-                    hi = min(nva, lo + bs)
+                # validation: nolearn averages the batch losses weighted by batch size = the mean over samples, so
+                # the hold-out set goes through in large slices (one read-back each) instead of `bs` at a time
+                for lo in range(0, nva, _SUPER * 4):
+                    hi = min(nva, lo + _SUPER * 4)
                     ls, nc = h.eval_batch(Xva[0][lo:hi], Xva[1][lo:hi], Xva[2][lo:hi], Xva[3][lo:hi], Xva[4][lo:hi],
                                           hi - lo, stream=stream)
                     vloss += ls

@@ -87,6 +87,32 @@ def cpu_baseline(weights, budget_s=12.0, batch=128):
                       % (done, batch, dt)}
 
 
+def cpu_baseline_train(weights, budget_s=12.0, batch=256):
+    """Training-step stand-in on the host cores: the torch-CPU restatement (autograd backward) + Adam, float32,
+    batch 256, explicit dropout masks - BASELINE.md section 3, config 3."""
+    import torch
+    from oracle import np_oracle as O, torch_ref as T
+    from cnn_cort import params as P, synth
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    ax, co, sa, at = synth.patch_batch(batch, seed=0)
+    rng = np.random.RandomState(4)
+    y = rng.randint(0, 15, batch)
+    masks = {'%s_l1drop' % t: (rng.rand(batch, 60, 3, 3) < 0.5).astype(np.float32) for t in P.TOWERS}
+    masks['f1_drop'] = (rng.rand(batch, 540) < 0.5).astype(np.float32)
+    masks['f2_drop'] = (rng.rand(batch, 540) < 0.5).astype(np.float32)
+    params, state = weights, {}
+    done, t0 = 0, time.time()
+    while done == 0 or time.time() - t0 < budget_s:
+        _, grads, bn, _ = T.train_loss_and_grads(params, ax, co, sa, at, y, masks, dtype=torch.float32)
+        params = O.bn_running_update(O.adam_step(params, grads, state, trainable=P.is_trainable), bn)
+        done += batch
+    dt = time.time() - t0
+    return {'value': done / dt, 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d training steps of batch %d (fwd + autograd bwd + Adam), float32 torch-CPU restatement, %.1f s'
+                      % (done // batch, batch, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -210,7 +236,7 @@ def main():
                          for i in range(8)}
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
     if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline(weights)
+        out['cpu_baseline'] = cpu_baseline_train(weights) if args.mode == 'train' else cpu_baseline(weights)
     if rank == 0:
         print(json.dumps(out, default=float))
     h.close()

@@ -68,7 +68,7 @@ def _workers():
     return max(1, min(n, 32))
 
 
-_STREAM_BYTES = 8 << 20             # inflated bytes handed on per step
+_STREAM_BYTES = 2 << 20             # inflated bytes handed on per step (cache-sized: the gather reads them once)
 _FEED_BYTES = 256 << 10             # compressed bytes fed to zlib per call
 
 

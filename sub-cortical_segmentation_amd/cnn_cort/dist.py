@@ -137,9 +137,9 @@ def allreduce_grads(handle, active, stream=0, n_active=None):
     if not active:
         g.zero_()
     td = _td()
-    flag = torch.tensor([1.0 if active else 0.0], device=g.device)
     td.all_reduce(g, op=td.ReduceOp.SUM)
-    if n_active is None:
+    if n_active is None:                      # callers that know the schedule pass it and skip this exchange
+        flag = torch.tensor([1.0 if active else 0.0], device=g.device)
         td.all_reduce(flag, op=td.ReduceOp.SUM)
         n_active = int(flag.item())
     return 1.0 / max(1, n_active)

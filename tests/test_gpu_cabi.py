@@ -1,0 +1,63 @@
+"""The boundary is a C ABI: a plain-C program (gcc, include/scs.h, -lscs; no Python, torch or HIP headers on its side)
+drives scs_forward_host and must produce the same bits as the Python binding on the same inputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def lcg_units(count, state=12345):
+    """The generator of tests/c/abi_host.c, vectorised: x_{k+1} = a x_k + c (mod 2^32); value = (x >> 8) / 2^24."""
+    a, c, out = 1664525, 1013904223, np.empty(count, np.uint32)
+    # jump-ahead in blocks: x_{k+j} = A_j x_k + C_j
+    block = 1 << 16
+    A, C = np.empty(block, np.uint64), np.empty(block, np.uint64)
+    Ak, Ck = 1, 0
+    for j in range(block):
+        Ak, Ck = (Ak * a) & 0xFFFFFFFF, (Ck * a + c) & 0xFFFFFFFF
+        A[j], C[j] = Ak, Ck
+    x = state
+    for lo in range(0, count, block):
+        m = min(block, count - lo)
+        vals = (A[:m] * np.uint64(x) + C[:m]) & np.uint64(0xFFFFFFFF)
+        out[lo:lo + m] = vals.astype(np.uint32)
+        x = int(vals[m - 1])
+    return (out >> 8).astype(np.float32) / np.float32(16777216.0), x
+
+
+def test_plain_c_host_matches_the_python_binding(tmp_path, handle):
+    exe = str(tmp_path / 'abi_host')
+    lib_dir = os.path.join(PKG, 'lib')
+    subprocess.check_call(['gcc', '-O1', '-std=c99', '-Wall', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'tests', 'c', 'abi_host.c'), '-o', exe,
+                           '-L', lib_dir, '-lscs', '-Wl,-rpath,' + lib_dir])
+    n = 300
+    out = str(tmp_path / 'out.bin')
+    env = dict(os.environ, LD_LIBRARY_PATH=lib_dir + ':/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
+    res = subprocess.run([exe, os.path.join(PKG, 'nets', 'miccai2012_v1', 'miccai2012_v1.f32'), str(n), out],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    raw = np.fromfile(out, dtype=np.uint8)
+    probs_c = raw[:n * 60].view(np.float32).reshape(n, 15)
+    labels_c = raw[n * 60:].view(np.int32)
+    # the same inputs in NumPy
+    state, views = 12345, []
+    for _ in range(3):
+        u, state = lcg_units(1024 * n, state)
+        views.append((np.float32(4.0) * u - np.float32(2.0)).reshape(n, 1, 32, 32))
+    u, state = lcg_units(15 * n, state)
+    atlas = u.reshape(n, 15)
+    s = np.zeros(n, np.float32)
+    for c in range(15):                                      # the C loop's summation order
+        s = s + atlas[:, c]
+    atlas = atlas / s[:, None]
+    probs = np.empty((n, 15), np.float32)
+    labels = np.empty((n,), np.int32)
+    handle.forward_host(views[0], views[1], views[2], atlas, n, probs, labels)
+    assert np.array_equal(probs, probs_c) and np.array_equal(labels, labels_c)
+    assert np.abs(probs_c.sum(1) - 1).max() < 1e-5

@@ -48,3 +48,13 @@ def test_python_surface_fails_loudly_without_a_device():
          'in3': np.zeros((1, 1, 32, 32), np.float32), 'in4': np.zeros((1, 15), np.float32)}
     with pytest.raises(RuntimeError):
         net.predict(X)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/scs.h is C99 (no C++-isms) and a C program links against libscs.so with gcc alone (not run here)."""
+    import subprocess
+    from conftest import PKG, ROOT
+    lib_dir = os.path.join(PKG, 'lib')
+    subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'tests', 'c', 'abi_host.c'), '-o', str(tmp_path / 'abi_host'),
+                           '-L', lib_dir, '-lscs', '-Wl,-rpath,' + lib_dir, '-Wl,--allow-shlib-undefined'])

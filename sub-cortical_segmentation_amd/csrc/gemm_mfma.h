@@ -16,7 +16,25 @@ struct GemmProblem {
     const float* W; int NS;      // packed [K4][NS]
     const float* bias;           // [>= N]
     float* C; int ldc;
+    // optional epilogue of the training step (all null / 0 at inference), applied after bias (+ ReLU):
+    //   C2 set   (forward through a dropout layer): C = v, C2 = mask ? 2v : 0
+    //   C2 null  (backward): v = mask ? 2v : 0 (dropout backward), then v = gate > 0 ? v : 0 (ReLU backward), C = v
+    const uint8_t* mask; int ldm;
+    const float* gate; int ldg;
+    float* C2; int ldc2;
 };
+
+__device__ __forceinline__ void gemm_store(const GemmProblem& P, int relu, int row, int col, float v) {
+    if (relu) v = fmaxf(v, 0.f);
+    if (P.C2) {
+        P.C[(size_t)row * P.ldc + col] = v;
+        P.C2[(size_t)row * P.ldc2 + col] = P.mask[(size_t)row * P.ldm + col] ? 2.f * v : 0.f;
+        return;
+    }
+    if (P.mask) v = P.mask[(size_t)row * P.ldm + col] ? 2.f * v : 0.f;
+    if (P.gate) v = P.gate[(size_t)row * P.ldg + col] > 0.f ? v : 0.f;
+    P.C[(size_t)row * P.ldc + col] = v;
+}
 struct GemmArgs {
     GemmProblem p[kTowers];      // blockIdx.z selects
     int M, K4, N;                // K4 = reduction length walked (multiple of 4)
@@ -120,11 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wave * 16 * MT + i * 16 + kq * 4 + r;
-                if (row < g.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    P.C[(size_t)row * P.ldc + col] = v;
-                }
+                if (row < g.M) gemm_store(P, g.relu, row, col, acc[i][j][r] + bv);
             }
         }
 }
@@ -193,11 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int orow = m0 + kq * 4 + r;
-                if (orow < g.M) {
-                    float o = v[r] + bvv;
-                    if (g.relu) o = fmaxf(o, 0.f);
-                    P.C[(size_t)orow * P.ldc + col] = o;
-                }
+                if (orow < g.M) gemm_store(P, g.relu, orow, col, v[r] + bvv);
             }
         }
     }

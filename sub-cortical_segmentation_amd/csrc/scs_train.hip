@@ -337,15 +337,6 @@ __global__ void atlas_cols_kernel(const float* __restrict__ atlas, float* __rest
     cat2[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? atlas[(size_t)row * 15 + c] : 0.f;
 }
 
-// out[n][ldo] (cols 0..cols-1) = in[n][ldi] * mask * 2
-__global__ void dropout_apply_kernel(const float* in, int ldi, float* out, int ldo, const uint8_t* mask, int n, int cols) {
-    const long total = (long)n * cols;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / cols; const int c = (int)(e - r * cols);
-        out[r * ldo + c] = mask[e] ? in[r * ldi + c] * 2.f : 0.f;
-    }
-}
-
 // out_layer + softmax + cross-entropy on unpacked arena weights W[270][15], b[15]
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ R2, const float* __restrict__ W,
                                                         const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
@@ -481,26 +472,6 @@ __global__ void mean_kernel(const float* v, int n, float* out) {
     for (int e = threadIdx.x; e < n; e += blockDim.x) s += v[e];
     s = block_sum(s, s_red);
     if (threadIdx.x == 0) out[0] = (float)(s / n);
-}
-
-// g[n][ldg] *= (act[n][lda] > 0) [* mask*2]   (ReLU backward, optionally through a dropout in front of it)
-__global__ void relu_mask_kernel(float* g, int ldg, const float* act, int lda, const uint8_t* mask, int n, int cols) {
-    const long total = (long)n * cols;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / cols; const int c = (int)(e - r * cols);
-        float v = g[r * ldg + c];
-        if (mask) v = mask[e] ? v * 2.f : 0.f;
-        g[r * ldg + c] = act[r * lda + c] > 0.f ? v : 0.f;
-    }
-}
-
-// g[t][n][540] = g * mask5[t] * 2 (dropout in front of d1), all towers
-__global__ void dropout_bwd_kernel(Ptr3 g, const uint8_t* mask, int n) {
-    const int t = blockIdx.y;
-    float* p = sel3(g.p, t);
-    const long total = (long)n * kFlat;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
-        p[e] = mask[(size_t)t * total + e] ? p[e] * 2.f : 0.f;
 }
 
 // out[j] = sum_r g[r][ldg + j]   (64 columns x 4 row groups per block, fixed summation order)
@@ -834,14 +805,14 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     g.M = n; g.K4 = kFlat; g.K = kFlat; g.N = kD1; g.relu = 1;
     for (int t = 0; t < kTowers; ++t) {
         const TowerOff T = tower_off(t * kTowerFloats);
-        g.p[t] = GemmProblem{w->H5[t], kFlat, P + T.d1W, kD1, P + T.d1b, w->feat + t * kD1, kFlat};
+        // feat = relu(H5 W + b) (kept: it gates the backward pass), featd = f1_drop(feat), both from the GEMM epilogue
+        g.p[t] = GemmProblem{w->H5[t], kFlat, P + T.d1W, kD1, P + T.d1b, w->feat + t * kD1, kFlat,
+                             mask1 + t * kD1, kFlat, nullptr, 0, w->featd + t * kD1, kFlat};
     }
     gemm_launch(g, kTowers, st);
-    hipLaunchKernelGGL(dropout_apply_kernel, ew_grid((long)n * kFlat), dim3(256), 0, st, w->feat, kFlat, w->featd, kFlat, mask1, n, kFlat);
     g.K4 = kFC1; g.K = kFC1; g.N = kFC1;
-    g.p[0] = GemmProblem{w->featd, kFlat, P + H.fc1W, kFC1, P + H.fc1b, w->R1, kFC1};
-    gemm_launch(g, 1, st);
-    hipLaunchKernelGGL(dropout_apply_kernel, ew_grid((long)n * kFC1), dim3(256), 0, st, w->R1, kFC1, w->cat2, kFC1ld, mask2, n, kFC1);
+    g.p[0] = GemmProblem{w->featd, kFlat, P + H.fc1W, kFC1, P + H.fc1b, w->R1, kFC1, mask2, kFC1, nullptr, 0, w->cat2, kFC1ld};
+    gemm_launch(g, 1, st);                    // R1 = relu(.), cat2[:, :540] = f2_drop(R1)
     hipLaunchKernelGGL(atlas_cols_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, w->cat2, n);   // cols 540..555
     g.K4 = kFC1ld; g.K = kFC1 + kAtlas; g.N = kFC2;
     g.p[0] = GemmProblem{w->cat2, kFC1ld, P + H.fc2W, kFC2, P + H.fc2b, w->R2, kFC2ld};
@@ -887,18 +858,16 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     bg.p[0] = GemmProblem{aTc, ldT, w->dR2, kFC2ld, nullptr, G + H.fc2W, kFC2};
     gemm_launch(bg, 1, sd);
     bg.M = n; bg.K4 = kFC2ld; bg.K = kFC2; bg.N = kFC1;
-    bg.p[0] = GemmProblem{w->dR2, kFC2ld, wT2, kFC1, nullptr, w->dcat, kFC1};
-    gemm_launch(bg, 1, st);
-    hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFC1), dim3(256), 0, st, w->dcat, kFC1, w->R1, kFC1, mask2, n, kFC1);
+    bg.p[0] = GemmProblem{w->dR2, kFC2ld, wT2, kFC1, nullptr, w->dcat, kFC1, mask2, kFC1, w->R1, kFC1, nullptr, 0};
+    gemm_launch(bg, 1, st);                   // through f2_drop and FC1's ReLU in the epilogue
     // FC1: dW1 (sd) needs the masked dcat; dfeat (st)
     fork();
     bg.M = kFlat; bg.K4 = (n + 3) / 4 * 4; bg.K = n; bg.N = kFC1;
     bg.p[0] = GemmProblem{aTf, ldT, w->dcat, kFC1, nullptr, G + H.fc1W, kFC1};
     gemm_launch(bg, 1, sd);
     bg.M = n; bg.K4 = kFC1; bg.K = kFC1; bg.N = kFlat;
-    bg.p[0] = GemmProblem{w->dcat, kFC1, wT1, kFlat, nullptr, w->dfeat, kFlat};
-    gemm_launch(bg, 1, st);
-    hipLaunchKernelGGL(relu_mask_kernel, ew_grid((long)n * kFlat), dim3(256), 0, st, w->dfeat, kFlat, w->feat, kFlat, mask1, n, kFlat);
+    bg.p[0] = GemmProblem{w->dcat, kFC1, wT1, kFlat, nullptr, w->dfeat, kFlat, mask1, kFlat, w->feat, kFlat, nullptr, 0};
+    gemm_launch(bg, 1, st);                   // through f1_drop and the d1 ReLUs in the epilogue
     fork();                                   // the masked dfeat is final
     // bias gradients of fc_2, FC1 and the three d1 layers: column sums of the (masked) upstream gradients, one launch
     {
@@ -920,12 +889,10 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
     }
     gemm_launch(bg, kTowers, sd);
     bg.M = n; bg.K4 = kD1; bg.K = kD1; bg.N = kFlat;
-    for (int t = 0; t < kTowers; ++t) bg.p[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kFlat, kFlat, nullptr, w->dX[t][0], kFlat};
+    for (int t = 0; t < kTowers; ++t)         // through the dropout in front of d1 (mask5 of the tower) in the epilogue
+        bg.p[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kFlat, kFlat, nullptr, w->dX[t][0], kFlat,
+                              mask5 + (size_t)t * n * kFlat, kFlat, nullptr, 0, nullptr, 0};
     gemm_launch(bg, kTowers, st);
-    {
-        Ptr3 gp{{w->dX[0][0], w->dX[1][0], w->dX[2][0]}};
-        hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid((long)n * kFlat).x, kTowers), dim3(256), 0, st, gp, mask5, n);
-    }
 
     // ---- backward: conv blocks 5..1 (dX ping-pongs between the two buffers)
     int cur = 0;

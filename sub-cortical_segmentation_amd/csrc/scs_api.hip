@@ -37,7 +37,7 @@ using CfgConv12 = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 
 using CfgConv12V = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_VOLUME, 496, 2, 2>;
 using CfgConv3 = ConvCfg<20, 40, 14, 2, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 3>;
 using CfgConv4 = ConvCfg<40, 40, 12, 1, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 4>;
-using CfgConv5 = ConvCfg<40, 60, 5, 8, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 2>;
+using CfgConv5 = ConvCfg<40, 60, 5, 7, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 3>;     // 7 x 9 = 63 of 64 rows: four full tiles
 
 // ----------------------------------------------------------------------------- packing kernels
 // conv i (Cin >= 4): packed chunks (scs_common.h), element = W[n][4*c4+kk][2-dy][2-dx] * scale[n]  (true conv -> correlation)

@@ -168,6 +168,11 @@ int main(int argc, char** argv) {
         run<ConvCfg<40, 40, 12, 2, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 2, 0, 8>>("conv4 G2 NW8 WPS2", n, rounds, c4);
         run<ConvCfg<40, 60, 5, 16, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 1>>("conv5 G16 WPS1", n, rounds, c5);
         run<ConvCfg<40, 60, 5, 8, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 2>>("conv5 G8 WPS2", n, rounds, c5);
+        run<ConvCfg<40, 60, 5, 4, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 4>>("conv5 G4 WPS4", n, rounds, c5);
+        run<ConvCfg<40, 60, 5, 7, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 3>>("conv5 G7 WPS3", n, rounds, c5);
+        run<ConvCfg<40, 60, 5, 6, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 3>>("conv5 G6 WPS3", n, rounds, c5);
+        run<ConvCfg<40, 60, 5, 14, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 2>>("conv5 G14 WPS2", n, rounds, c5);
+        run<ConvCfg<40, 60, 5, 12, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 2>>("conv5 G12 WPS2", n, rounds, c5);
         printf("\n");
     }
     return 0;

@@ -2,7 +2,7 @@
 // M = patches of the chunk.  Replaces the DenseLayer(+rectify) nodes of /root/reference/cnn_cort/nets.py:
 // <tower>_d1 (:179), FC1 (:217), fc_2 (:227).  W arrives packed [K4][NS] (zero padded rows/columns).
 //
-// Workgroup = 4 waves, tile 128 rows x 96 columns, K walked in slabs of 32 staged through LDS (register
+// Workgroup = 4 waves, tile 128 rows x 96 columns, K walked in slabs of BK staged through LDS (register
 // prefetch of slab s+1 while slab s feeds the MFMAs); each wave owns 2 M-tiles x 6 N-tiles (12 accumulators).
 // LDS images: A rows padded to 34 floats (bank = 2*row + k: the 16 rows x 2 k of a 32-lane read group hit 32
 // distinct banks), W rows padded to 112 (112 % 32 == 16).
@@ -52,8 +52,8 @@ struct GemmTile {
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int MT, int NT, int BK = 32>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
+template <int MT, int NT, int BK = 32, int WPC = 2>
+__global__ __launch_bounds__(256, WPC) void gemm_mfma_kernel(GemmArgs g) {
     using T = GemmTile<MT, NT, BK>;
     constexpr int kGemmBK = BK, kGemmAS = T::AS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -213,9 +213,14 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
     }
 }
 
+#ifndef SCS_GEMM_BK
+#define SCS_GEMM_BK 16           // K slab and workgroups per CU of the throughput (128 x 96) configuration: a 16-wide
+#define SCS_GEMM_WPC 3           // slab keeps the LDS image at 32 KB, so 3-4 workgroups share a CU (BK 32 / 2 per CU: -9 %)
+#endif
+
 inline hipError_t gemm_set_attrs() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<2, 6, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)GemmTile<2, 6, 32>::LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<2, 6, SCS_GEMM_BK, SCS_GEMM_WPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)GemmTile<2, 6, SCS_GEMM_BK>::LDS);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<1, 3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)GemmTile<1, 3, 32>::LDS);
@@ -227,14 +232,14 @@ inline hipError_t gemm_set_attrs() {
 // latency configuration when even that leaves most CUs without a workgroup (training batches)
 inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
     if (g.M <= 0) return;
-    using Big = GemmTile<2, 6, 32>;
+    using Big = GemmTile<2, 6, SCS_GEMM_BK>;
     using Small = GemmTile<1, 3, 32>;
     using Lat = GemmSplitK;
     const long big_wgs = (long)((g.M + Big::BM - 1) / Big::BM) * ((g.N + Big::BN - 1) / Big::BN) * nproblems;
     const long small_wgs = (long)((g.M + Small::BM - 1) / Small::BM) * ((g.N + Small::BN - 1) / Small::BN) * nproblems;
     if (big_wgs >= 192) {
         dim3 grid((g.M + Big::BM - 1) / Big::BM, (g.N + Big::BN - 1) / Big::BN, nproblems);
-        hipLaunchKernelGGL((gemm_mfma_kernel<2, 6, 32>), grid, dim3(256), Big::LDS, st, g);
+        hipLaunchKernelGGL((gemm_mfma_kernel<2, 6, SCS_GEMM_BK, SCS_GEMM_WPC>), grid, dim3(256), Big::LDS, st, g);
     } else if (small_wgs > 256) {
         dim3 grid((g.M + Small::BM - 1) / Small::BM, (g.N + Small::BN - 1) / Small::BN, nproblems);
         hipLaunchKernelGGL((gemm_mfma_kernel<1, 3, 32>), grid, dim3(256), Small::LDS, st, g);

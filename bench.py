@@ -87,6 +87,36 @@ def cpu_baseline(weights, budget_s=12.0, batch=128):
                       % (done, batch, dt)}
 
 
+def cpu_baseline_volume(weights, budget_s=12.0, chunk=4096, batch=128):
+    """Whole-subject stand-in: the literal per-voxel patch extraction of
+    load_patch_batch / get_patches (oracle/patches_ref.py; one np.pad of the volume per view and chunk, then one slice
+    per voxel - the reference does this per 100 000-voxel chunk) + the torch-CPU forward in nolearn's batches of 128,
+    on a bounded sample of ROI voxels of a synthetic 256x256x192 volume."""
+    import torch
+    from oracle import patches_ref as R, torch_ref as T
+    from cnn_cort import synth
+    cores = usable_cpus()
+    torch.set_num_threads(cores)
+    shape = (256, 256, 192)
+    vol = R.zscore_inference(synth.smooth_volume(shape, seed=0, as_int=True))
+    rng = np.random.RandomState(0)
+    net = T.FoldedCPUNet(weights)
+    done, t0 = 0, time.time()
+    while done == 0 or time.time() - t0 < budget_s:
+        centers = [tuple(int(rng.randint(40, s - 40)) for s in shape) for _ in range(chunk)]
+        views = [np.stack([np.array(R.get_patches(vol, centers, (32, 32), mode=m)).astype(np.float32)], axis=1)
+                 for m in ('axial', 'coronal', 'saggital')]
+        atlas_rows = rng.dirichlet(np.ones(15), size=chunk).astype(np.float32)
+        for lo in range(0, chunk, batch):
+            net.forward(*[torch.from_numpy(v[lo:lo + batch]) for v in views], torch.from_numpy(atlas_rows[lo:lo + batch]))
+        done += chunk
+    dt = time.time() - t0
+    return {'value': done / dt, 'unit': 'patches/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d ROI voxels of a 256x256x192 volume in chunks of %d: literal get_patches per view + float32 torch-CPU '
+                      'forward in batches of %d, %.1f s (a 400 000-voxel subject would take %.0f s)'
+                      % (done, chunk, batch, dt, 400000 * dt / done)}
+
+
 def cpu_baseline_train(weights, budget_s=12.0, batch=256):
     """Training-step stand-in on the host cores: the torch-CPU restatement (autograd backward) + Adam, float32,
     batch 256, explicit dropout masks - BASELINE.md section 3, config 3."""
@@ -236,7 +266,7 @@ def main():
                          for i in range(8)}
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
     if rank == 0 and world == 1 and not args.no_cpu:
-        out['cpu_baseline'] = cpu_baseline_train(weights) if args.mode == 'train' else cpu_baseline(weights)
+        out['cpu_baseline'] = {'train': cpu_baseline_train, 'volume': cpu_baseline_volume, 'forward': cpu_baseline}[args.mode](weights)
     if rank == 0:
         print(json.dumps(out, default=float))
     h.close()

@@ -240,3 +240,11 @@ def test_two_handles_on_two_streams(handle, weights):
         other.close()
     for name in ('a', 'b'):
         assert np.array_equal(outs[name][0], ref_p) and np.array_equal(outs[name][1], ref_l)
+
+
+def test_forward_is_deterministic(handle):
+    g = gold('g2_volume.npz')
+    first = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+    for _ in range(4):
+        again = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+        assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])

@@ -201,3 +201,28 @@ def test_three_step_trajectory_matches_oracle(fresh, weights):
     # level (|g| ~ eps of Adam), never more than a handful of entries and never by more than the steps themselves
     # observed: worst 6.5e-5, none above 1e-4
     assert worst <= 1e-3 and n_off <= 50
+
+
+def test_training_step_is_deterministic(weights):
+    """Fixed-order reductions everywhere (no atomics, the side stream only changes WHEN kernels run): two handles fed
+    the same batch and masks produce bit-identical losses, gradient arenas and parameters, step after step."""
+    from cnn_cort import _hip
+    g = gold('g5_train.npz')
+    n = g['ax'].shape[0]
+    masks = dev(pack_masks({k[5:]: g[k] for k in g.files if k.startswith('mask_')}), torch.uint8)
+    d_in = [dev(g['ax']), dev(g['co']), dev(g['sa']), dev(g['atlas']), dev(g['y'], torch.uint8)]
+    st = torch.cuda.current_stream().cuda_stream
+    runs = []
+    for _ in range(2):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        rec = []
+        for step in range(3):
+            loss = h.train_step(*d_in, n, masks=masks, stream=st)
+            grads = arena(h, 'grad')
+            h.adam_apply(stream=st)
+            rec.append((loss, grads, arena(h, 'param')))
+        runs.append(rec)
+        h.close()
+    for (l0, g0, p0), (l1, g1, p1) in zip(*runs):
+        assert l0 == l1 and np.array_equal(g0, g1) and np.array_equal(p0, p1)

@@ -226,3 +226,33 @@ def test_training_step_is_deterministic(weights):
         h.close()
     for (l0, g0, p0), (l1, g1, p1) in zip(*runs):
         assert l0 == l1 and np.array_equal(g0, g1) and np.array_equal(p0, p1)
+
+
+def test_eval_batch_over_several_chunks(fresh):
+    """scs_eval_batch on more rows than one internal chunk: loss sum and correct count equal what the forward pass
+    gives for the same rows (the hold-out pass of fit() goes through it in large slices)."""
+    from cnn_cort import synth
+    n = 70001
+    ax, co, sa, at = synth.patch_batch(n, seed=9)
+    st = torch.cuda.current_stream().cuda_stream
+    d = [dev(ax), dev(co), dev(sa), dev(at)]
+    probs = torch.empty((n, 15), device='cuda:0')
+    labels = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+    fresh.forward(*d, n, probs, labels, st)
+    torch.cuda.synchronize()
+    p = probs.cpu().numpy().astype(np.float64)
+    # labels: the prediction, or (every fourth row) the runner-up where its probability is large enough for
+    # -log(float32 p) to be a meaningful reference
+    order = np.argsort(p, axis=1)
+    y = order[:, -1].copy()
+    second = order[:, -2]
+    flip = (np.arange(n) % 4 == 0) & (p[np.arange(n), second] > 1e-12)
+    y[flip] = second[flip]
+    y = y.astype(np.uint8)
+    assert flip.sum() > 1000
+    want_loss = float(-np.log(p[np.arange(n), y]).sum())
+    assert np.isfinite(want_loss)
+    want_correct = int((labels.cpu().numpy() == y).sum())
+    ls, nc = fresh.eval_batch(*d, dev(y, torch.uint8), n, stream=st)
+    assert nc == want_correct
+    assert abs(ls - want_loss) <= 1e-4 * abs(want_loss)

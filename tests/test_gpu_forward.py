@@ -248,3 +248,31 @@ def test_forward_is_deterministic(handle):
     for _ in range(4):
         again = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
         assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+
+
+def test_large_n_is_chunked_consistently(handle):
+    """300 001 patches in one call (ten internal chunks, 3.7 GB of inputs): every row is a distribution, and slices
+    from the beginning, the middle and the ragged tail equal separate small calls on the same rows."""
+    n = 300001
+    gen = torch.Generator(device='cuda:0')
+    gen.manual_seed(1)
+    ax, co, sa = [torch.randn((n, 1, 32, 32), generator=gen, device='cuda:0') for _ in range(3)]
+    at = torch.rand((n, 15), generator=gen, device='cuda:0')
+    at = at / at.sum(1, keepdim=True)
+    pr = torch.empty((n, 15), device='cuda:0')
+    lb = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    handle.forward(ax, co, sa, at, n, pr, lb, st)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(pr).all()) and float((pr.sum(1) - 1).abs().max()) < 1e-5
+    assert bool((pr.argmax(1).to(torch.int32) == lb).all())
+    m = 555
+    for lo in (0, 150000, n - m):
+        p2 = torch.empty((m, 15), device='cuda:0')
+        l2 = torch.empty((m,), dtype=torch.int32, device='cuda:0')
+        handle.forward(ax[lo:lo + m], co[lo:lo + m], sa[lo:lo + m], at[lo:lo + m], m, p2, l2, st)
+        torch.cuda.synchronize()
+        assert float((p2 - pr[lo:lo + m]).abs().max()) < 1e-5      # the small call takes the split-K dense kernels
+        srt = torch.sort(p2, dim=1).values
+        clear = (srt[:, -1] - srt[:, -2]) > 1e-4
+        assert bool((l2 == lb[lo:lo + m])[clear].all())

@@ -44,6 +44,11 @@ def load_options(user_config):
     options['post_process'] = user_config.get('model', 'post_process').strip()
     options['crop'] = user_config.get('model', 'speedup_segmentation').strip()
     options['device'] = device_from_mode(options['mode'])
+    # optional keys the reference's configuration.cfg does not have
+    if user_config.has_option('model', 'augment'):
+        options['augment'] = user_config.get('model', 'augment').strip()
+    if user_config.has_option('model', 'seed'):
+        options['seed'] = user_config.getint('model', 'seed')
     return options
 
 

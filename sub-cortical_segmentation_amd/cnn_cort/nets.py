@@ -483,7 +483,8 @@ def build_model(weights_path, options):
     net = Net(weights_file=net_weights, history_file=net_history,
               max_epochs=options['max_epochs'], patience=options['patience'], eval_size=options['train_split'],
               batch_size=options.get('batch_size') or 128, verbose=options['net_verbose'],
-              device=options.get('device'), augment=is_true(options.get('augment')))
+              device=options.get('device'), augment=is_true(options.get('augment')),
+              seed=int(options.get('seed') or 0))
     if is_true(options['load_weights']):
         if net.verbose:
             print("    --> loading weights from ", net_weights)

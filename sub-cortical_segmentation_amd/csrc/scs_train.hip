@@ -5,10 +5,12 @@
 // alpha 0.1) -> ReLU -> PReLU (identity on ReLU output, zero alpha gradient: SURVEY F2) -> max-pool, dropout 0.5,
 // dense layers, softmax + mean categorical cross-entropy (nets.py:235), Adam (nets.py:236-237).
 //
-// Forward convolutions (raw, unfolded weights) and the data gradients (correlation of the zero-padded output
-// gradient with the channel-transposed filters) run on the same fp32 MFMA kernel as inference (conv_mfma.h);
-// BN statistics/gradients are per-channel reductions with double accumulators; weight gradients and the
-// dense-layer backward GEMMs are plain LDS-tiled vector-ALU kernels in this round.
+// Forward convolutions (raw, unfolded weights; their epilogue also leaves the per-patch BN sums) and the data gradients
+// (correlation of the zero-padded output gradient with the channel-transposed filters) run on the same fp32 MFMA
+// kernel as inference (conv_mfma.h); weight gradients on wgrad_mfma.h; every dense product (forward, data and weight
+// gradients) on the split-K MFMA GEMM of gemm_mfma.h with dropout / ReLU masks in its epilogue.  BN passes are one
+// workgroup per (channel, tower, batch slice) with double-precision, fixed-order reductions: the step is deterministic.
+// Weight-gradient work runs on a second stream beside the data-gradient path (fork / join events inside the call).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +25,8 @@
 namespace scs {
 
 // ------------------------------------------------------------------------------------------- configurations
+// tuned at the training batch size (tools/kbench.hip train; profiles/r01_kbench_train_batch.txt): finer bands / one
+// patch per workgroup than at inference, where a launch is many rounds of workgroups
 using TF2 = ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_NCHW, 180, 7, 4>;
 using TF3 = ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_NCHW, 208, 1, 4>;
 using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_NCHW, 144, 1, 4>;

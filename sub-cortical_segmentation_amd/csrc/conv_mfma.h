@@ -2,7 +2,8 @@
 //
 // One workgroup (NW waves, 4 unless stated) owns G whole patches.  Their input planes sit in LDS ([g][cin][PLANE]); the
 // GEMM view is  out[pixel][cout] = sum_k in[pixel @ (cin,tap)] * W[(cin,tap)][cout]  with
-//   M = G * output pixels (16 per MFMA tile), N = Cout padded to 16s, K = Cin*9 walked as
+//   M = G * output pixels (16 per MFMA tile), N = Cout = 16-wide blocks + 4-wide blocks (scs_common.h: no padding),
+//   K = Cin*9 walked as
 //   (cin-group of 4) x (9 taps) so that one k-step = 4 consecutive input channels at one tap:
 //   lane l supplies A[pixel l&15][cin 4c+(l>>4)] (one ds_read_b32 at  base + tap offset) and
 //   B[cin 4c+(l>>4)][cout l&15] (one ds_read_b32 of the packed weight chunk).

@@ -522,14 +522,22 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
         const bool more = s + hstep < n;
         std::thread next;
         hipError_t nerr = hipSuccess;
-        if (more) next = std::thread(upload, s + hstep, which ^ 1, &nerr);       // the other buffer: its results were read back
+        bool inline_upload = false;
+        if (more) {
+            try {
+                next = std::thread(upload, s + hstep, which ^ 1, &nerr);      // the other buffer: its results were read back
+            } catch (...) {                                                     // no thread to be had: upload after the kernels instead
+                inline_upload = true;
+            }
+        }
         const Buf& d = buf[which];
         rc = forward_chunk(h, d.ax, d.co, d.sa, d.at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d.pr, d.lb, sc, nullptr);
         hipError_t e = hipSuccess;
         if (rc == SCS_OK && probs) e = hipMemcpyAsync(probs + s * 15, d.pr, m * 60, hipMemcpyDeviceToHost, sc);
         if (rc == SCS_OK && e == hipSuccess && labels) e = hipMemcpyAsync(labels + s, d.lb, m * 4, hipMemcpyDeviceToHost, sc);
         if (e == hipSuccess) e = hipStreamSynchronize(sc);
-        if (more) next.join();
+        if (next.joinable()) next.join();
+        if (inline_upload) upload(s + hstep, which ^ 1, &nerr);
         if (rc != SCS_OK) return rc;
         SCS_HIP(e);
         SCS_HIP(nerr);

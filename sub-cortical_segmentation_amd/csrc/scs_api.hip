@@ -557,7 +557,8 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
     const int nchunks = (int)((n + step - 1) / step);
-    std::vector<hipEvent_t> ev((size_t)nchunks * 9);
+    std::vector<hipEvent_t> ev;
+    try { ev.resize((size_t)nchunks * 9); } catch (...) { set_error("out of host memory"); return SCS_ERR_HIP; }
     for (auto& e : ev) SCS_HIP(hipEventCreate(&e));
     int c = 0;
     for (int64_t s = 0; s < n; s += step, ++c) {

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <new>
 #include <type_traits>
 #include <vector>
 
@@ -100,7 +101,10 @@ void train_free(scs_ctx* h) {
 }
 
 static int train_ensure(scs_ctx* h, int n) {
-    if (!h->tws) h->tws = new TrainWs();
+    if (!h->tws) {
+        h->tws = new (std::nothrow) TrainWs();
+        if (!h->tws) { set_error("out of host memory"); return SCS_ERR_HIP; }
+    }
     TrainWs* w = h->tws;
     if (!w->pack_base) {
         size_t off = 0;

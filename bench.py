@@ -9,7 +9,10 @@ A "step" is one pass of the hot path over one batch of synthetic input resident 
       scs_forward (probabilities + labels), shipped miccai2012_v1 weights.
   train   (BASELINE configs[2]/[3]):     one scs_train_step + gradient all-reduce (RCCL, N > 1) + scs_adam_apply
       on B = 256 samples per GPU.
-N > 1: launched by torchrun, one rank per GPU; ranks process independent batches (weak scaling), the forward
+N > 1: one rank per GPU over RCCL.  Either launched by torchrun (RANK/WORLD_SIZE/... in the environment) or, when
+`--gpus N` is given without that environment, bench.py starts the N ranks itself as child processes (torchrun,
+127.0.0.1) before touching the GPU; a world size that differs from --gpus is an error, never a silent 1-GPU run.
+Ranks process independent batches (weak scaling), the forward
 path has no collective, the training path exactly one (the gradient arena).  Timing = K steps between
 barrier + synchronize brackets, max over ranks; rank 0 prints ONE JSON line.
 
@@ -143,6 +146,23 @@ def cpu_baseline_train(weights, budget_s=12.0, batch=256):
                       % (done // batch, batch, dt)}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no torchrun environment: start N ranks as CHILD processes (one per GPU,
+    torch.distributed.run, rendezvous on 127.0.0.1) and exit with their code.  Called before anything in this process
+    touches the GPU (importing torch does not; counting devices does not initialise the runtime on this image)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # RCCL needs dmabuf IPC on this pool
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -152,14 +172,44 @@ def main():
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher rehearsal without a GPU: ranks rendezvous (gloo), run the barrier / max-over-ranks '
+                         'timing brackets around an empty step and rank 0 prints a line marked "dry_run": true, value null')
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    env_world = int(os.environ.get('WORLD_SIZE', '1'))
+    if env_world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s); refusing to report a run whose '
+                         'world size differs from --gpus' % (args.gpus, env_world))
 
     import torch
-    from cnn_cort import _hip, dist, params as P
+    from cnn_cort import dist
 
-    rank, world, local = dist.init_from_env()
+    if args.dry_run:
+        rank, world, _ = dist.init_from_env(backend='gloo')
+        assert world == args.gpus
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.barrier()
+        dt = dist.max_scalar(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({'metric': 'tri-view 32x32 patches/s (%s)' % args.mode, 'value': None, 'unit': 'patches/s',
+                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+                              'dry_run': True, 'bracket_s': dt}))
+        return
+
+    from cnn_cort import _hip, params as P
+
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device')
+    if torch.cuda.device_count() < args.gpus and not os.environ.get('SCS_DIST_BACKEND'):
+        raise SystemExit('bench.py: --gpus %d but only %d HIP device(s) are visible (set SCS_DIST_BACKEND=gloo for a '
+                         'shared-GPU rehearsal)' % (args.gpus, torch.cuda.device_count()))
+    rank, world, local = dist.init_from_env()
+    assert world == args.gpus, (world, args.gpus)
     torch.cuda.set_device(local)
     dev = 'cuda:%d' % local
     weights = P.load_params(os.path.join(PKG, 'nets', 'miccai2012_v1', 'miccai2012_v1'))

@@ -34,6 +34,14 @@ extern "C" {
 
 typedef struct scs_ctx* scs_handle;
 
+/* One z-scored volume inside a concatenated device buffer of volumes (gather-fused training, scs_train_step_volume):
+ * `offset` floats from the start of the buffer, C order [dim_x][dim_y][dim_z]. */
+typedef struct {
+    int64_t offset;
+    int32_t dim_x, dim_y, dim_z;
+    int32_t reserved;
+} scs_volume;
+
 typedef enum {
     SCS_OK = 0,
     SCS_ERR_ARG = -1,        /* bad argument (null pointer, wrong size, n < 0 ...) */
@@ -120,9 +128,44 @@ int scs_train_step(scs_handle h, const float* ax_dev, const float* co_dev, const
                    const float* atlas_dev, const uint8_t* y_dev, int64_t n, uint64_t dropout_seed,
                    const uint8_t* masks_dev, float* loss_host, void* stream);
 
+/* Gather-fused training step: the same step, but the 32x32 tri-planar patches are cut inside the kernels from z-scored
+ * volumes resident on the device, so a training set is 77 bytes per sample (sample row + prior row + label) instead of
+ * 12.3 KB of materialised patches.
+ *   vols_dev       float32, all training volumes concatenated (each [X][Y][Z], C order, normalised as base.py:146)
+ *   descs_dev      scs_volume[*] (device memory): where each volume lies in vols_dev and its dims
+ *   samples_dev    int32 [N][4]: (volume, x, y, z) of every sample of the training set; the patch of a sample is cut around
+ *                  its voxel exactly as get_patches does (base.py:293-306; zero padded outside the volume)
+ *   atlas_rows_dev float32 [N][15], y_dev uint8 [N]: prior vector and class id (0..14) of every sample
+ *   index_dev      int32 [n]: the rows of samples / atlas_rows / y that form THIS batch - generate_training_set's permutation
+ *                  (base.py:92-103) as an index array - or NULL for rows 0..n-1
+ * Replaces: load_patch_vectors + generate_training_set materialising [N,1,32,32] x 3 (base.py:120-184, 53-117) in front of
+ * net.fit.  Results are bit-identical to scs_train_step on the materialised patches. */
+int scs_train_step_volume(scs_handle h, const float* vols_dev, const scs_volume* descs_dev, const int32_t* samples_dev,
+                          const float* atlas_rows_dev, const uint8_t* y_dev, const int32_t* index_dev, int64_t n,
+                          uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, void* stream);
+
+/* Class id of every sample: the label volume at the sample's voxel, with the boundary class 15 mapped to background 0
+ * (generate_training_set, base.py:85-89).  label_vols_dev: uint8, concatenated like vols_dev (same descs). */
+int scs_gather_labels(scs_handle h, const uint8_t* label_vols_dev, const scs_volume* descs_dev, const int32_t* samples_dev,
+                      int64_t n_samples, uint8_t* y_dev, void* stream);
+
+/* Labelled evaluation / inference on the same compact form (deterministic forward, patches cut in the first kernel). */
+int scs_eval_batch_volume(scs_handle h, const float* vols_dev, const scs_volume* descs_dev, const int32_t* samples_dev,
+                          const float* atlas_rows_dev, const uint8_t* y_dev, const int32_t* index_dev, int64_t n,
+                          double* loss_sum_host, int64_t* n_correct_host, void* stream);
+
+/* Measurement hook (bench.py --mode train): one scs_train_step with HIP events recorded around every launch on the stream
+ * it is issued on (the weight-gradient kernels run on an internal side stream); synchronises.  stage_ms[i] = summed
+ * duration of the launches of stage i, i < scs_train_stage_count(); scs_train_stage_name(i) names it. */
+int scs_train_stage_count(void);
+const char* scs_train_stage_name(int stage);
+int scs_train_step_profiled(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,
+                            const float* atlas_dev, const uint8_t* y_dev, int64_t n, uint64_t dropout_seed,
+                            float* stage_ms, void* stream);
+
 /* Device pointers to the parameter and gradient arenas (SCS_N_PARAMS floats each) - the gradient arena is
  * what a data-parallel caller all-reduces (RCCL) between scs_train_step and scs_adam_apply. */
-int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n);
+int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n);   /* marks the inference operands stale: the caller may write */
 int scs_grad_arena(scs_handle h, float** dev_ptr, size_t* n);
 
 /* Device address of the mean loss of the most recent scs_train_step (one float, valid once that step's work on its
@@ -136,7 +179,7 @@ int scs_train_loss(scs_handle h, float** dev_ptr);
 int scs_adam_apply(scs_handle h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* Deterministic forward + summed cross-entropy + number of correct argmax predictions on n labelled
- * samples (nolearn eval_iter_).  Synchronises. */
+ * samples (nolearn eval_iter_).  Synchronises.  The sums are formed in a fixed order (bit-reproducible). */
 int scs_eval_batch(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,
                    const float* atlas_dev, const uint8_t* y_dev, int64_t n,
                    double* loss_sum_host, int64_t* n_correct_host, void* stream);

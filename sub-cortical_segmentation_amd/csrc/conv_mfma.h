@@ -25,21 +25,43 @@ namespace scs {
 constexpr int kW1Floats = 12 * 16 + 12 * 4 + 20;   // conv1 operands: [12][16] + [12][4] + bias[20]
 static_assert(kW1Floats > 256 && kW1Floats <= 512, "conv1 operand staging assumes two loads per thread");
 
-// EPI_RAW_STATS: raw outputs plus, per (patch, band, channel), their sum and sum of squares (batch-norm statistics
-// of the training forward pass without a second pass over the activations)
-enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2, EPI_RAW_STATS = 3 };
-enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3 };
+// Epilogues.
+//   EPI_RAW_STATS      raw outputs plus, per (patch, band, channel), the sum and sum of squares of (output - pivot[channel])
+//                      (batch-norm statistics of the training forward pass without a second pass over the activations; the
+//                      pivot - the channel's running mean - keeps E[v^2] - E[v]^2 free of cancellation)
+//   EPI_RAW_BNB[_POOL] data gradient of a training conv: raw outputs dX plus, per (patch, band, channel), the partial
+//                      sums (d beta, d gamma) of the batch-norm layer BELOW (whose block output X this kernel differentiates):
+//                      dy = dX routed through that block's (max-pool and) ReLU, from its raw conv output `zlow`
+//   EPI_L1             data gradient of conv2 in training: dX1 is never stored.  The block below is conv1 -> BN -> ReLU,
+//                      whose raw output is recomputed from the 32x32 input rows; the kernel leaves, per (patch, band,
+//                      channel c), A[c][tap] = sum_px dy[c][px] * x0[px + tap] and d beta[c] = sum_px dy[c][px], from which
+//                      d W1, d gamma1 follow algebraically (scs_train.hip: l1_final_kernel)
+enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2, EPI_RAW_STATS = 3, EPI_RAW_BNB = 4, EPI_RAW_BNB_POOL = 5, EPI_L1 = 6 };
+// Sources.
+//   SRC_NCHW           [n][CIN][HIN][HIN] activations
+//   SRC_CONV1 / SRC_VOLUME / SRC_X0   the 32x32 input patch (given / cut from one volume at inference / given or cut from
+//                      a set of volumes in training); conv1 (+ folded BN + ReLU) runs first and its output stays in LDS
+//   SRC_NCHW_PAD2      [n][CIN][HIN-4][HIN-4], zero padded by 2 on every side in LDS (data gradients)
+//   SRC_BN[_POOL]      training forward: the previous layer's RAW conv output; y = relu(sc * z + sh) (then 2x2 max-pool of a
+//                      [2 HIN][2 HIN] plane) is applied while staging, and the block output X is stored as a by-product
+//   SRC_DZ[_POOL]_PAD2 training backward: d z = [y > 0 (and arg max of its window)] * sc * dUp + ca * z + cb is computed
+//                      while staging from this layer's raw output z and the upstream gradient dUp (pooled grid for _POOL);
+//                      zero padded by 2; d z is stored as a by-product (the weight-gradient kernel reads it)
+enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3, SRC_BN = 4, SRC_BN_POOL = 5, SRC_DZ_PAD2 = 6,
+               SRC_DZ_POOL_PAD2 = 7, SRC_X0 = 8 };
 
 template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4>
 struct ConvCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_;
     static constexpr int NW = NW_, NTH = 64 * NW_;          // waves / threads per workgroup
-    // SRC_NCHW_PAD2: the global input is (HIN_-4)^2 and is zero-padded by 2 on every side in LDS (dgrad)
+    static constexpr bool PAD2 = (SRC_ == SRC_NCHW_PAD2 || SRC_ == SRC_DZ_PAD2 || SRC_ == SRC_DZ_POOL_PAD2);
+    static constexpr bool FUSED1 = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME || SRC_ == SRC_X0);
+    // PAD2: the global input is (HIN_-4)^2 and is zero-padded by 2 on every side in LDS (dgrad)
     static constexpr int HIN = HIN_, WIN = HIN_;
-    static constexpr int HSRC = (SRC_ == SRC_NCHW_PAD2) ? HIN_ - 4 : HIN_;
+    static constexpr int HSRC = PAD2 ? HIN_ - 4 : HIN_;
     static constexpr int HO = HIN_ - 2;
     static constexpr bool POOL = (EPI_ == EPI_BIAS_RELU_POOL);
-    static constexpr bool RAW = (EPI_ == EPI_RAW || EPI_ == EPI_RAW_STATS);
+    static constexpr bool RAW = (EPI_ >= EPI_RAW);
     static constexpr int HP = HO / 2;
     static constexpr int PIX = HO * HO;                 // conv outputs per patch
     static constexpr int OUTPIX = POOL ? HP * HP : PIX; // stored outputs per patch and channel
@@ -64,33 +86,62 @@ struct ConvCfg {
     static constexpr int IN_FLOATS = G_ * CIN_ * PLANE_;
     static constexpr int IN_FLOATS_AL = (IN_FLOATS + 3) / 4 * 4;
     static constexpr int XS_ROWS_FLOATS = (XROWS * 32 + 3) / 4 * 4;
-    static constexpr int XS_FLOATS = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME) ? XS_ROWS_FLOATS + 4 + kW1Floats : 0;
+    static constexpr int XS_FLOATS = FUSED1 ? XS_ROWS_FLOATS + 4 + kW1Floats : 0;
     // the epilogue restages the outputs in LDS ([g][cout][OSTR], odd stride) and stores them as whole rows
     static constexpr bool OUT_VEC4 = (OUTB % 4 == 0) && (OUTPIX % 4 == 0);
     static constexpr int OSTR = OUT_VEC4 ? OUTB + 4 : (OUTB | 1);
     static constexpr int OUT_FLOATS = G_ * COUT_ * OSTR;
+    // EPI_L1 scratch behind the restaged outputs: the input rows of the band ((HOB + 2) x 32) and the waves' partial A
+    static constexpr int L1_X_FLOATS = (HOB + 2) * 32 + 8, L1_RED_FLOATS = NW_ * 20 * 16;
+    static constexpr int EPI_FLOATS = OUT_FLOATS + (EPI_ == EPI_L1 ? L1_X_FLOATS + L1_RED_FLOATS : 0);
     static constexpr int MAIN_FLOATS = IN_FLOATS_AL + 2 * WCHUNK + XS_FLOATS;
-    static constexpr size_t LDS_BYTES = (size_t)(MAIN_FLOATS > OUT_FLOATS ? MAIN_FLOATS : OUT_FLOATS) * 4;
+    static constexpr size_t LDS_BYTES = (size_t)(MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS) * 4;
     static_assert(CIN_ % 4 == 0, "k-steps are groups of 4 input channels");
     static_assert(COUT_ % 4 == 0, "output channels are covered by 16-wide and 4-wide MFMA blocks");
     static_assert(HO % NB_ == 0 && (!POOL || (HOB % 2 == 0)), "bands must split the output rows (evenly for pooling)");
     static_assert(NB_ == 1 || G_ == 1, "bands: one patch per workgroup");
     static_assert(PLANE_ >= HINB * HIN_, "plane stride too small");
     static_assert(LDS_BYTES * WPS_ <= 160 * 1024, "LDS budget (WPS workgroups per CU)");
-    static_assert(NTH >= 8 * XROWS || (SRC_ != SRC_CONV1 && SRC_ != SRC_VOLUME), "raw patch rows are staged in one pass");
+    static_assert(NTH >= 8 * XROWS || !FUSED1, "raw patch rows are staged in one pass");
+    static_assert((SRC_ != SRC_BN && SRC_ != SRC_BN_POOL) || NB_ == 1, "BN-fused staging takes whole planes");
+    static_assert(SRC_ != SRC_BN || ((HIN_ * HIN_) % 4 == 0 && PLANE_ % 4 == 0), "SRC_BN stages 16-byte pieces");
+    static_assert(SRC_ != SRC_DZ_POOL_PAD2 || (HINB % 2 == 0 && HIN_ % 2 == 0 && PLANE_ % 2 == 0 && (NB_ == 1 || HOB % 2 == 0)),
+                  "pooled d z staging walks 2x2 windows");
+    static_assert(EPI_ != EPI_L1 || (COUT_ == 20 && HO == 30 && G_ == 1 && NW_ == 4), "EPI_L1 is the conv2 data gradient");
+};
+
+// the 32x32 input patches of a training batch: given as three [n][32][32] arrays, or cut on the fly from z-scored
+// volumes resident on the device (tri-planar gather of base.py:293-306 around each sample's centre voxel)
+struct X0Src {
+    const float* views[kTowers];  // null: gather
+    const float* vols;            // all volumes, concatenated
+    const scs_volume* descs;      // per volume: offset into vols, dims
+    const int32_t* samples;       // [N][4]: volume, x, y, z
+    const int32_t* index;         // [n] rows of `samples` that form this batch (null: rows 0..n-1)
 };
 
 struct ConvArgs {
-    const float* in[kTowers];     // SRC_NCHW*: [n][CIN][HSRC][HSRC]; SRC_CONV1: [n][32][32]; SRC_VOLUME: the volume
+    const float* in[kTowers];     // SRC_NCHW*: [n][CIN][HSRC][HSRC]; SRC_CONV1: [n][32][32]; SRC_VOLUME: the volume;
+                                  // SRC_BN*: raw conv output of the layer below; SRC_DZ*: raw conv output of THIS layer
     const float* w[kTowers];      // packed chunks per 4 input channels: [9][4][NS16] + [9][4][L4] (scs_common.h)
-    const float* bias[kTowers];   // [NT*16] (unused for EPI_RAW)
+    const float* bias[kTowers];   // [NT*16] (unused for EPI_RAW*)
     float* out[kTowers];          // [n][COUT][OUTPIX]
-    const float* w1[kTowers];     // SRC_CONV1/VOLUME: conv1 operands [12][16] + [12][4] + bias[20] (kW1Floats)
+    const float* w1[kTowers];     // fused conv1: operands [12][16] + [12][4] + bias[20] (kW1Floats)
     const int32_t* centers;       // SRC_VOLUME: [n][3]
     int dimx, dimy, dimz;
     int n;                        // patches
-    float* stats;                 // EPI_RAW_STATS: [tower][n * NB][COUT][2] (sum, sum of squares) per patch band
+    float* stats;                 // EPI_RAW_STATS / EPI_RAW_BNB*: [tower][n * NB][COUT][2] partial sums per patch band;
+                                  // EPI_L1: [tower][n * NB][20][10]
     unsigned long long* stamps;   // diagnostic builds only (STAMP): [workgroup][8] s_memtime values
+    // ---- training only
+    const float* pivot[kTowers];  // EPI_RAW_STATS: [COUT] statistics pivot (null: 0)
+    const float* bn[kTowers];     // SRC_BN*: float2 [CIN] (scale, shift); SRC_DZ*: float4 [CIN] (sc, sh, ca, cb)
+    float* xout[kTowers];         // SRC_BN*: block output X [n][CIN][HIN][HIN]; SRC_DZ*: d z [n][CIN][HSRC][HSRC] (null: not stored)
+    const float* dup[kTowers];    // SRC_DZ*: upstream gradient
+    const float* zlow[kTowers];   // EPI_RAW_BNB*: raw conv output of the layer below [n][COUT][HO or 2 HO]^2
+    const float* bnlow[kTowers];  // EPI_RAW_BNB*: float4 [COUT] (sc, sh, mean, inv_std) of the layer below; EPI_L1: [20][12] flipped
+                                  // conv1 filters (9), sc, sh, pad
+    X0Src x0;                     // SRC_X0 / EPI_L1: the input patches
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -185,9 +236,9 @@ __device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, cons
 
 // batched copy helper: K independent loads in flight per thread before the LDS writes (a plain strided loop
 // serialises one global-load latency per iteration)
-template <int TOTAL, class V, int NTH = 256, class SrcF, class DstF>
+template <int TOTAL, class V, int NTH = 256, int K = 8, class SrcF, class DstF>
 __device__ __forceinline__ void staged_copy(int tid, SrcF&& src_of, DstF&& dst_of) {
-    constexpr int ITER = (TOTAL + NTH - 1) / NTH, K = 8;
+    constexpr int ITER = (TOTAL + NTH - 1) / NTH;
 #pragma unroll
     for (int i0 = 0; i0 < ITER; i0 += K) {
         V v[K];
@@ -198,6 +249,42 @@ __device__ __forceinline__ void staged_copy(int tid, SrcF&& src_of, DstF&& dst_o
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (i0 + k < ITER) { const int e = tid + NTH * (i0 + k); if (e < TOTAL) dst_of(e, v[k]); }
+        }
+    }
+}
+
+// one element of the tri-planar gather, zero padded (base.py:293-306): patch pixel (i, j) of `tower` around (cx, cy, cz):
+// axial [x-16+i][y-16+j][z], coronal [x-16+i][y][z-16+j], sagittal [x][y-16+i][z-16+j]
+__device__ __forceinline__ float gather_voxel(const float* __restrict__ vol, int dx, int dy, int dz, int tower, int cx, int cy, int cz,
+                                              int i, int j) {
+    int vx, vy, vz;
+    if (tower == 0) { vx = cx - 16 + i; vy = cy - 16 + j; vz = cz; }
+    else if (tower == 1) { vx = cx - 16 + i; vy = cy; vz = cz - 16 + j; }
+    else { vx = cx; vy = cy - 16 + i; vz = cz - 16 + j; }
+    const bool ok = (unsigned)vx < (unsigned)dx && (unsigned)vy < (unsigned)dy && (unsigned)vz < (unsigned)dz;
+    return ok ? vol[((size_t)vx * dy + vy) * dz + vz] : 0.f;
+}
+
+// rows [row0, row0 + NROWS) of the 32x32 input patch g of `tower` -> s_x[NROWS][32]
+template <int NROWS, int NTH>
+__device__ __forceinline__ void load_x0_rows(const X0Src& s, int tower, int g, int row0, float* __restrict__ s_x, int tid) {
+    const float* __restrict__ v = pick3(s.views, tower);
+    if (v) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(v + (size_t)g * 1024 + row0 * 32);
+#pragma unroll
+        for (int e0 = 0; e0 < NROWS * 8; e0 += NTH) {
+            const int e = e0 + tid;
+            if (e < NROWS * 8) reinterpret_cast<float4*>(s_x)[e] = src[e];
+        }
+    } else {
+        const int r = s.index ? s.index[g] : g;
+        const int4 smp = reinterpret_cast<const int4*>(s.samples)[r];
+        const scs_volume d = s.descs[smp.x];
+        const float* __restrict__ vol = s.vols + d.offset;
+#pragma unroll
+        for (int e0 = 0; e0 < NROWS * 32; e0 += NTH) {
+            const int e = e0 + tid;
+            if (e < NROWS * 32) s_x[e] = gather_voxel(vol, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, row0 + (e >> 5), e & 31);
         }
     }
 }
@@ -291,8 +378,141 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                 return ok ? src[(size_t)pl * HW + ys * HS + xs] : 0.f;
             },
             [&](int e, float v) { const int pl = e / BW, r = e - pl * BW; s_in[pl * C::PLANE + r] = v; });
+    } else if constexpr (C::SRC == SRC_BN) {
+        // training forward: x = relu(sc * z + sh) while staging; x is also stored (the weight-gradient kernel reads it)
+        constexpr int HW = C::HIN * C::HIN, HW4 = HW / 4;
+        const float4* __restrict__ src4 = reinterpret_cast<const float4*>(insrc + (size_t)g0 * C::CIN * HW);
+        const float2* __restrict__ bn2 = reinterpret_cast<const float2*>(pick3(a.bn, tower));
+        float* __restrict__ xo = pick3(a.xout, tower);
+        float4* __restrict__ xo4 = xo ? reinterpret_cast<float4*>(xo + (size_t)g0 * C::CIN * HW) : nullptr;
+        float4* dst4 = reinterpret_cast<float4*>(s_in);
+        const int planes = ng * C::CIN;
+        struct V { float4 v; float2 ss; };
+        staged_copy<C::G * C::CIN * HW4, V, C::NTH, 6>(
+            tid,
+            [&](int e) { const int pl = e / HW4; V r; r.ss = bn2[pl % C::CIN];
+                         r.v = (pl < planes) ? src4[e] : float4{0.f, 0.f, 0.f, 0.f}; return r; },
+            [&](int e, V r) {
+                const int pl = e / HW4, q = e - pl * HW4;
+                const float4 y{fmaxf(fmaf(r.v.x, r.ss.x, r.ss.y), 0.f), fmaxf(fmaf(r.v.y, r.ss.x, r.ss.y), 0.f),
+                               fmaxf(fmaf(r.v.z, r.ss.x, r.ss.y), 0.f), fmaxf(fmaf(r.v.w, r.ss.x, r.ss.y), 0.f)};
+                dst4[pl * (C::PLANE / 4) + q] = y;
+                if (xo4 && pl < planes) xo4[e] = y;
+            });
+    } else if constexpr (C::SRC == SRC_BN_POOL) {
+        // training forward: x = maxpool2x2(relu(sc * z + sh)) while staging (one thread per window), x also stored
+        constexpr int HZ = 2 * C::HIN, HWZ = HZ * HZ, W = C::HIN * C::HIN;
+        const float* __restrict__ src = insrc + (size_t)g0 * C::CIN * HWZ;
+        const float2* __restrict__ bn2 = reinterpret_cast<const float2*>(pick3(a.bn, tower));
+        float* __restrict__ xo = pick3(a.xout, tower);
+        if (xo) xo += (size_t)g0 * C::CIN * W;
+        const int planes = ng * C::CIN;
+        struct V { float2 r0, r1, ss; };
+        staged_copy<C::G * C::CIN * W, V, C::NTH, 6>(
+            tid,
+            [&](int e) {
+                const int pl = e / W, wdx = e - pl * W, wy = wdx / C::HIN, wx = wdx - wy * C::HIN;
+                V r; r.ss = bn2[pl % C::CIN];
+                const float* zp = src + (size_t)min(pl, planes - 1) * HWZ + (2 * wy) * HZ + 2 * wx;
+                r.r0 = *reinterpret_cast<const float2*>(zp); r.r1 = *reinterpret_cast<const float2*>(zp + HZ);
+                return r;
+            },
+            [&](int e, V r) {
+                const int pl = e / W, wdx = e - pl * W;
+                const float m = fmaxf(fmaxf(fmaf(r.r0.x, r.ss.x, r.ss.y), fmaf(r.r0.y, r.ss.x, r.ss.y)),
+                                      fmaxf(fmaf(r.r1.x, r.ss.x, r.ss.y), fmaf(r.r1.y, r.ss.x, r.ss.y)));
+                const float y = (pl < planes) ? fmaxf(m, 0.f) : 0.f;
+                s_in[pl * C::PLANE + wdx] = y;
+                if (xo && pl < planes) xo[(size_t)pl * W + wdx] = y;
+            });
+    } else if constexpr (C::SRC == SRC_DZ_PAD2) {
+        // training backward: d z = [sc z + sh > 0] sc dUp + ca z + cb, zero padded by 2; rows the band owns are stored
+        constexpr int HS = C::HSRC, HW = HS * HS, BW = C::HINB * C::WIN;
+        const float* __restrict__ zsrc = insrc + (size_t)g0 * C::CIN * HW;
+        const float* __restrict__ dsrc = pick3(a.dup, tower) + (size_t)g0 * C::CIN * HW;
+        const float4* __restrict__ bn4 = reinterpret_cast<const float4*>(pick3(a.bn, tower));
+        float* __restrict__ dzo = pick3(a.xout, tower);
+        if (dzo) dzo += (size_t)g0 * C::CIN * HW;
+        const int planes = ng * C::CIN;
+        struct V { float z, d; float4 cf; };
+        auto locate = [&](int e, int& pl, int& r, int& idx, bool& own) {
+            pl = e / BW; r = e - pl * BW;
+            const int yl = r / C::WIN, xp = r - yl * C::WIN;
+            const int ys = band * C::HOB + yl - 2, xs = xp - 2;
+            idx = pl * HW + ys * HS + xs;
+            own = yl < C::HOB;
+            return pl < planes && (unsigned)ys < (unsigned)HS && (unsigned)xs < (unsigned)HS;
+        };
+        staged_copy<C::G * C::CIN * BW, V, C::NTH, 6>(
+            tid,
+            [&](int e) {
+                int pl, r, idx; bool own;
+                const bool ok = locate(e, pl, r, idx, own);
+                V v; v.z = ok ? zsrc[idx] : 0.f; v.d = ok ? dsrc[idx] : 0.f;
+                v.cf = ok ? bn4[pl % C::CIN] : float4{0.f, 0.f, 0.f, 0.f};
+                return v;
+            },
+            [&](int e, V v) {
+                int pl, r, idx; bool own;
+                const bool ok = locate(e, pl, r, idx, own);
+                const float dz = ((fmaf(v.z, v.cf.x, v.cf.y) > 0.f) ? v.cf.x * v.d : 0.f) + fmaf(v.cf.z, v.z, v.cf.w);
+                s_in[pl * C::PLANE + r] = dz;                      // all-zero coefficients outside the plane: dz = 0
+                if (dzo && ok && own) dzo[idx] = dz;
+            });
+    } else if constexpr (C::SRC == SRC_DZ_POOL_PAD2) {
+        // same through a 2x2 max-pool: one thread per window of the padded band; dUp lives on the pooled grid and goes
+        // to every position that attains the window maximum (Theano MaxPoolGrad), if the maximum survives the ReLU
+        constexpr int HS = C::HSRC, HW = HS * HS, HPS = HS / 2, WR = C::HINB / 2, WC = C::WIN / 2, WP = WR * WC;
+        const float* __restrict__ zsrc = insrc + (size_t)g0 * C::CIN * HW;
+        const float* __restrict__ dsrc = pick3(a.dup, tower) + (size_t)g0 * C::CIN * HPS * HPS;
+        const float4* __restrict__ bn4 = reinterpret_cast<const float4*>(pick3(a.bn, tower));
+        float* __restrict__ dzo = pick3(a.xout, tower);
+        if (dzo) dzo += (size_t)g0 * C::CIN * HW;
+        const int planes = ng * C::CIN;
+        struct V { float2 r0, r1; float d; float4 cf; };
+        auto locate = [&](int e, int& pl, int& wyl, int& wxp, int& wsy, int& wsx) {
+            pl = e / WP;
+            const int w = e - pl * WP;
+            wyl = w / WC; wxp = w - wyl * WC;
+            wsy = (band * C::HOB) / 2 + wyl - 1; wsx = wxp - 1;
+            return pl < planes && (unsigned)wsy < (unsigned)HPS && (unsigned)wsx < (unsigned)HPS;
+        };
+        staged_copy<C::G * C::CIN * WP, V, C::NTH, 4>(
+            tid,
+            [&](int e) {
+                int pl, wyl, wxp, wsy, wsx;
+                const bool ok = locate(e, pl, wyl, wxp, wsy, wsx);
+                V v;
+                if (ok) {
+                    const float* zp = zsrc + (size_t)pl * HW + (2 * wsy) * HS + 2 * wsx;
+                    v.r0 = *reinterpret_cast<const float2*>(zp); v.r1 = *reinterpret_cast<const float2*>(zp + HS);
+                    v.d = dsrc[(size_t)pl * HPS * HPS + wsy * HPS + wsx];
+                    v.cf = bn4[pl % C::CIN];
+                } else {
+                    v.r0 = v.r1 = float2{0.f, 0.f}; v.d = 0.f; v.cf = float4{0.f, 0.f, 0.f, 0.f};
+                }
+                return v;
+            },
+            [&](int e, V v) {
+                int pl, wyl, wxp, wsy, wsx;
+                const bool ok = locate(e, pl, wyl, wxp, wsy, wsx);
+                const float y0 = fmaf(v.r0.x, v.cf.x, v.cf.y), y1 = fmaf(v.r0.y, v.cf.x, v.cf.y);
+                const float y2 = fmaf(v.r1.x, v.cf.x, v.cf.y), y3 = fmaf(v.r1.y, v.cf.x, v.cf.y);
+                const float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+                const float g = (m > 0.f) ? v.cf.x * v.d : 0.f;
+                const float2 o0{(y0 == m ? g : 0.f) + fmaf(v.cf.z, v.r0.x, v.cf.w), (y1 == m ? g : 0.f) + fmaf(v.cf.z, v.r0.y, v.cf.w)};
+                const float2 o1{(y2 == m ? g : 0.f) + fmaf(v.cf.z, v.r1.x, v.cf.w), (y3 == m ? g : 0.f) + fmaf(v.cf.z, v.r1.y, v.cf.w)};
+                float* d = s_in + pl * C::PLANE + (2 * wyl) * C::WIN + 2 * wxp;
+                *reinterpret_cast<float2*>(d) = o0;
+                *reinterpret_cast<float2*>(d + C::WIN) = o1;
+                if (dzo && ok && 2 * wyl < C::HOB) {
+                    float* q = dzo + (size_t)pl * HW + (2 * wsy) * HS + 2 * wsx;
+                    *reinterpret_cast<float2*>(q) = o0;
+                    *reinterpret_cast<float2*>(q + HS) = o1;
+                }
+            });
     } else {
-        static_assert(C::SRC == SRC_NCHW || C::SRC == SRC_NCHW_PAD2 || C::G == 1, "fused conv1 variants take one patch per workgroup");
+        static_assert(C::FUSED1 && C::G == 1, "fused conv1 variants take one patch per workgroup");
         // conv1 operands and the raw rows are fetched together: one global round trip, not two
         const float* __restrict__ w1g = pick3(a.w1, tower);
         const float w1a = w1g[min(tid, kW1Floats - 1)];
@@ -300,29 +520,19 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         if constexpr (C::SRC == SRC_CONV1) {
             const float4* __restrict__ src = reinterpret_cast<const float4*>(insrc + (size_t)g0 * 1024 + band * C::HOB * 32);
             if (tid < C::XROWS * 8) reinterpret_cast<float4*>(s_x)[tid] = src[tid];
+        } else if constexpr (C::SRC == SRC_X0) {
+            load_x0_rows<C::XROWS, C::NTH>(a.x0, tower, g0, band * C::HOB, s_x, tid);
         } else {
-            // tri-planar gather, zero padded (base.py:293-306): axial [x-16+i][y-16+j][z], coronal
-            // [x-16+i][y][z-16+j], sagittal [x][y-16+i][z-16+j]
             const int cx = a.centers[(size_t)g0 * 3 + 0], cy = a.centers[(size_t)g0 * 3 + 1], cz = a.centers[(size_t)g0 * 3 + 2];
-            const float* __restrict__ vol = insrc;
-            for (int e = tid; e < C::XROWS * 32; e += C::NTH) {
-                const int i = band * C::HOB + (e >> 5), j = e & 31;
-                int vx, vy, vz;
-                if (tower == 0) { vx = cx - 16 + i; vy = cy - 16 + j; vz = cz; }
-                else if (tower == 1) { vx = cx - 16 + i; vy = cy; vz = cz - 16 + j; }
-                else { vx = cx; vy = cy - 16 + i; vz = cz - 16 + j; }
-                const bool ok = (unsigned)vx < (unsigned)a.dimx && (unsigned)vy < (unsigned)a.dimy && (unsigned)vz < (unsigned)a.dimz;
-                s_x[e] = ok ? vol[((size_t)vx * a.dimy + vy) * a.dimz + vz] : 0.f;
-            }
+            for (int e = tid; e < C::XROWS * 32; e += C::NTH)
+                s_x[e] = gather_voxel(insrc, a.dimx, a.dimy, a.dimz, tower, cx, cy, cz, band * C::HOB + (e >> 5), e & 31);
         }
         float* s_w1 = s_x + C::XS_ROWS_FLOATS + 4;
         if (tid < kW1Floats) s_w1[tid] = w1a;              // kW1Floats = 260: two loads per lane at 256 threads
         if (tid + C::NTH < kW1Floats) s_w1[tid + C::NTH] = w1b;
         __syncthreads();
         if constexpr (C::STAMP) { if (tid == 0) stp[5] = __builtin_amdgcn_s_memtime(); }
-#if !(defined(SCS_ABLATE) && SCS_ABLATE == 3)
         conv1_to_lds<C::PLANE, C::HINB, C::NW>(s_x, s_w1, s_in, wave, lane);
-#endif
     }
 
     if constexpr (C::STAMP) { if (tid == 0) stp[1] = __builtin_amdgcn_s_memtime(); }
@@ -356,9 +566,6 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             x = r - y * C::HO;
         }
         abase[j] = (g * C::CIN + kq) * C::PLANE + y * C::WIN + x;
-#if defined(SCS_ABLATE) && SCS_ABLATE == 6
-        abase[j] = (g * C::CIN + kq) * C::PLANE + lr + 16 * j;      // conflict-free A reads (wrong data): what would it buy?
-#endif
     }
 
     f32x4 acc[C::TPW][C::NT16 > 0 ? C::NT16 : 1], acc4[C::TPW][C::NT4 > 0 ? C::NT4 : 1];
@@ -396,17 +603,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 #pragma unroll
             for (int j = 0; j < C::TPW; ++j) {
                 if (C::LAST_RAGGED && j == C::TPW - 1 && !last_ok) continue;   // wave-uniform: this wave has no such tile
-#if defined(SCS_ABLATE) && SCS_ABLATE == 2
-                const float av = __builtin_bit_cast(float, abase[j] + toff);       // ablation: no activation reads
-#else
                 const float av = sa[abase[j] + toff];
-#endif
-#if defined(SCS_ABLATE) && SCS_ABLATE == 1
-#pragma unroll
-                for (int nt = 0; nt < C::NT16; ++nt) acc[j][nt][0] += av * b[nt];  // ablation: no MFMA
-#pragma unroll
-                for (int u = 0; u < C::NT4; ++u) acc4[j][u][0] += av * b4[u];
-#else
 #pragma unroll
                 for (int nt = 0; nt < C::NT16; ++nt)
                     acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[j][nt], 0, 0, 0);
@@ -415,7 +612,6 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 #pragma unroll
                 for (int u = 0; u < C::NT4; ++u)
                     acc4[j][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[j][u], 0, 0, 0);
-#endif
             }
         }
         if (c4 + 1 < C::NC4) {
@@ -482,9 +678,6 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     for (int j = 0; j < C::TPW; ++j) {
         const int t = wave + C::NW * j;
         if (t >= C::TILES) continue;
-#if defined(SCS_ABLATE) && SCS_ABLATE == 4
-        if (t >= 0) { s_o[lane] = lval[j][0]; continue; }
-#endif
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
             float val = lval[j][u];
@@ -511,14 +704,11 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     if constexpr (C::STAMP) { if (tid == 0) stp[6] = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
     if constexpr (C::STAMP) { if (tid == 0) stp[7] = __builtin_amdgcn_s_memtime(); }
-    {
+    if constexpr (C::EPI != EPI_L1) {
         float* __restrict__ outp = pick3(a.out, tower) + (size_t)g0 * C::COUT * C::OUTPIX + band * C::OUTB;
         if constexpr (C::OUT_VEC4) {
             constexpr int O4 = C::OUTB / 4, ITER = (C::G * C::COUT * O4 + C::NTH - 1) / C::NTH;
             const int total = ng * C::COUT * O4;
-#if defined(SCS_ABLATE) && SCS_ABLATE == 5
-            if (tid < 0)
-#endif
 #pragma unroll 4
             for (int it = 0; it < ITER; ++it) {
                 const int e = tid + C::NTH * it;
@@ -531,9 +721,6 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         } else {
             const int total = ng * C::COUT * C::OUTB;
             constexpr int ITER = (C::G * C::COUT * C::OUTB + C::NTH - 1) / C::NTH;
-#if defined(SCS_ABLATE) && SCS_ABLATE == 5
-            if (tid < 0)
-#endif
 #pragma unroll 2
             for (int it = 0; it < ITER; ++it) {
                 const int e = tid + C::NTH * it;
@@ -544,7 +731,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             }
         }
     }
-    if constexpr (C::EPI == EPI_RAW_STATS) {
+    if constexpr (C::EPI == EPI_RAW_STATS || C::EPI == EPI_RAW_BNB || C::EPI == EPI_RAW_BNB_POOL) {
         // rows of s_o are (patch, channel); LPR lanes share a row, then combine through the crossbar
         constexpr int ROWS = C::G * C::COUT;
         constexpr int LPR = ROWS * 16 <= C::NTH ? 16 : ROWS * 8 <= C::NTH ? 8 : ROWS * 4 <= C::NTH ? 4 : ROWS * 2 <= C::NTH ? 2 : 1;
@@ -554,18 +741,101 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 #pragma unroll
         for (int row0 = 0; row0 < ROWS; row0 += RPI) {
             const int row = row0 + tid / LPR;
+            const bool live = row < ng * C::COUT;
+            const int g = row / C::COUT, c = row - g * C::COUT;
             float sm = 0.f, sq = 0.f;
-            if (row < ng * C::COUT) {
+            if (live) {
                 const float* __restrict__ rp = s_o + row * C::OSTR;
-                for (int i = sub; i < C::OUTB; i += LPR) { const float v = rp[i]; sm += v; sq = fmaf(v, v, sq); }
+                if constexpr (C::EPI == EPI_RAW_STATS) {
+                    const float* __restrict__ pv = pick3(a.pivot, tower);
+                    const float p0 = pv ? pv[c] : 0.f;
+                    for (int i = sub; i < C::OUTB; i += LPR) { const float v = rp[i] - p0; sm += v; sq = fmaf(v, v, sq); }
+                } else {
+                    // (d beta, d gamma) partials of the block below: dy = dX through (pool and) ReLU, xhat = (z - mean) inv_std
+                    const float4 cf = reinterpret_cast<const float4*>(pick3(a.bnlow, tower))[c];     // sc, sh, mean, inv
+                    if constexpr (C::EPI == EPI_RAW_BNB) {
+                        const float* __restrict__ zp = pick3(a.zlow, tower) + ((size_t)(g0 + g) * C::COUT + c) * C::PIX + band * C::OUTB;
+                        for (int i = sub; i < C::OUTB; i += LPR) {
+                            const float z = zp[i];
+                            const float dy = fmaf(z, cf.x, cf.y) > 0.f ? rp[i] : 0.f;
+                            sm += dy; sq = fmaf(dy, (z - cf.z) * cf.w, sq);
+                        }
+                    } else {
+                        constexpr int HZ = 2 * C::HO;
+                        const float* __restrict__ zp = pick3(a.zlow, tower) + ((size_t)(g0 + g) * C::COUT + c) * HZ * HZ + (2 * band * C::HOB) * HZ;
+                        for (int i = sub; i < C::OUTB; i += LPR) {
+                            const int yy = i / C::HO, xx = i - yy * C::HO;
+                            const float* q = zp + (2 * yy) * HZ + 2 * xx;
+                            const float2 r0 = *reinterpret_cast<const float2*>(q), r1 = *reinterpret_cast<const float2*>(q + HZ);
+                            const float y0 = fmaf(r0.x, cf.x, cf.y), y1 = fmaf(r0.y, cf.x, cf.y), y2 = fmaf(r1.x, cf.x, cf.y), y3 = fmaf(r1.y, cf.x, cf.y);
+                            const float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+                            const float dv = m > 0.f ? rp[i] : 0.f;
+                            const float d0 = y0 == m ? dv : 0.f, d1 = y1 == m ? dv : 0.f, d2 = y2 == m ? dv : 0.f, d3 = y3 == m ? dv : 0.f;
+                            sm += (d0 + d1) + (d2 + d3);
+                            sq = fmaf(d0, (r0.x - cf.z) * cf.w, sq); sq = fmaf(d1, (r0.y - cf.z) * cf.w, sq);
+                            sq = fmaf(d2, (r1.x - cf.z) * cf.w, sq); sq = fmaf(d3, (r1.y - cf.z) * cf.w, sq);
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-            if (sub == 0 && row < ng * C::COUT) {
-                const int g = row / C::COUT, c = row - g * C::COUT;
+            if (sub == 0 && live) {
                 float2* dst = reinterpret_cast<float2*>(sp + (((size_t)(g0 + g) * C::NB + band) * C::COUT + c) * 2);
                 *dst = make_float2(sm, sq);
             }
+        }
+    }
+    if constexpr (C::EPI == EPI_L1) {
+        // s_o = dX1 of this band: [20][OSTR], pixel p = y * 30 + x over HOB rows.  (1) ReLU mask of the block below from the
+        // recomputed conv1 output (9 taps from the input rows, folded BN: y = sc z + sh); (2) A[c][tap] = sum_p dy[c][p] *
+        // x0[p + tap] and d beta[c] = sum_p dy[c][p] on the matrix cores (k = pixels, n = taps, tap 9 = constant one);
+        // (3) the four waves' partial sums are added in wave order and leave as [20][10] per (patch, band).
+        float* s_x0 = smem + C::OUT_FLOATS;
+        float* s_red = s_x0 + C::L1_X_FLOATS;
+        constexpr int XR = C::HOB + 2;
+        load_x0_rows<XR, C::NTH>(a.x0, tower, g0, band * C::HOB, s_x0, tid);
+        if (tid < 8) s_x0[XR * 32 + tid] = 0.f;                         // tail read by the masked last k-step of a row
+        __syncthreads();
+        const float* __restrict__ l1 = pick3(a.bnlow, tower);           // [20][12]: 9 flipped taps, sc, sh, pad
+        if (tid < C::PIXB) {
+            const int y = tid / 30, x = tid - y * 30;
+            float xv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) xv[t] = s_x0[(y + t / 3) * 32 + x + t % 3];
+#pragma unroll 4
+            for (int c = 0; c < 20; ++c) {
+                float z = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) z = fmaf(l1[c * 12 + t], xv[t], z);
+                if (!(fmaf(z, l1[c * 12 + 9], l1[c * 12 + 10]) > 0.f)) s_o[c * C::OSTR + tid] = 0.f;
+            }
+        }
+        __syncthreads();
+        const int toff = lr < 9 ? (lr / 3) * 32 + lr % 3 : 0;
+        f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+        for (int r = wave; r < C::HOB; r += C::NW) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int x = 4 * j + kq;
+                const bool ok = x < 30;
+                const float bx = ok ? (lr < 9 ? s_x0[r * 32 + x + toff] : (lr == 9 ? 1.f : 0.f)) : 0.f;
+                const float a16 = ok ? s_o[lr * C::OSTR + r * 30 + x] : 0.f;
+                const float a4 = ok ? s_o[(16 + (lane & 3)) * C::OSTR + r * 30 + x] : 0.f;
+                am = __builtin_amdgcn_mfma_f32_16x16x4f32(a16, bx, am, 0, 0, 0);       // D[c = 4 kq + i][tap = lr]
+                al = __builtin_amdgcn_mfma_f32_4x4x1f32(a4, bx, al, 0, 0, 0);          // k-subgroup partials of c = 16 + i
+            }
+        }
+        const float lv = ksub_reduce(al, kq, (lane ^ 32) << 2);                          // c = 16 + kq, tap = lr
+        float* rw = s_red + wave * 320;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[(4 * kq + i) * 16 + lr] = am[i];
+        rw[(16 + kq) * 16 + lr] = lv;
+        __syncthreads();
+        if (tid < 200) {
+            const int c = tid / 10, t = tid - c * 10;
+            const float v = (s_red[c * 16 + t] + s_red[320 + c * 16 + t]) + (s_red[640 + c * 16 + t] + s_red[960 + c * 16 + t]);
+            a.stats[(((size_t)tower * a.n + g0) * C::NB + band) * 200 + tid] = v;
         }
     }
     if constexpr (C::STAMP) { if (tid == 0) stp[4] = __builtin_amdgcn_s_memtime(); }

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, WPC) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < T::A_PER; ++i) {
             const int row = m0 + a_row + RSTEP * i, k = k0 + a_col;
-            ra[i] = (row < g.M && k < g.K4) ? P.A[(size_t)row * P.lda + k] : 0.f;
+            ra[i] = (row < g.M && k < kmax) ? P.A[(size_t)row * P.lda + k] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < T::B_PER; ++i) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
         for (int i = 0; i < T::CH; ++i) {
             const int ks = s0 + i, k = 4 * ks + kq;
             const bool on = ks < s_end;
-            av[i] = (on && row_ok) ? arow[4 * ks] : 0.f;
+            av[i] = (on && row_ok && k < kmax) ? arow[4 * ks] : 0.f;
 #pragma unroll
             for (int j = 0; j < T::NT; ++j) bv[i][j] = (on && k < kmax && col_ok[j]) ? wcol[(size_t)4 * ks * P.NS + j * 16] : 0.f;
         }
@@ -211,6 +211,91 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
             }
         }
     }
+}
+
+// Weight (and bias) gradients of the dense layers, all layers in ONE launch (blockIdx.z = problem):
+//   C[m][n] = sum_k A[k][m] * W[k][n],  k < K = batch;  row m = M (when bias_out is set) = sum_k W[k][n]
+// A = the layer's input activations, row-major [batch][features] (read "transposed": the 16 lanes of an operand group
+// load 16 consecutive floats of one batch row), W = the upstream gradient [batch][outputs].  Same latency structure as
+// gemm_splitk_kernel: the four waves split the batch, every lane loads its own operands straight from global memory, the
+// four partial accumulators are added through LDS in wave order (deterministic).
+struct WgProblem {
+    const float* A; int lda;
+    const float* W; int ldw;
+    float* C; int ldc;
+    float* bias_out;             // [N] or null
+    int M, N;
+};
+constexpr int kWgProblems = 6;
+struct WgGroupArgs { WgProblem p[kWgProblems]; int K; };
+
+template <int CH_ = 32>
+__global__ __launch_bounds__(256, 2) void dense_wgrad_kernel(WgGroupArgs g) {
+    constexpr int NT = 3, CH = CH_;
+    __shared__ f32x4 s_r[4 * NT * 64];
+    WgProblem P = g.p[0];
+#pragma unroll
+    for (int i = 1; i < kWgProblems; ++i) if ((int)blockIdx.z == i) P = g.p[i];
+    const int rows = P.M + (P.bias_out ? 1 : 0);
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 48;
+    if (m0 >= rows || n0 >= P.N) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int steps = (g.K + 3) / 4, per = (steps + 3) / 4;
+    const int s_beg = min(steps, wave * per), s_end = min(steps, s_beg + per);
+    const int m = m0 + lr;
+    const bool m_act = m < P.M, m_one = (m == P.M) && P.bias_out != nullptr;
+    const float* __restrict__ acol = P.A + (m_act ? m : 0);
+    const float* __restrict__ wcol = P.W + n0 + lr;
+    bool col_ok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) col_ok[j] = n0 + j * 16 + lr < P.N;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = s_beg; s0 < s_end; s0 += CH) {
+        float av[CH], bv[CH][NT];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int k = 4 * (s0 + i) + kq;
+            const bool on = (s0 + i) < s_end && k < g.K;
+            av[i] = on ? (m_act ? acol[(size_t)k * P.lda] : (m_one ? 1.f : 0.f)) : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[i][j] = (on && col_ok[j]) ? wcol[(size_t)k * P.ldw + j * 16] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s_r[(wave * NT + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wave < NT) {
+        const int j = wave;
+        f32x4 v = s_r[(0 * NT + j) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { const f32x4 u = s_r[(q * NT + j) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        const int col = n0 + j * 16 + lr;
+        if (col < P.N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = m0 + kq * 4 + r;
+                if (orow < P.M) P.C[(size_t)orow * P.ldc + col] = v[r];
+                else if (orow == P.M && P.bias_out) P.bias_out[col] = v[r];
+            }
+        }
+    }
+}
+
+inline void dense_wgrad_launch(const WgGroupArgs& g, int nproblems, hipStream_t st) {
+    int mr = 0, mc = 0;
+    for (int i = 0; i < nproblems; ++i) {
+        const int rows = g.p[i].M + (g.p[i].bias_out ? 1 : 0);
+        mr = rows > mr ? rows : mr; mc = g.p[i].N > mc ? g.p[i].N : mc;
+    }
+    hipLaunchKernelGGL(dense_wgrad_kernel<>, dim3((mr + 15) / 16, (mc + 47) / 48, nproblems), dim3(256), 0, st, g);
 }
 
 #ifndef SCS_GEMM_BK

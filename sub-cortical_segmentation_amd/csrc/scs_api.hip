@@ -35,6 +35,7 @@ void set_error(const char* fmt, ...) {
 // <CIN, COUT, HIN, patches per workgroup, epilogue, source, LDS plane stride, bands, workgroups per CU>
 using CfgConv12 = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_CONV1, 496, 2, 2>;    // half a patch per workgroup
 using CfgConv12V = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_VOLUME, 496, 2, 2>;
+using CfgConv12X = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_X0, 496, 2, 2>;     // patches cut from a set of volumes (sample table)
 using CfgConv3 = ConvCfg<20, 40, 14, 2, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 3>;
 using CfgConv4 = ConvCfg<40, 40, 12, 1, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 4>;
 using CfgConv5 = ConvCfg<40, 60, 5, 7, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 3>;     // 7 x 9 = 63 of 64 rows: four full tiles
@@ -96,11 +97,12 @@ __global__ void pack_dense_kernel(const float* __restrict__ W, const float* __re
 
 // ----------------------------------------------------------------------------- small kernels of the head
 // atlas -> columns 540..554 of the FC1 output rows (ConcatLayer elem_channels2, nets.py:224); column 555 = 0
-__global__ void atlas_concat_kernel(const float* __restrict__ atlas, float* __restrict__ fc1, int n) {
+__global__ void atlas_concat_kernel(const float* __restrict__ atlas, const int32_t* __restrict__ index, float* __restrict__ fc1, int n) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * 16) return;
     const int row = e >> 4, c = e & 15;
-    fc1[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? atlas[(size_t)row * 15 + c] : 0.f;
+    const int src = index ? index[row] : row;
+    fc1[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? atlas[(size_t)src * 15 + c] : 0.f;
 }
 
 // same from the 4-D prior volume at the patch centres, with the zero-row -> background rule (base.py:388-394)
@@ -259,7 +261,8 @@ int ensure_workspace(scs_ctx* h, int need) {
 // ----------------------------------------------------------------------------- one chunk of the forward
 int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
-                  int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev) {
+                  int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev, const X0Src* x0,
+                  const int32_t* atlas_index) {
     const PackedNet& pk = h->pk;
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     mark(0);
@@ -270,7 +273,10 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
         a.w[t] = pk.convw[t][1]; a.bias[t] = pk.convb[t][1]; a.out[t] = h->a_pool1[t];
         a.w1[t] = pk.conv1w[t];
     }
-    if (vol) {
+    if (x0) {
+        a.x0 = *x0;
+        conv_launch<CfgConv12X>(a, st);
+    } else if (vol) {
         a.in[0] = a.in[1] = a.in[2] = vol;
         a.centers = centers; a.dimx = dx; a.dimy = dy; a.dimz = dz;
         conv_launch<CfgConv12V>(a, st);
@@ -304,7 +310,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     if (vol && atlas4d)
         hipLaunchKernelGGL(atlas_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->a_fc1, n);
     else
-        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, h->a_fc1, n);
+        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, atlas_index, h->a_fc1, n);
     mark(6);
     // fc_2
     g.K4 = kFC1ld; g.N = kFC2;
@@ -323,6 +329,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
 static int set_kernel_attrs() {
     SCS_HIP(conv_set_attr<CfgConv12>());
     SCS_HIP(conv_set_attr<CfgConv12V>());
+    SCS_HIP(conv_set_attr<CfgConv12X>());
     SCS_HIP(conv_set_attr<CfgConv3>());
     SCS_HIP(conv_set_attr<CfgConv4>());
     SCS_HIP(conv_set_attr<CfgConv5>());
@@ -379,6 +386,7 @@ int scs_destroy(scs_handle h) {
     if (h->packed) (void)hipFree(h->packed);
     if (h->ws) (void)hipFree(h->ws);
     if (h->stage_dev) (void)hipFree(h->stage_dev);
+    if (h->last_train_event) (void)hipEventDestroy(h->last_train_event);
     if (h->host_compute) (void)hipStreamDestroy(h->host_compute);
     if (h->host_copy) (void)hipStreamDestroy(h->host_copy);
     delete h;
@@ -487,7 +495,13 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
         SCS_HIP(hipStreamCreateWithFlags(&h->host_copy, hipStreamNonBlocking));
     }
     hipStream_t sc = h->host_compute, su = h->host_copy;
-    if (h->packed_dirty) { rc = repack_inference(h, sc); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
+    if (h->packed_dirty) {
+        // the parameter arena may still be written by training work the caller enqueued on a stream of theirs
+        if (h->last_train_event) SCS_HIP(hipStreamWaitEvent(sc, h->last_train_event, 0));
+        rc = repack_inference(h, sc);
+        if (rc != SCS_OK) return rc;
+        h->packed_dirty = false;
+    }
     const size_t c = (size_t)h->ws_chunk;
     const size_t per = 3 * 1024 + 15 + 15 + 1;                  // views, atlas, probs, label
     if (!h->stage_dev || h->stage_floats < 2 * c * per) {
@@ -616,6 +630,7 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
 int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n) {
     SCS_ARG(h && dev_ptr && n, "null pointer");
     *dev_ptr = h->params; *n = SCS_N_PARAMS;
+    h->packed_dirty = true;            // the caller may write through the pointer (data-parallel parameter averaging)
     return SCS_OK;
 }
 int scs_grad_arena(scs_handle h, float** dev_ptr, size_t* n) {

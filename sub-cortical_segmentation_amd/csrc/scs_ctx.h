@@ -1,6 +1,6 @@
 // Per-instance state of libscs (opaque to callers: include/scs.h).
 #pragma once
-#include "scs_common.h"
+#include "conv_mfma.h"
 
 struct TrainWs;
 
@@ -42,6 +42,8 @@ struct scs_ctx {
 
     // training state (scs_train.hip)
     TrainWs* tws = nullptr;
+    hipEvent_t last_train_event = nullptr;   // recorded behind the last scs_train_step / scs_adam_apply work: entry points that
+                                             // repack on a stream of their own (scs_forward_host) wait for it first
 };
 
 namespace scs {
@@ -49,6 +51,7 @@ int ensure_workspace(scs_ctx* h, int need);
 int repack_inference(scs_ctx* h, hipStream_t st);
 int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
-                  int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev);
+                  int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
+                  const X0Src* x0 = nullptr, const int32_t* atlas_index = nullptr);
 void train_free(scs_ctx* h);
 }

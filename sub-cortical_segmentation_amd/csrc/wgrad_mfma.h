@@ -12,21 +12,20 @@
 #pragma once
 #include "conv_mfma.h"
 
-#ifndef SCS_WG_ABLATE
-#define SCS_WG_ABLATE 0          // tools/wgbench.hip diagnostic builds only
-#endif
-
 namespace scs {
 
-template <int CIN_, int COUT_, int HIN_, int NB_ = 1, int WPC_ = 1>
+// XSRC_: 0 = X is read from global memory ([n][CIN][HIN][HIN]); 1 = X is the conv1 block output (conv2's weight gradient),
+// recomputed per patch band from the 32x32 input rows with the batch-statistics-folded conv1 operands (conv_mfma.h:
+// conv1_to_lds) - it is never stored in the training step
+template <int CIN_, int COUT_, int HIN_, int NB_ = 1, int WPC_ = 1, int XSRC_ = 0>
 struct WgCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2;
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2, XSRC = XSRC_;
     // a workgroup owns band `b` of NB bands of output rows (HOB rows of dz, HOB + 2 rows of X) of the patches of its
     // batch slice: smaller LDS footprint -> WPC workgroups share a CU and overlap staging with the matrix phase
     static constexpr int NB = NB_, WPC = WPC_, HOB = HO / NB_, HXB = HOB + 2;
     static_assert(HO % NB_ == 0, "bands must split the output rows evenly");
     static constexpr int WOP = (HO + 3) / 4 * 4;             // padded output row
-    static constexpr int XPL = HXB * HIN_ + 8;               // X plane stride (tail absorbs the padded-column reads)
+    static constexpr int XPL = (HXB * HIN_ + 8 + 3) / 4 * 4; // X plane stride (tail absorbs the padded-column reads)
     static constexpr int ZPL = HOB * WOP;                    // dz plane stride
     static constexpr int J = CIN_ * 9;                       // (c,tap) rows
     static constexpr int MT = (J + 15) / 16;
@@ -36,13 +35,17 @@ struct WgCfg {
     // each writes its own partial (the final reduction sums slices x 4 partials)
     static constexpr bool ROWSPLIT = (MT == 1);
     static constexpr int PARTS = ROWSPLIT ? 4 : 1;
-    static constexpr int X_FLOATS = (CIN_ * XPL + 3) / 4 * 4, Z_FLOATS = COUT_ * ZPL;   // s_z 16-byte aligned
-    static constexpr size_t LDS_BYTES = (size_t)(X_FLOATS + Z_FLOATS) * 4;
+    static constexpr int X_FLOATS = (CIN_ * XPL + 3) / 4 * 4, Z_FLOATS = (COUT_ * ZPL + 3) / 4 * 4;   // 16-byte aligned pieces
+    static constexpr int X0_FLOATS = XSRC_ ? (HXB + 2) * 32 + 4 + kW1Floats : 0;        // input rows + conv1 operands
+    static constexpr size_t LDS_BYTES = (size_t)(X_FLOATS + Z_FLOATS + X0_FLOATS) * 4;
     static_assert(LDS_BYTES * WPC_ <= 160 * 1024, "LDS budget");
+    static_assert(!XSRC_ || (CIN_ == 20 && HIN_ == 30), "the recomputed X is the conv1 block output");
 };
 
 struct WgArgs {
-    const float* X[kTowers];      // [n][CIN][HIN][HIN]
+    const float* X[kTowers];      // [n][CIN][HIN][HIN] (XSRC 0)
+    const float* w1[kTowers];     // XSRC 1: conv1 operands (kW1Floats, batch statistics folded)
+    X0Src x0;                     // XSRC 1: the input patches
     const float* dZ[kTowers];     // [n][COUT][HO][HO]
     float* part;                  // [tower][slice][band][part][CIN*9][COUT]
     int n, slices;
@@ -64,6 +67,12 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
 
     // zero once: dz padding columns and the X plane tails stay zero for the whole kernel
     for (int e = tid; e < C::X_FLOATS + C::Z_FLOATS; e += 256) smem[e] = 0.f;
+    float* s_x0 = s_z + C::Z_FLOATS;
+    float* s_w1 = s_x0 + (C::HXB + 2) * 32 + 4;
+    if constexpr (C::XSRC == 1) {
+        const float* __restrict__ w1g = pick3(a.w1, tower);
+        for (int e = tid; e < kW1Floats; e += 256) s_w1[e] = w1g[e];
+    }
 
     // per-lane row bases of this wave's (c,tap) tiles; rows beyond J are clamped (computed, never stored)
     int xbase[C::MTW];
@@ -87,11 +96,14 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
 
     for (int ni = n0; ni < n1; ++ni) {
         __syncthreads();                                                   // previous patch consumed (and the zero fill)
-        if (SCS_WG_ABLATE != 2 || ni == n0) {
+        if constexpr (C::XSRC == 1) load_x0_rows<C::HXB + 2, 256>(a.x0, tower, ni, y0, s_x0, tid);
+        {
             // rows y0 .. y0+HXB of every X plane are one contiguous run of XB floats
             constexpr int HW = C::HIN * C::HIN, XB = C::HXB * C::HIN;
             const float* __restrict__ xs = X + (size_t)ni * C::CIN * HW + y0 * C::HIN;
-            if constexpr (HW % 4 == 0 && C::XPL % 4 == 0 && XB % 4 == 0 && (C::HOB * C::HIN) % 4 == 0) {
+            if constexpr (C::XSRC == 1) {
+                // s_x is filled below from the input rows
+            } else if constexpr (HW % 4 == 0 && C::XPL % 4 == 0 && XB % 4 == 0 && (C::HOB * C::HIN) % 4 == 0) {
                 staged_copy<C::CIN * XB / 4, float4>(
                     tid, [&](int e) { const int pl = e / (XB / 4), r = e - pl * (XB / 4);
                                       return reinterpret_cast<const float4*>(xs + pl * HW)[r]; },
@@ -125,6 +137,10 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
             }
         }
         __syncthreads();
+        if constexpr (C::XSRC == 1) {
+            conv1_to_lds<C::XPL, C::HXB, 4>(s_x0, s_w1, s_x, wave, lane);
+            __syncthreads();
+        }
         for (int y = C::ROWSPLIT ? wave : 0; y < C::HOB; y += C::PARTS) {
             const float* __restrict__ sxr = s_x + y * C::HIN;
             const float* __restrict__ szr = s_z + y * C::WOP;
@@ -141,13 +157,11 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
                     const float av = sxr[xbase[m] + 4 * xg];
 #pragma unroll
                     for (int nt = 0; nt < C::NT16; ++nt) {
-                        if (SCS_WG_ABLATE == 1) acc[m][nt][0] += av * b[nt];
-                        else acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[m][nt], 0, 0, 0);
                     }
 #pragma unroll
                     for (int u = 0; u < C::NT4; ++u) {
-                        if (SCS_WG_ABLATE == 1) acc4[m][u][0] += av * b4[u];
-                        else acc4[m][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[m][u], 0, 0, 0);
+                        acc4[m][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[m][u], 0, 0, 0);
                     }
                 }
             }
@@ -161,7 +175,6 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
     for (int m = 0; m < C::MTW; ++m) {
         const int t = (C::ROWSPLIT ? 0 : wave) + 4 * m;
         if (t >= C::MT) continue;
-        if (SCS_WG_ABLATE == 3 && a.n > 0) continue;
 #pragma unroll
         for (int nt = 0; nt < C::NT16; ++nt) {
             const int o = nt * 16 + lr;

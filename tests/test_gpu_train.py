@@ -256,3 +256,47 @@ def test_eval_batch_over_several_chunks(fresh):
     ls, nc = fresh.eval_batch(*d, dev(y, torch.uint8), n, stream=st)
     assert nc == want_correct
     assert abs(ls - want_loss) <= 1e-4 * abs(want_loss)
+
+
+def _random_masks(rng, n):
+    m = {'%s_l1drop' % t: (rng.rand(n, 60, 3, 3) < 0.5).astype(np.uint8) for t in P.TOWERS}
+    m['f1_drop'] = (rng.rand(n, 540) < 0.5).astype(np.uint8)
+    m['f2_drop'] = (rng.rand(n, 540) < 0.5).astype(np.uint8)
+    return m
+
+
+@pytest.mark.parametrize('n', [1, 5, 37, 255, 256, 257])
+def test_training_step_at_ragged_batch_sizes(fresh, weights, n):
+    """scs_train_step against the oracle at batch sizes that are not multiples of anything the kernels tile by (n = 256 is
+    BASELINE configs[2]): slice partition of the weight-gradient kernels, patch groups of the moment / data-gradient
+    kernels, K padding of the dense weight gradients."""
+    from cnn_cort import synth
+    ax, co, sa, at = synth.patch_batch(n, seed=100 + n)
+    rng = np.random.RandomState(n)
+    y = rng.randint(0, 15, n).astype(np.uint8)
+    masks = _random_masks(rng, n)
+    loss_ref, grads_ref, bn_ref, _ = O.train_forward_backward(weights, ax, co, sa, at, y, masks)
+    st = torch.cuda.current_stream().cuda_stream
+    # a larger batch first, so that the workspace holds stale values beyond row n
+    big = synth.patch_batch(300, seed=3)
+    fresh.train_step(*[dev(a) for a in big], dev(rng.randint(0, 15, 300).astype(np.uint8), torch.uint8), 300, seed=1, stream=st)
+    fresh.set_params(P.params_to_flat(weights))
+    loss = fresh.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, masks=dev(pack_masks(masks), torch.uint8), stream=st)
+    assert abs(loss - loss_ref) <= 2e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    got = P.flat_to_params(arena(fresh, 'grad'))
+    worst = 0.0
+    for name, shapes in P.LAYER_SPEC:
+        for i, _ in enumerate(shapes):
+            ref = np.asarray(grads_ref[name][i])
+            scale = max(np.abs(ref).max(), 1e-6)
+            err = np.abs(got[name][i] - ref).max() / scale
+            worst = max(worst, err)
+            assert np.isfinite(got[name][i]).all(), name
+            # n = 1: the 3x3 planes of conv5 give BN nine values per channel - inv_std up to 100 amplifies float32 rounding
+            assert err <= (GRAD_RTOL if n > 1 else 2e-2), '%s[%d]: rel err %g (scale %g)' % (name, i, err, scale)
+    newp = P.flat_to_params(arena(fresh, 'param'))
+    run = O.bn_running_update(weights, bn_ref)
+    for name in bn_ref:
+        assert np.abs(newp[name][2] - run[name][2]).max() <= 1e-4 * max(1.0, np.abs(run[name][2]).max()), name
+        assert np.abs(newp[name][3] - run[name][3]).max() <= 2e-4 * max(1.0, np.abs(run[name][3]).max()), name
+    print('n = %d: worst relative gradient error %.3g' % (n, worst))

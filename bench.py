@@ -16,8 +16,9 @@ Ranks process independent batches (weak scaling), the forward
 path has no collective, the training path exactly one (the gradient arena).  Timing = K steps between
 barrier + synchronize brackets, max over ranks; rank 0 prints ONE JSON line.
 
-roofline: the dominant kernel (fused conv1+conv2+pool1, 50.6 % of the net's MACs) is timed live with HIP events
-on the launch stream (scs_forward_profiled); achieved = algorithmic FLOP per launch / mean launch duration against
+roofline: the dominant kernel (forward: fused conv1+conv2+pool1, 50.6 % of the net's MACs; train: the longest of the
+conv forward / data-gradient / weight-gradient kernels) is timed live with HIP events on the stream it is launched on
+(scs_forward_profiled / scs_train_step_profiled); achieved = algorithmic FLOP per launch / mean launch duration against
 the 157.3 TFLOP/s fp32 matrix/vector peak of gfx950.  cpu_baseline: the float32 torch-CPU port of the same net
 (oracle/torch_ref.py, all host threads) on a bounded sample - a reported baseline, not the target.
 """
@@ -315,6 +316,34 @@ def main():
                                           'tflops': float(2.0 * STAGE_MACS[i] * B / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else None}
                          for i in range(8)}
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
+    if rank == 0 and args.mode == 'train':
+        # dominant training kernel: every launch of one step timed with HIP events on the stream it is issued on
+        # (scs_train_step_profiled; the weight-gradient kernels run on the library's side stream), averaged over a few steps
+        reps = 5
+        acc = {}
+        for r in range(reps):
+            for k, v in h.train_step_profiled(ax, co, sa, at, y, B, seed=1000 + r, stream=st).items():
+                acc[k] = acc.get(k, 0.0) + v / reps
+        conv_macs = {'conv1+conv2 fwd': 3 * (162000 + 2822400), 'conv3 fwd': 3 * 1036800, 'conv4 fwd': 3 * 1440000, 'conv5 fwd': 3 * 194400,
+                     'conv5 dgrad': 3 * 194400, 'conv4 dgrad': 3 * 1440000, 'conv3 dgrad': 3 * 1036800,
+                     'conv2 dgrad + layer-1 sums': 3 * (2822400 + 162000), 'conv5 wgrad': 3 * 194400, 'conv4 wgrad': 3 * 1440000,
+                     'conv3 wgrad': 3 * 1036800, 'conv2 wgrad': 3 * 2822400}
+        dom = max(conv_macs, key=lambda k: acc.get(k, 0.0))
+        dur = acc[dom] * 1e-3
+        achieved = 2.0 * conv_macs[dom] * B / dur / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get('train: ' + dom)
+            except Exception:
+                traffic = None
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'launch_ms': acc[dom], 'patches_per_launch': B}
+        out['stages'] = {k: {'ms': v, 'tflops': (2.0 * conv_macs[k] * B / (v * 1e-3) / 1e12) if k in conv_macs and v > 0 else None}
+                         for k, v in acc.items()}
+        out['launches_per_step'] = len([k for k, v in acc.items() if v > 0])
+        out['sum_of_launch_ms'] = float(sum(acc.values()))
     if rank == 0 and world == 1 and not args.no_cpu:
         out['cpu_baseline'] = {'train': cpu_baseline_train, 'volume': cpu_baseline_volume, 'forward': cpu_baseline}[args.mode](weights)
     if rank == 0:

@@ -163,6 +163,11 @@ int scs_train_step_profiled(scs_handle h, const float* ax_dev, const float* co_d
                             const float* atlas_dev, const uint8_t* y_dev, int64_t n, uint64_t dropout_seed,
                             float* stage_ms, void* stream);
 
+/* Test hook: copy an intermediate of the LAST training step to the host.  which: 0 d(fc_2 pre-activation) [n][272],
+ * 1 d(FC1 pre-activation) [n][540], 2 d(d1 pre-activations) [n][540], 3 f1_drop(feat) [n][540], 4 relu(FC1) [n][540],
+ * 5 fc_2 input [n][556], 6 d logits [n][16].  count = floats to copy. */
+int scs_get_train_buffer(scs_handle h, int which, float* host_out, size_t count);
+
 /* Device pointers to the parameter and gradient arenas (SCS_N_PARAMS floats each) - the gradient arena is
  * what a data-parallel caller all-reduces (RCCL) between scs_train_step and scs_adam_apply. */
 int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n);   /* marks the inference operands stale: the caller may write */

@@ -182,7 +182,7 @@ def _pool_bwd(x, y, g):
     return (x == up(y)) * up(g)
 
 
-def train_forward_backward(params, ax, co, sa, atlas, y, masks):
+def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None):
     """One training forward/backward in float64 (deterministic=False semantics).
 
     masks: dict with 0/1 arrays 'axial_l1drop','coronal_l1drop','saggital_l1drop' [N,60,3,3],
@@ -254,12 +254,18 @@ def train_forward_backward(params, ax, co, sa, atlas, y, masks):
     grads['prelu_f2'] = [da]
     g = _relu_bwd(pre2, g)
     grads['fc_2'] = [cat2.T @ g, g.sum(0)]
+    if debug is not None:
+        debug.update(dpre2=g.copy(), cat2=cat2, r1=r1, cat_d=cat_d,
+                     relu_margin=min(float(np.abs(pre1).min()), float(np.abs(pre2).min()),
+                                     min(float(np.abs(cache[t]['pre']).min()) for t in TOWERS)))
     g = (g @ W2.T)[:, :540]                                  # the atlas input takes no gradient
     g = g / 0.5 * m2
     g, da = _prelu_bwd(r1, P['prelu_f1'][0], g)
     grads['prelu_f1'] = [da]
     g = _relu_bwd(pre1, g)
     grads['FC1'] = [cat_d.T @ g, g.sum(0)]
+    if debug is not None:
+        debug.update(dpre1=g.copy())
     g = (g @ W1.T) / 0.5 * m1
     for ti, t in enumerate(TOWERS):
         ch = cache[t]

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libscs.so')
+LIB_PATH = os.environ.get('SCS_LIB_PATH') or os.path.join(os.path.dirname(_HERE), 'lib', 'libscs.so')   # override: A/B runs of two builds
 N_PARAMS = 883455
 
 _lib = None
@@ -43,6 +43,7 @@ SIGNATURES = {
     'scs_train_stage_count': (_c.c_int, []),
     'scs_train_stage_name': (_c.c_char_p, [_c.c_int]),
     'scs_train_step_profiled': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp]),
+    'scs_get_train_buffer': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
     'scs_param_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
     'scs_train_loss': (_c.c_int, [_vp, _c.POINTER(_c.c_void_p)]),
     'scs_grad_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
@@ -66,6 +67,8 @@ def load_library():
                        '`make -C sub-cortical_segmentation_amd/csrc`)' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get('SCS_LIB_PATH') and not hasattr(lib, name):
+            continue                      # an older build under test
         fn = getattr(lib, name)           # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
@@ -194,6 +197,11 @@ class Handle:
                                                 ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ms.ctypes.data, stream or None),
                'scs_train_step_profiled')
         return {self.lib.scs_train_stage_name(i).decode(): float(ms[i]) for i in range(k)}
+
+    def get_train_buffer(self, which, count):
+        out = np.empty(count, np.float32)
+        _check(self.lib.scs_get_train_buffer(self.h, int(which), out.ctypes.data, out.size), 'scs_get_train_buffer')
+        return out
 
     def train_loss_ptr(self):
         """Device address of the last train step's mean loss (float32)."""

@@ -1015,6 +1015,27 @@ int scs_gather_labels(scs_handle h, const uint8_t* label_vols, const scs_volume*
     return SCS_OK;
 }
 
+int scs_get_train_buffer(scs_handle h, int which, float* host_out, size_t count) {
+    SCS_ARG(h && host_out, "null pointer");
+    if (!h->tws || !h->tws->base) { set_error("no training step has run"); return SCS_ERR_STATE; }
+    TrainWs* w = h->tws;
+    const float* src = nullptr;
+    switch (which) {
+        case 0: src = w->dR2; break;     // [n][272]
+        case 1: src = w->dcat; break;    // [n][540]
+        case 2: src = w->dfeat; break;   // [n][540]
+        case 3: src = w->featd; break;   // [n][540]
+        case 4: src = w->R1; break;      // [n][540]
+        case 5: src = w->cat2; break;    // [n][556]
+        case 6: src = w->dlog; break;    // [n][16]
+        default: SCS_ARG(false, "unknown buffer id");
+    }
+    SCS_HIP(hipSetDevice(h->device));
+    SCS_HIP(hipDeviceSynchronize());
+    SCS_HIP(hipMemcpy(host_out, src, count * sizeof(float), hipMemcpyDeviceToHost));
+    return SCS_OK;
+}
+
 int scs_train_loss(scs_handle h, float** dev_ptr) {
     SCS_ARG(h && dev_ptr, "null pointer");
     if (!h->tws || !h->tws->loss_dev) { set_error("scs_train_loss before scs_train_step"); return SCS_ERR_STATE; }

@@ -91,11 +91,14 @@ struct ConvCfg {
     static constexpr bool OUT_VEC4 = (OUTB % 4 == 0) && (OUTPIX % 4 == 0);
     static constexpr int OSTR = OUT_VEC4 ? OUTB + 4 : (OUTB | 1);
     static constexpr int OUT_FLOATS = G_ * COUT_ * OSTR;
-    // EPI_L1 scratch behind the restaged outputs: the input rows of the band ((HOB + 2) x 32) and the waves' partial A
-    static constexpr int L1_X_FLOATS = (HOB + 2) * 32 + 8, L1_RED_FLOATS = NW_ * 20 * 16;
-    static constexpr int EPI_FLOATS = OUT_FLOATS + (EPI_ == EPI_L1 ? L1_X_FLOATS + L1_RED_FLOATS : 0);
+    // EPI_L1: the input rows of the band ((HOB + 2) x 32) and the conv1 tap table sit behind the main buffers (they are
+    // fetched at kernel start); the waves' partial sums reuse the space behind the restaged outputs
+    static constexpr int L1_X_FLOATS = (HOB + 2) * 32 + 8, L1_TAB_FLOATS = 240, L1_RED_FLOATS = NW_ * 20 * 16;
+    static constexpr int L1_PRE_FLOATS = EPI_ == EPI_L1 ? L1_X_FLOATS + L1_TAB_FLOATS : 0;
+    static constexpr int EPI_FLOATS = OUT_FLOATS + (EPI_ == EPI_L1 ? L1_RED_FLOATS : 0);
     static constexpr int MAIN_FLOATS = IN_FLOATS_AL + 2 * WCHUNK + XS_FLOATS;
-    static constexpr size_t LDS_BYTES = (size_t)(MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS) * 4;
+    static_assert(EPI_ != EPI_L1 || EPI_FLOATS <= MAIN_FLOATS, "EPI_L1 scratch must not reach the prefetched input rows");
+    static constexpr size_t LDS_BYTES = (size_t)((MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS) + L1_PRE_FLOATS) * 4;
     static_assert(CIN_ % 4 == 0, "k-steps are groups of 4 input channels");
     static_assert(COUT_ % 4 == 0, "output channels are covered by 16-wide and 4-wide MFMA blocks");
     static_assert(HO % NB_ == 0 && (!POOL || (HOB % 2 == 0)), "bands must split the output rows (evenly for pooling)");
@@ -142,6 +145,7 @@ struct ConvArgs {
     const float* bnlow[kTowers];  // EPI_RAW_BNB*: float4 [COUT] (sc, sh, mean, inv_std) of the layer below; EPI_L1: [20][12] flipped
                                   // conv1 filters (9), sc, sh, pad
     X0Src x0;                     // SRC_X0 / EPI_L1: the input patches
+    int tower0;                   // first tower of this launch (grid.y towers from here; per-tower streams launch one each)
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -236,9 +240,12 @@ __device__ __forceinline__ void conv1_to_lds(const float* __restrict__ s_x, cons
 
 // batched copy helper: K independent loads in flight per thread before the LDS writes (a plain strided loop
 // serialises one global-load latency per iteration)
-template <int TOTAL, class V, int NTH = 256, int K = 8, class SrcF, class DstF>
+// K_ = 0: as few round trips as possible with at most 12 loads in flight per thread (equal batches)
+template <int TOTAL, class V, int NTH = 256, int K_ = 8, class SrcF, class DstF>
 __device__ __forceinline__ void staged_copy(int tid, SrcF&& src_of, DstF&& dst_of) {
     constexpr int ITER = (TOTAL + NTH - 1) / NTH;
+    constexpr int TRIPS = (ITER + 11) / 12;
+    constexpr int K = K_ > 0 ? K_ : (ITER + TRIPS - 1) / TRIPS;
 #pragma unroll
     for (int i0 = 0; i0 < ITER; i0 += K) {
         V v[K];
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
-    const int tower = blockIdx.y;
+    const int tower = blockIdx.y + a.tower0;
     const int band = (C::NB > 1) ? (int)(blockIdx.x % C::NB) : 0;
     const int g0 = (int)(blockIdx.x / C::NB) * C::G;
     const int ng = min(C::G, a.n - g0);
@@ -333,6 +340,25 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     for (int u = 0; u < C::NT4; ++u) {
         bv4[u] = 0.f;
         if constexpr (!C::RAW) bv4[u] = pick3(a.bias, tower)[C::NT16 * 16 + u * 4 + kq];
+    }
+
+    // EPI_L1: the band's input rows and the conv1 tap table, fetched now, parked in LDS behind the main buffers after the
+    // staging (the main loop's barriers publish them long before the epilogue reads them)
+    float4 l1x4 = {0.f, 0.f, 0.f, 0.f};
+    float l1xs = 0.f, l1tab = 0.f;
+    if constexpr (C::EPI == EPI_L1) {
+        constexpr int XR = C::HOB + 2;
+        static_assert(XR * 32 <= C::NTH && 240 <= C::NTH, "one element per thread");
+        const float* __restrict__ v = pick3(a.x0.views, tower);
+        if (v) {
+            if (tid < XR * 8) l1x4 = reinterpret_cast<const float4*>(v + (size_t)g0 * 1024 + band * C::HOB * 32)[tid];
+        } else if (tid < XR * 32) {
+            const int r = a.x0.index ? a.x0.index[g0] : g0;
+            const int4 smp = reinterpret_cast<const int4*>(a.x0.samples)[r];
+            const scs_volume d = a.x0.descs[smp.x];
+            l1xs = gather_voxel(a.x0.vols + d.offset, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, band * C::HOB + (tid >> 5), tid & 31);
+        }
+        if (tid < 240) l1tab = pick3(a.bnlow, tower)[tid];
     }
 
     // ---- stage the input planes of this workgroup's patches
@@ -388,7 +414,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         float4* dst4 = reinterpret_cast<float4*>(s_in);
         const int planes = ng * C::CIN;
         struct V { float4 v; float2 ss; };
-        staged_copy<C::G * C::CIN * HW4, V, C::NTH, 6>(
+        staged_copy<C::G * C::CIN * HW4, V, C::NTH, 0>(
             tid,
             [&](int e) { const int pl = e / HW4; V r; r.ss = bn2[pl % C::CIN];
                          r.v = (pl < planes) ? src4[e] : float4{0.f, 0.f, 0.f, 0.f}; return r; },
@@ -408,7 +434,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         if (xo) xo += (size_t)g0 * C::CIN * W;
         const int planes = ng * C::CIN;
         struct V { float2 r0, r1, ss; };
-        staged_copy<C::G * C::CIN * W, V, C::NTH, 6>(
+        staged_copy<C::G * C::CIN * W, V, C::NTH, 0>(
             tid,
             [&](int e) {
                 const int pl = e / W, wdx = e - pl * W, wy = wdx / C::HIN, wx = wdx - wy * C::HIN;
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             own = yl < C::HOB;
             return pl < planes && (unsigned)ys < (unsigned)HS && (unsigned)xs < (unsigned)HS;
         };
-        staged_copy<C::G * C::CIN * BW, V, C::NTH, 6>(
+        staged_copy<C::G * C::CIN * BW, V, C::NTH, 0>(
             tid,
             [&](int e) {
                 int pl, r, idx; bool own;
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             wsy = (band * C::HOB) / 2 + wyl - 1; wsx = wxp - 1;
             return pl < planes && (unsigned)wsy < (unsigned)HPS && (unsigned)wsx < (unsigned)HPS;
         };
-        staged_copy<C::G * C::CIN * WP, V, C::NTH, 4>(
+        staged_copy<C::G * C::CIN * WP, V, C::NTH, 0>(
             tid,
             [&](int e) {
                 int pl, wyl, wxp, wsy, wsx;
@@ -536,6 +562,14 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     }
 
     if constexpr (C::STAMP) { if (tid == 0) stp[1] = __builtin_amdgcn_s_memtime(); }
+    if constexpr (C::EPI == EPI_L1) {
+        constexpr int XR = C::HOB + 2;
+        float* s_x0 = smem + (C::MAIN_FLOATS > C::EPI_FLOATS ? C::MAIN_FLOATS : C::EPI_FLOATS);
+        if (pick3(a.x0.views, tower)) { if (tid < XR * 8) reinterpret_cast<float4*>(s_x0)[tid] = l1x4; }
+        else if (tid < XR * 32) s_x0[tid] = l1xs;
+        if (tid < 8) s_x0[XR * 32 + tid] = 0.f;
+        if (tid < 240) s_x0[C::L1_X_FLOATS + tid] = l1tab;
+    }
     // ---- weight chunk 0 -> LDS
     {
         float4* dst = reinterpret_cast<float4*>(s_w);
@@ -755,25 +789,48 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                     const float4 cf = reinterpret_cast<const float4*>(pick3(a.bnlow, tower))[c];     // sc, sh, mean, inv
                     if constexpr (C::EPI == EPI_RAW_BNB) {
                         const float* __restrict__ zp = pick3(a.zlow, tower) + ((size_t)(g0 + g) * C::COUT + c) * C::PIX + band * C::OUTB;
-                        for (int i = sub; i < C::OUTB; i += LPR) {
-                            const float z = zp[i];
-                            const float dy = fmaf(z, cf.x, cf.y) > 0.f ? rp[i] : 0.f;
-                            sm += dy; sq = fmaf(dy, (z - cf.z) * cf.w, sq);
+                        constexpr int IT = (C::OUTB + LPR - 1) / LPR, KB = IT <= 12 ? IT : (IT + (IT + 11) / 12 - 1) / ((IT + 11) / 12);
+#pragma unroll
+                        for (int i0 = 0; i0 < IT; i0 += KB) {
+                            float zv[KB];
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) zv[k] = zp[min(sub + LPR * (i0 + k), C::OUTB - 1)];
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) {
+                                const int i = sub + LPR * (i0 + k);
+                                if (i0 + k < IT && i < C::OUTB) {
+                                    const float dy = fmaf(zv[k], cf.x, cf.y) > 0.f ? rp[i] : 0.f;
+                                    sm += dy; sq = fmaf(dy, (zv[k] - cf.z) * cf.w, sq);
+                                }
+                            }
                         }
                     } else {
                         constexpr int HZ = 2 * C::HO;
                         const float* __restrict__ zp = pick3(a.zlow, tower) + ((size_t)(g0 + g) * C::COUT + c) * HZ * HZ + (2 * band * C::HOB) * HZ;
-                        for (int i = sub; i < C::OUTB; i += LPR) {
-                            const int yy = i / C::HO, xx = i - yy * C::HO;
-                            const float* q = zp + (2 * yy) * HZ + 2 * xx;
-                            const float2 r0 = *reinterpret_cast<const float2*>(q), r1 = *reinterpret_cast<const float2*>(q + HZ);
-                            const float y0 = fmaf(r0.x, cf.x, cf.y), y1 = fmaf(r0.y, cf.x, cf.y), y2 = fmaf(r1.x, cf.x, cf.y), y3 = fmaf(r1.y, cf.x, cf.y);
-                            const float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
-                            const float dv = m > 0.f ? rp[i] : 0.f;
-                            const float d0 = y0 == m ? dv : 0.f, d1 = y1 == m ? dv : 0.f, d2 = y2 == m ? dv : 0.f, d3 = y3 == m ? dv : 0.f;
-                            sm += (d0 + d1) + (d2 + d3);
-                            sq = fmaf(d0, (r0.x - cf.z) * cf.w, sq); sq = fmaf(d1, (r0.y - cf.z) * cf.w, sq);
-                            sq = fmaf(d2, (r1.x - cf.z) * cf.w, sq); sq = fmaf(d3, (r1.y - cf.z) * cf.w, sq);
+                        constexpr int IT = (C::OUTB + LPR - 1) / LPR, KB = IT <= 8 ? IT : (IT + (IT + 7) / 8 - 1) / ((IT + 7) / 8);
+#pragma unroll
+                        for (int i0 = 0; i0 < IT; i0 += KB) {
+                            float2 r0[KB], r1[KB];
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) {
+                                const int i = min(sub + LPR * (i0 + k), C::OUTB - 1), yy = i / C::HO, xx = i - yy * C::HO;
+                                const float* q = zp + (2 * yy) * HZ + 2 * xx;
+                                r0[k] = *reinterpret_cast<const float2*>(q); r1[k] = *reinterpret_cast<const float2*>(q + HZ);
+                            }
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) {
+                                const int i = sub + LPR * (i0 + k);
+                                if (i0 + k < IT && i < C::OUTB) {
+                                    const float y0 = fmaf(r0[k].x, cf.x, cf.y), y1 = fmaf(r0[k].y, cf.x, cf.y);
+                                    const float y2 = fmaf(r1[k].x, cf.x, cf.y), y3 = fmaf(r1[k].y, cf.x, cf.y);
+                                    const float m = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+                                    const float dv = m > 0.f ? rp[i] : 0.f;
+                                    const float d0 = y0 == m ? dv : 0.f, d1 = y1 == m ? dv : 0.f, d2 = y2 == m ? dv : 0.f, d3 = y3 == m ? dv : 0.f;
+                                    sm += (d0 + d1) + (d2 + d3);
+                                    sq = fmaf(d0, (r0[k].x - cf.z) * cf.w, sq); sq = fmaf(d1, (r0[k].y - cf.z) * cf.w, sq);
+                                    sq = fmaf(d2, (r1[k].x - cf.z) * cf.w, sq); sq = fmaf(d3, (r1[k].y - cf.z) * cf.w, sq);
+                                }
+                            }
                         }
                     }
                 }
@@ -788,32 +845,57 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     }
     if constexpr (C::EPI == EPI_L1) {
         // s_o = dX1 of this band: [20][OSTR], pixel p = y * 30 + x over HOB rows.  (1) ReLU mask of the block below from the
-        // recomputed conv1 output (9 taps from the input rows, folded BN: y = sc z + sh); (2) A[c][tap] = sum_p dy[c][p] *
-        // x0[p + tap] and d beta[c] = sum_p dy[c][p] on the matrix cores (k = pixels, n = taps, tap 9 = constant one);
-        // (3) the four waves' partial sums are added in wave order and leave as [20][10] per (patch, band).
-        float* s_x0 = smem + C::OUT_FLOATS;
-        float* s_red = s_x0 + C::L1_X_FLOATS;
-        constexpr int XR = C::HOB + 2;
-        load_x0_rows<XR, C::NTH>(a.x0, tower, g0, band * C::HOB, s_x0, tid);
-        if (tid < 8) s_x0[XR * 32 + tid] = 0.f;                         // tail read by the masked last k-step of a row
-        __syncthreads();
-        const float* __restrict__ l1 = pick3(a.bnlow, tower);           // [20][12]: 9 flipped taps, sc, sh, pad
-        if (tid < C::PIXB) {
-            const int y = tid / 30, x = tid - y * 30;
-            float xv[9];
+        // recomputed conv1 output (folded BN: y = sc z + sh); (2) A[c][tap] = sum_p dy[c][p] * x0[p + tap] and d beta[c] =
+        // sum_p dy[c][p] on the matrix cores (k = pixels, n = taps, tap 9 = constant one); (3) the four waves' partial sums
+        // are added in wave order and leave as [20][10] per (patch, band).
+        const float* s_x0 = smem + (C::MAIN_FLOATS > C::EPI_FLOATS ? C::MAIN_FLOATS : C::EPI_FLOATS);
+        const float* s_l1 = s_x0 + C::L1_X_FLOATS;                      // [20][12]: 9 flipped taps, sc, sh, pad
+        float* s_red = smem + C::OUT_FLOATS;
+        {
+            // (1) conv1 on the matrix cores once more (K = 9 taps padded to 12, N = 20 = 16 + 4, M = the band's 180 pixels)
+            // and zero dX1 wherever sc z + sh <= 0
+            constexpr int NPIX = C::PIXB, T1 = (NPIX + 15) / 16, TW = (T1 + C::NW - 1) / C::NW;
+            int koff[3];
+            float bm[3], bl[3];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) xv[t] = s_x0[(y + t / 3) * 32 + x + t % 3];
-#pragma unroll 4
-            for (int c = 0; c < 20; ++c) {
-                float z = 0.f;
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int k = 4 * s3 + kq, tk = k < 9 ? k : 8;
+                koff[s3] = (tk / 3) * 32 + tk % 3;
+                bm[s3] = k < 9 ? s_l1[lr * 12 + k] : 0.f;
+                bl[s3] = k < 9 ? s_l1[(16 + (lane & 3)) * 12 + k] : 0.f;
+            }
+            const float sc_m = s_l1[lr * 12 + 9], sh_m = s_l1[lr * 12 + 10];
+            const float sc_l = s_l1[(16 + kq) * 12 + 9], sh_l = s_l1[(16 + kq) * 12 + 10];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) z = fmaf(l1[c * 12 + t], xv[t], z);
-                if (!(fmaf(z, l1[c * 12 + 9], l1[c * 12 + 10]) > 0.f)) s_o[c * C::OSTR + tid] = 0.f;
+            for (int jj = 0; jj < TW; ++jj) {
+                const int t = wave + C::NW * jj, tc = min(t, T1 - 1);
+                const int p = min(tc * 16 + lr, NPIX - 1), y = p / 30, x = p - y * 30;
+                f32x4 zm = {0.f, 0.f, 0.f, 0.f}, zl = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const float av = s_x0[y * 32 + x + koff[s3]];
+                    zm = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bm[s3], zm, 0, 0, 0);      // D[pixel 4 kq + i][c = lr]
+                    zl = __builtin_amdgcn_mfma_f32_4x4x1f32(bl[s3], av, zl, 0, 0, 0);
+                }
+                const float zv = ksub_reduce(zl, kq, (lane ^ 32) << 2);                       // c = 16 + kq, pixel lr of the tile
+                if (t < T1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int pp = tc * 16 + kq * 4 + i;
+                        if (pp < NPIX && !(fmaf(zm[i], sc_m, sh_m) > 0.f)) s_o[lr * C::OSTR + pp] = 0.f;
+                    }
+                    const int pl = tc * 16 + lr;
+                    if (pl < NPIX && !(fmaf(zv, sc_l, sh_l) > 0.f)) s_o[(16 + kq) * C::OSTR + pl] = 0.f;
+                }
             }
         }
         __syncthreads();
         const int toff = lr < 9 ? (lr / 3) * 32 + lr % 3 : 0;
-        f32x4 am = {0.f, 0.f, 0.f, 0.f}, al = {0.f, 0.f, 0.f, 0.f};
+        // four independent accumulator sets: under the other workgroups' matrix phases a dependent MFMA chain advances one
+        // link per pipe round trip, so a 16-deep chain costs four times a 4-deep one
+        f32x4 am4[4], al4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { am4[q] = f32x4{0.f, 0.f, 0.f, 0.f}; al4[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         for (int r = wave; r < C::HOB; r += C::NW) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -822,10 +904,13 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                 const float bx = ok ? (lr < 9 ? s_x0[r * 32 + x + toff] : (lr == 9 ? 1.f : 0.f)) : 0.f;
                 const float a16 = ok ? s_o[lr * C::OSTR + r * 30 + x] : 0.f;
                 const float a4 = ok ? s_o[(16 + (lane & 3)) * C::OSTR + r * 30 + x] : 0.f;
-                am = __builtin_amdgcn_mfma_f32_16x16x4f32(a16, bx, am, 0, 0, 0);       // D[c = 4 kq + i][tap = lr]
-                al = __builtin_amdgcn_mfma_f32_4x4x1f32(a4, bx, al, 0, 0, 0);          // k-subgroup partials of c = 16 + i
+                am4[j & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a16, bx, am4[j & 3], 0, 0, 0);       // D[c = 4 kq + i][tap = lr]
+                al4[j & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4, bx, al4[j & 3], 0, 0, 0);          // k-subgroup partials of c = 16 + i
             }
         }
+        f32x4 am, al;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { am[i] = (am4[0][i] + am4[1][i]) + (am4[2][i] + am4[3][i]); al[i] = (al4[0][i] + al4[1][i]) + (al4[2][i] + al4[3][i]); }
         const float lv = ksub_reduce(al, kq, (lane ^ 32) << 2);                          // c = 16 + kq, tap = lr
         float* rw = s_red + wave * 320;
 #pragma unroll
@@ -848,9 +933,9 @@ inline hipError_t conv_set_attr() {
 }
 
 template <class C>
-inline void conv_launch(const ConvArgs& a, hipStream_t st) {
+inline void conv_launch(const ConvArgs& a, hipStream_t st, int ntowers = kTowers) {
     if (a.n <= 0) return;
-    dim3 grid(((a.n + C::G - 1) / C::G) * C::NB, kTowers);
+    dim3 grid(((a.n + C::G - 1) / C::G) * C::NB, ntowers);
     hipLaunchKernelGGL(conv3x3_mfma_kernel<C>, grid, dim3(C::NTH), C::LDS_BYTES, st, a);
 }
 

@@ -25,35 +25,15 @@
 #include <new>
 #include <type_traits>
 #include <vector>
+#include <algorithm>
 
 #include "conv_mfma.h"
 #include "gemm_mfma.h"
 #include "scs_ctx.h"
 #include "wgrad_mfma.h"
+#include "train_cfg.h"
 
 namespace scs {
-
-// ------------------------------------------------------------------------------------------- configurations
-// <CIN, COUT, HIN, patches per workgroup, epilogue, source, LDS plane stride, bands, workgroups per CU>
-using TF12 = ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 4>;          // conv1 (recomputed) + conv2
-using TF3 = ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 208, 1, 4>;      // BN2 + ReLU + pool1 while staging
-using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4>;           // BN3 + ReLU while staging
-using TF5 = ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4>;        // BN4 + ReLU + pool2 while staging
-// data gradients: input = dZ_i (computed while staging) zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i; the epilogue
-// leaves the BN-backward partial sums of the block below
-using DG5 = ConvCfg<60, 40, 7, 2, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 3>;     // below: conv4 block (pooled)
-using DG4 = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3>;   // below: conv3 block
-using DG3 = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 144, 2, 4>;   // below: conv2 block (pooled)
-using DG2 = ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 256, 5, 4>;        // below: conv1 block (recomputed)
-
-constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
-// <CIN, COUT, HIN, row bands, workgroups per CU, X source>
-using WG2 = WgCfg<20, 20, 30, 4, 3, 1>;
-using WG3 = WgCfg<20, 40, 14, 2, 3>;
-using WG4 = WgCfg<40, 40, 12, 1, 3>;
-using WG5 = WgCfg<40, 60, 5, 1, 2>;
-constexpr size_t kWgPartFloats = (size_t)256 * 60 * 40 * 9;   // per tower and layer: room for 256 partials of the largest layer
-constexpr int kL1Bands = DG2::NB;
 
 // profiling stages of scs_train_step_profiled (one per launch)
 enum Stage { ST_PREP, ST_MOMENTS, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
@@ -455,11 +435,17 @@ __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const float* __restri
         const float sc = s_ss[0], sh = s_ss[1];
         const float* __restrict__ z = sel3(Z.p, t);
         float* __restrict__ o = sel3(H5.p, t);
-        for (int idx = threadIdx.x; idx < n * 9; idx += 256) {
-            const int ni = idx / 9, e = idx - ni * 9;
-            const size_t at = ((size_t)ni * C + c) * 9 + e;
-            const float v = fmaxf(fmaf(z[at], sc, sh), 0.f);
-            o[at] = mask[(size_t)t * n * kFlat + at] ? v * 2.f : 0.f;      // dropout 0.5 in front of d1 (nets.py:178)
+        for (int ni = threadIdx.x; ni < n; ni += 256) {
+            const size_t at = ((size_t)ni * C + c) * 9;
+            float zv[9];
+            uint8_t mk[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { zv[e] = z[at + e]; mk[e] = mask[(size_t)t * n * kFlat + at + e]; }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const float v = fmaxf(fmaf(zv[e], sc, sh), 0.f);
+                o[at + e] = mk[e] ? v * 2.f : 0.f;                   // dropout 0.5 in front of d1 (nets.py:178)
+            }
         }
     }
 }
@@ -478,12 +464,16 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
         const float* __restrict__ z = sel3(Z.p, t);
         const float* __restrict__ d = sel3(dUp.p, t);
         float fb = 0.f, fg = 0.f;
-        for (int idx = threadIdx.x; idx < n * 9; idx += 256) {
-            const int ni = idx / 9, e = idx - ni * 9;
-            const size_t at = ((size_t)ni * C + c) * 9 + e;
-            const float zv = z[at];
-            const float dy = fmaf(zv, lo.x, lo.y) > 0.f ? d[at] : 0.f;
-            fb += dy; fg = fmaf(dy, (zv - lo.z) * lo.w, fg);
+        for (int ni = threadIdx.x; ni < n; ni += 256) {
+            const size_t at = ((size_t)ni * C + c) * 9;
+            float zv[9], dv[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { zv[e] = z[at + e]; dv[e] = d[at + e]; }
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const float dy = fmaf(zv[e], lo.x, lo.y) > 0.f ? dv[e] : 0.f;
+                fb += dy; fg = fmaf(dy, (zv[e] - lo.z) * lo.w, fg);
+            }
         }
         sb = fb; sg = fg;
     } else {
@@ -508,19 +498,41 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
 // and d W = d wf flipped back to Lasagne's true-convolution layout.  One workgroup per (channel, tower).
 __global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, int units, int n, const double* __restrict__ mom, CPtr3 l1p,
                                                       CPtr3 l1m, float* grads, int w_off0, int bn_off0, int tower_stride) {
-    __shared__ double s_red[4];
+    __shared__ double s_w[4][10];
     __shared__ double s_A[10];
     const int c = blockIdx.x, t = blockIdx.y;
-    const float* __restrict__ p = part + (size_t)t * units * 200 + c * 10;
+    const float2* __restrict__ p = reinterpret_cast<const float2*>(part + (size_t)t * units * 200 + c * 10);
     double a[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) a[k] = 0;
-    for (int u = threadIdx.x; u < units; u += 256) {
+    for (int u0 = threadIdx.x; u0 < units; u0 += 4 * 256) {
+        float2 v[4][5];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) a[k] += p[(size_t)u * 200 + k];
+        for (int q = 0; q < 4; ++q) {
+            const int u = min(u0 + 256 * q, units - 1);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[q][k] = p[(size_t)u * 100 + k];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (u0 + 256 * q < units) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { a[2 * k] += v[q][k].x; a[2 * k + 1] += v[q][k].y; }
+            }
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 10; ++k) { const double v = block_sum(a[k], s_red); if (threadIdx.x == 0) s_A[k] = v; }
+    for (int k = 0; k < 10; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_down(a[k], o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s_w[threadIdx.x >> 6][k] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) s_A[threadIdx.x] = (s_w[0][threadIdx.x] + s_w[1][threadIdx.x]) + (s_w[2][threadIdx.x] + s_w[3][threadIdx.x]);
+    __syncthreads();
     if (threadIdx.x != 0) return;
     const float* l1 = sel3(l1p.p, t) + c * 12;
     const float* lm = sel3(l1m.p, t);
@@ -591,30 +603,41 @@ __global__ __launch_bounds__(256) void eval_sum_kernel(const float* __restrict__
 
 // Training head in one pass per row: out_layer (270 -> 15) + softmax + cross-entropy, d logits = (p - onehot)/n, and
 // the gradient that flows back through fc_2's ReLU:  dR2[row][k] = (R2[row][k] > 0) * sum_c dlog[c] * W[k][c].
-// 16 lanes per row (lane = class), 16 rows per workgroup.  The workgroup that finishes last adds the per-row losses in a
-// fixed order into the batch mean (no extra launch; the ticket is an integer atomic, the sum itself is ordered).
-__global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict__ R2, const float* __restrict__ W,
-                                                        const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
-                                                        float* __restrict__ probs /*[n][16]*/, float* __restrict__ dlog /*[n][16]*/,
-                                                        float* __restrict__ loss_rows /*[n]*/, float* __restrict__ dR2 /*[n][kFC2ld]*/,
-                                                        float* __restrict__ loss_mean, unsigned int* ticket) {
-    __shared__ float s_w[kFC2 * 15 + 16];
-    __shared__ float s_x[16][kFC2ld];
-    __shared__ float s_d[16][16];
-    __shared__ double s_red[4];
+// 16 lanes per row (lane = class), kHeadRows rows per workgroup (small workgroups: at batch 256 the kernel is one latency
+// chain per workgroup, so more of them in parallel is what shortens it).  The workgroup that finishes last adds the per-row
+// losses in a fixed order into the batch mean (no extra launch; the ticket is an integer atomic, the sum itself is ordered).
+constexpr int kHeadRows = 8, kHeadThreads = 16 * kHeadRows;
+__global__ __launch_bounds__(kHeadThreads) void head_train_kernel(const float* __restrict__ R2, const float* __restrict__ W,
+                                                                 const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
+                                                                 float* __restrict__ probs /*[n][16]*/, float* __restrict__ dlog /*[n][16]*/,
+                                                                 float* __restrict__ loss_rows /*[n]*/, float* __restrict__ dR2 /*[n][kFC2ld]*/,
+                                                                 float* __restrict__ loss_mean, unsigned int* ticket) {
+    __shared__ __attribute__((aligned(16))) float s_w[kFC2 * 15 + 18];
+    __shared__ __attribute__((aligned(16))) float s_x[kHeadRows][kFC2ld];
+    __shared__ float s_d[kHeadRows][16];
+    __shared__ double s_red[kHeadThreads / 64];
     __shared__ bool s_last;
-    for (int e = threadIdx.x; e < kFC2 * 15; e += 256) s_w[e] = W[e];
-    if (threadIdx.x < 15) s_w[kFC2 * 15 + threadIdx.x] = b[threadIdx.x];
-    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-    const int row0 = blockIdx.x * 16, row = row0 + r;
-    for (int e = threadIdx.x; e < 16 * kFC2ld; e += 256) {
-        const int rr = e / kFC2ld, k = e - rr * kFC2ld;
-        s_x[rr][k] = (row0 + rr < n) ? R2[(size_t)(row0 + rr) * kFC2ld + k] : 0.f;
+    constexpr int NT = kHeadThreads;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < kFC2 * 15; e += NT) s_w[e] = W[e];
+    if (tid < 15) s_w[kFC2 * 15 + tid] = b[tid];
+    const int r = tid >> 4, c = tid & 15;
+    const int row0 = blockIdx.x * kHeadRows, row = row0 + r;
+    {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(R2 + (size_t)row0 * kFC2ld);      // kFC2ld = 272 = 68 float4 per row
+        const int rows_here = min(kHeadRows, n - row0);
+        for (int e = tid; e < kHeadRows * (kFC2ld / 4); e += NT)
+            reinterpret_cast<float4*>(&s_x[0][0])[e] = (e < rows_here * (kFC2ld / 4)) ? src[e] : float4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
     const int cc = c < 15 ? c : 14;                                // lane 15 shadows class 14, its results are dropped
-    float z = s_w[kFC2 * 15 + cc];
-    for (int k = 0; k < kFC2; ++k) z = fmaf(s_x[r][k], s_w[k * 15 + cc], z);
+    float z0 = s_w[kFC2 * 15 + cc], z1 = 0.f;
+#pragma unroll 5
+    for (int k = 0; k < kFC2; k += 2) {                            // two independent chains (same order of additions per chain)
+        z0 = fmaf(s_x[r][k], s_w[k * 15 + cc], z0);
+        z1 = fmaf(s_x[r][k + 1], s_w[(k + 1) * 15 + cc], z1);
+    }
+    const float z = z0 + z1;
     float mx = z;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -645,14 +668,14 @@ __global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict
     // ---- batch mean of the losses by the last workgroup
     __threadfence();                                               // this workgroup's loss_rows are visible device-wide
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
     __syncthreads();
     if (!s_last) return;
     __threadfence();                                               // acquire: the other workgroups' rows
     double s = 0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)__builtin_nontemporal_load(loss_rows + i);
+    for (int i = tid; i < n; i += NT) s += (double)__builtin_nontemporal_load(loss_rows + i);
     s = block_sum(s, s_red);
-    if (threadIdx.x == 0) { loss_mean[0] = (float)(s / n); *ticket = 0u; }
+    if (tid == 0) { loss_mean[0] = (float)(s / n); *ticket = 0u; }
 }
 
 // sum of the partial weight gradients of ALL conv layers in a fixed order (deterministic): blockIdx.z = layer, 64 elements x
@@ -695,7 +718,7 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(WgFinalArgs a) {
 // slices x bands x parts).  SCS_WG_SLICES="b,c,d,e" (conv2..conv5) overrides for tuning runs.
 struct WgSlices { int v[kConvs]; };
 static WgSlices wg_slices() {
-    WgSlices s{{0, 64, 128, 256, 64}};
+    WgSlices s{{0, 64, 128, 64, 64}};
     if (const char* e = getenv("SCS_WG_SLICES")) {
         int x[4];
         if (sscanf(e, "%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3]) == 4)
@@ -739,7 +762,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     float* G = h->grads;
     constexpr HeadOff H = head_off();
     constexpr TowerOff T0 = tower_off(0);
-    hipStream_t sd = w->side;
+    static const bool one_stream = getenv("SCS_TRAIN_ONE_STREAM") != nullptr;      // tuning runs: no side stream
+    hipStream_t sd = one_stream ? st : w->side;
 
     w->prof = stage_ms != nullptr;
     if (w->prof) {
@@ -751,8 +775,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         launch();
         if (w->prof) { (void)hipEventRecord(w->pev[2 * stage + 1], s); w->pused[stage] = true; }
     };
-    auto fork = [&]() { (void)hipEventRecord(w->ev_fork, st); (void)hipStreamWaitEvent(sd, w->ev_fork, 0); };   // sd sees what st has done
-    auto join = [&]() { (void)hipEventRecord(w->ev_join, sd); (void)hipStreamWaitEvent(st, w->ev_join, 0); };   // st waits for sd
+    auto fork = [&]() { if (sd != st) { (void)hipEventRecord(w->ev_fork, st); (void)hipStreamWaitEvent(sd, w->ev_fork, 0); } };   // sd sees what st has done
+    auto join = [&]() { if (sd != st) { (void)hipEventRecord(w->ev_join, sd); (void)hipStreamWaitEvent(st, w->ev_join, 0); } };   // st waits for sd
     auto c3 = [&](auto& a, int i) { CPtr3 r; for (int t = 0; t < kTowers; ++t) r.p[t] = reinterpret_cast<const float*>(a[t][i]); return r; };
     auto p3 = [&](auto& a, int i) { Ptr3 r; for (int t = 0; t < kTowers; ++t) r.p[t] = reinterpret_cast<float*>(a[t][i]); return r; };
 
@@ -778,7 +802,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat, kFlat, kFC1};
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
-        run(ST_PREP, st, [&] { hipLaunchKernelGGL(prep_kernel, dim3(32, kPackJobs + kTrJobs + 2), dim3(256), 0, st, pa); });
+        run(ST_PREP, st, [&] { hipLaunchKernelGGL(prep_kernel, dim3(64, kPackJobs + kTrJobs + 2), dim3(256), 0, st, pa); });
     }
 
     // ---- forward, training mode
@@ -837,7 +861,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     g.p[0] = GemmProblem{w->cat2, kFC1ld, P + H.fc2W, kFC2, P + H.fc2b, w->R2, kFC2ld};
     run(ST_FC2, st, [&] { gemm_launch(g, 1, st); });
     run(ST_HEAD, st, [&] {
-        hipLaunchKernelGGL(head_train_kernel, dim3((n + 15) / 16), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,
+        hipLaunchKernelGGL(head_train_kernel, dim3((n + kHeadRows - 1) / kHeadRows), dim3(kHeadThreads), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,
                            w->loss_rows, w->dR2, w->loss_dev, w->counter);
     });
 
@@ -895,6 +919,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
                                    c3(w->low4, i), p3(w->cf4, i), G, T0.bn[i], kTowerFloats, CPtr3{}, CPtr3{}, n);
             });
         }
+        // data gradient (d z_i while staging, stored for the weight gradient; epilogue: partial sums of layer i-1)
         ConvArgs a{};
         a.n = n;
         for (int t = 0; t < kTowers; ++t) {
@@ -913,14 +938,18 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         fork();
         WgArgs wa{};
         float* part = w->wg_part + (size_t)(i - 1) * kTowers * kWgPartFloats;
-        for (int t = 0; t < kTowers; ++t) { wa.X[t] = w->X[t][i]; wa.dZ[t] = w->dZ[t][i]; wa.w1[t] = w->w1p[t]; }
+        for (int t = 0; t < kTowers; ++t) {
+            wa.X[t] = w->X[t][i]; wa.w1[t] = w->w1p[t]; wa.dZ[t] = w->dZ[t][i];
+            wa.Z[t] = w->Z[t][i]; wa.dUp[t] = dUp.p[t]; wa.cf[t] = reinterpret_cast<const float*>(w->cf4[t][i]);
+        }
         wa.x0 = x0;
-        wa.part = part; wa.n = n; wa.slices = n < slices.v[i] ? n : slices.v[i];
+        constexpr int kParts[kConvs] = {0, WG2::NB, WG3::NB, WG4::NB, WG5::NB};
+        const int max_slices = (int)(kWgPartFloats / ((size_t)kParts[i] * kCin[i] * 9 * C));      // what the partial buffer holds
+        wa.part = part; wa.n = n; wa.slices = std::min(std::min(n, slices.v[i]), max_slices);
         if (i == 4) run(ST_WG5, sd, [&] { wgrad_launch<WG5>(wa, sd); });
         else if (i == 3) run(ST_WG4, sd, [&] { wgrad_launch<WG4>(wa, sd); });
         else if (i == 2) run(ST_WG3, sd, [&] { wgrad_launch<WG3>(wa, sd); });
         else run(ST_WG2, sd, [&] { wgrad_launch<WG2>(wa, sd); });
-        constexpr int kParts[kConvs] = {0, WG2::NB * WG2::PARTS, WG3::NB * WG3::PARTS, WG4::NB * WG4::PARTS, WG5::NB * WG5::PARTS};
         fa.j[i - 1] = WgFinalJob{part, wa.slices * kParts[i], kCin[i], C, T0.convW[i]};
     }
     // conv1 block: gradients from the layer-1 sums and the input moments (caller's stream); all conv weight-gradient

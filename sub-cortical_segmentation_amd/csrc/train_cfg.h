@@ -1,0 +1,34 @@
+// Kernel configurations of the training step (scs_train.hip), shared with the micro-benchmark tools/tbench.hip.
+#pragma once
+#include "conv_mfma.h"
+#include "wgrad_mfma.h"
+
+namespace scs {
+
+// ------------------------------------------------------------------------------------------- configurations
+// <CIN, COUT, HIN, patches per workgroup, epilogue, source, LDS plane stride, bands, workgroups per CU>; tilings picked at
+// batch 256 with tools/tbench.hip (profiles/r02_tbench_sweep.txt)
+using TF12 = ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 4>;          // conv1 (recomputed) + conv2
+using TF3 = ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 208, 1, 4>;      // BN2 + ReLU + pool1 while staging
+using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4>;           // BN3 + ReLU while staging
+using TF5 = ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4>;        // BN4 + ReLU + pool2 while staging
+// data gradients: input = dZ_i (computed while staging) zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i; the epilogue
+// leaves the BN-backward partial sums of the block below
+using DG5 = ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4>;     // below: conv4 block (pooled)
+using DG4 = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3>;   // below: conv3 block
+using DG3 = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3>;   // below: conv2 block (pooled)
+using DG2 = ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 256, 5, 4>;        // below: conv1 block (recomputed)
+
+constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
+// <CIN, COUT, HIN, row bands, workgroups per CU, X source, d z source, patches per staging round>.  d z is read from memory
+// (ZSRC 0: the data-gradient kernel of the layer stores it as a by-product of its staging, which costs it nothing, while
+// forming it again here costs 3-15 us per layer - tools/tbench.hip); conv2's X is the recomputed conv1 block output.
+using WG2 = WgCfg<20, 20, 30, 4, 3, 1, 0, 1>;
+using WG3 = WgCfg<20, 40, 14, 2, 3, 0, 0, 1>;
+using WG4 = WgCfg<40, 40, 12, 5, 3, 0, 0, 1>;
+using WG5 = WgCfg<40, 60, 5, 1, 2, 0, 0, 1>;
+constexpr size_t kWgPartFloats = (size_t)256 * 60 * 40 * 9;   // per tower and layer: room for 256 partials of the largest layer
+constexpr int kL1Bands = DG2::NB;
+
+
+}  // namespace scs

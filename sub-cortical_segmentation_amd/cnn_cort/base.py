@@ -12,6 +12,9 @@ Mirrors /root/reference/cnn_cort/base.py (load_data :11-37, load_test_names :41-
     4-D atlas go to the GPU once and libscs cuts the tri-planar patches inside the first conv kernel
     (scs_forward_volume).  Labels and probabilities come from ONE forward pass (the reference runs the net
     twice when out_probabilities is set, base.py:425,435).
+  * load_data_compact / generate_training_set_compact keep a training set as volumes + voxel rows + one index
+    permutation (77 bytes per sample instead of 12.3 KB): Net.fit cuts the patches inside the first conv kernel
+    (scs_train_step_volume).  load_data / generate_training_set keep their signatures and outputs.
   * registration (register_masks, base.py:483-551: NiftyReg binaries + atlases that do not ship,
     .MISSING_LARGE_BLOBS) is out of scope: tmp/MNI_sub_probabilities.nii.gz and tmp/MNI_subcortical_mask.nii.gz
     must exist (FileNotFoundError otherwise).
@@ -190,6 +193,98 @@ def generate_training_set(x_axial, x_coronal, x_saggital, x_atlas, y, options, r
         print("    --> Y_TRAIN POS: ", y_train[y_train > 0].shape[0])
         print("    --> Y_TRAIN NEG: ", y_train[y_train == 0].shape[0])
     return x_train_axial, x_train_cor, x_train_sag, x_train_atlas, y_train
+
+
+# --------------------------------------------------------------------------------------------- compact training set
+class CompactTrainingData:
+    """What load_data returns, without the patches: per subject the z-scored volume, the label volume, the sampled voxel
+    positions (positives then negatives, as load_patch_vectors orders them) and the prior vectors at those voxels."""
+
+    def __init__(self, volumes, labels, positions, atlas, names):
+        self.volumes, self.labels, self.positions, self.atlas, self.names = volumes, labels, positions, atlas, names
+
+
+class CompactTrainingSet:
+    """A training set as the GPU consumes it (scs_train_step_volume): volumes + one (volume, x, y, z) row, one prior row and
+    one label per sample + the permutation as an index array - 77 bytes per sample instead of 12.3 KB of patches.
+    `materialize()` gives back exactly what generate_training_set returns for the same data and seed."""
+
+    def __init__(self, volumes, labels, samples, atlas, y, index):
+        self.volumes = [np.ascontiguousarray(v, dtype=np.float32) for v in volumes]
+        self.labels = [np.ascontiguousarray(v, dtype=np.uint8) for v in labels]
+        self.samples = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, 4)
+        self.atlas = np.ascontiguousarray(atlas, dtype=np.float32).reshape(-1, 15)
+        self.y = np.ascontiguousarray(y, dtype=np.uint8).reshape(-1)
+        self.index = np.ascontiguousarray(index, dtype=np.int32).reshape(-1)
+        n = self.samples.shape[0]
+        if not (self.atlas.shape[0] == n and self.y.shape[0] == n and self.index.shape[0] <= n):
+            raise ValueError('samples, atlas rows, labels and index disagree on the number of samples')
+
+    def __len__(self):
+        return int(self.index.shape[0])
+
+    def descriptors(self):
+        """(offsets into the concatenated volume buffer, dims) per volume - the scs_volume table (include/scs.h)."""
+        offs, dims, at = [], [], 0
+        for v in self.volumes:
+            offs.append(at)
+            dims.append(v.shape)
+            at += v.size
+        return offs, dims
+
+    def materialize(self, lo=0, hi=None):
+        """Host patches of rows index[lo:hi]: (x_axial [n,1,32,32], x_cor, x_sag, x_atlas [n,15], y [n]) - what
+        generate_training_set returns (base.py:53-117)."""
+        rows = self.index[lo:hi]
+        smp = self.samples[rows]
+        out = []
+        for mode in _MODES:
+            x = np.zeros((rows.shape[0], 32, 32), np.float32)
+            for v, vol in enumerate(self.volumes):
+                sel = np.nonzero(smp[:, 0] == v)[0]
+                if sel.size:
+                    x[sel] = get_patches(vol, smp[sel, 1:4], (32, 32), mode)
+            out.append(x[:, None])
+        return out[0], out[1], out[2], self.atlas[rows], self.y[rows]
+
+
+def load_data_compact(options):
+    """load_data (base.py:11-37) without cutting patches: same subjects, same voxel sampling (every voxel with label 1..14,
+    then as many randomly chosen label-15 voxels, same generator state as load_data under options['seed']), same prior
+    vectors - but the tri-planar patches stay implicit in (volume, voxel) and are cut on the GPU."""
+    rng = random.Random(options['seed']) if options.get('seed') is not None else None
+    dir_name, name, label_name = options['train_folder'], options['t1_name'], options['roi_name']
+    subjects = _subjects(dir_name)
+    image_names = [os.path.join(dir_name, s, name) for s in subjects]
+    volumes = [np.ascontiguousarray(_zscore(nifti.load(n).get_data(), True), dtype=np.float32) for n in image_names]
+    labels = [np.ascontiguousarray(nifti.load(os.path.join(dir_name, s, label_name)).get_data()) for s in subjects]
+    pos = [get_mask_voxels(np.logical_and(m > 0, m < 15)) for m in labels]
+    neg = [get_mask_voxels(m == 15, size=len(p), rng=rng) for m, p in zip(labels, pos)]
+    positions = [np.concatenate([p, n]) for p, n in zip(pos, neg)]
+    atlas = get_atlas_vectors(dir_name, positions, image_names)
+    return CompactTrainingData(volumes, [lb.astype(np.uint8) for lb in labels], positions, atlas, image_names)
+
+
+def generate_training_set_compact(data, options, randomize=True):
+    """generate_training_set (base.py:53-117) on the compact form: subjects concatenated, centre label with 15 -> 0, and the
+    ONE permutation the reference applies to all five arrays kept as an index array (same seed -> same order)."""
+    samples = np.concatenate([np.concatenate([np.full((p.shape[0], 1), v, np.int64), p], axis=1) for v, p in enumerate(data.positions)])
+    atlas = np.concatenate(data.atlas, axis=0).astype('float32')
+    y = np.concatenate([lb[p[:, 0], p[:, 1], p[:, 2]] for lb, p in zip(data.labels, data.positions)]).astype('uint8')
+    y[y == 15] = 0
+    n = samples.shape[0]
+    index = np.arange(n)
+    if randomize:
+        seed = options.get('seed')
+        if seed is None:
+            seed = np.random.randint(np.iinfo(np.int32).max)
+        np.random.seed(seed)
+        index = np.random.permutation(n)
+    if is_true(options.get('debug')):
+        print("    --> X_TRAIN: ", n, (n, 1, 32, 32))
+        print("    --> Y_TRAIN POS: ", y[y > 0].shape[0])
+        print("    --> Y_TRAIN NEG: ", y[y == 0].shape[0])
+    return CompactTrainingSet(data.volumes, data.labels, samples, atlas, y, index)
 
 
 # --------------------------------------------------------------------------------------------- inference

@@ -192,6 +192,18 @@ def sum_scalar(value):
     return float(t[0])
 
 
+def sum_pair(a, b):
+    """Sum of two per-rank scalars over the ranks in ONE exchange (epoch loss sums and their counts)."""
+    if world_size() == 1:
+        return float(a), float(b)
+    import torch
+    td = _td()
+    dev = 'cuda' if td.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([float(a), float(b)], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t[0]), float(t[1])
+
+
 def barrier():
     if is_dist() and world_size() > 1:
         _td().barrier()

@@ -111,8 +111,11 @@ class Net:
     """Drop-in for the nolearn NeuralNet the reference builds at nets.py:233-246."""
 
     def __init__(self, weights_file=None, history_file=None, max_epochs=100, patience=20, eval_size=0.25,
-                 batch_size=128, verbose=0, device=None, update_learning_rate=0.001, seed=0, augment=False):
+                 batch_size=128, verbose=0, device=None, update_learning_rate=0.001, seed=0, augment=False,
+                 fit_slice=16384, fit_resident_bytes=2 << 30):
         self.augment = bool(augment)
+        self.fit_slice = int(fit_slice)                      # samples per streamed slice of a materialised training set
+        self.fit_resident_bytes = int(fit_resident_bytes)    # sets up to this size are uploaded once instead
         self.weights_file = weights_file
         self.history_file = history_file
         self.max_epochs = int(max_epochs)
@@ -354,40 +357,178 @@ class Net:
         return labels, (d_pr.cpu().numpy() if want_probs else None)
 
     # ------------------------------------------------------------------ training
-    def fit(self, X, y, epochs=None):
-        """net.fit({'in1','in2','in3','in4'}, y) - train_model.py:57-60."""
-        from . import dist
+    def _uploads_ahead(self, host_slices):
+        """Run `host_slices` (a generator of lists of host arrays) in a helper thread that uploads each list on its own
+        stream, one slice ahead of the consumer: the transfer of slice i+1 runs under the kernels of slice i.  Yields
+        lists of device tensors that the consumer's current stream may use."""
+        import queue
+        import threading
         torch = self._torch()
-        n = self._check_X(X)
-        y = np.asarray(y)
-        if y.shape[0] != n:
-            raise ValueError('y has %d labels for %d samples' % (y.shape[0], n))
-        if y.size and (y.min() < 0 or y.max() > 14):
+        dev = self._dev()
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        q = queue.Queue(maxsize=1)                 # one slice in flight + one being consumed = two resident slices
+
+        def uploader():
+            try:
+                with torch.cuda.stream(side):
+                    for arrs in host_slices:
+                        ts = [torch.from_numpy(a).to('cuda:%d' % dev, non_blocking=False) for a in arrs]
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        q.put((ts, ev))
+                q.put(None)
+            except BaseException as e:            # surfaced in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=uploader, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                ts, ev = item
+                main.wait_event(ev)
+                for t in ts:
+                    t.record_stream(main)
+                yield ts
+        finally:
+            while th.is_alive():                  # drain so that the helper can finish if the consumer stopped early
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+
+    def fit(self, X, y=None, epochs=None):
+        """net.fit({'in1','in2','in3','in4'}, y) - train_model.py:57-60.
+
+        X may also be a cnn_cort.base.CompactTrainingSet (volumes + voxel rows + index permutation, from
+        generate_training_set_compact): the patches are then cut inside the first conv kernel and never exist in memory.
+
+        Materialised sets stay on the HOST; the device holds two slices of `self.fit_slice` samples at a time (default
+        16 384: 2 x 202 MB), uploaded one slice ahead of the kernels, unless the whole set fits `self.fit_resident_bytes`
+        (default 2 GiB), in which case it is uploaded once.
+
+        Data parallel (torch.distributed initialised): mini-batch s*world + r goes to rank r, so one optimiser step sees
+        world x batch_size samples at the unchanged learning rate (the reference is single-device; scale batch_size down by
+        the world size for history-comparable runs); the hold-out pass is sharded over the ranks."""
+        from . import dist
+        from .base import CompactTrainingSet
+        torch = self._torch()
+        compact = isinstance(X, CompactTrainingSet)
+        if compact:
+            n = len(X)
+            y_all = X.y[X.index]                       # labels in training order
+        else:
+            n = self._check_X(X)
+            if y is None:
+                raise ValueError('fit() needs the labels y')
+            y_all = np.asarray(y)
+            if y_all.shape[0] != n:
+                raise ValueError('y has %d labels for %d samples' % (y_all.shape[0], n))
+        if y_all.size and (y_all.min() < 0 or y_all.max() > 14):
             raise ValueError('labels must lie in 0..14')
         h = self._ensure_handle()
         dev = 'cuda:%d' % self._dev()
         stream = torch.cuda.current_stream(self._dev()).cuda_stream
+        world, rank = dist.world_size(), dist.rank()
 
         if self.eval_size and self.eval_size > 0:
-            tr_idx, va_idx = stratified_first_fold(y, int(round(1.0 / self.eval_size)))
+            tr_idx, va_idx = stratified_first_fold(y_all, int(round(1.0 / self.eval_size)))
         else:
             tr_idx, va_idx = np.arange(n), np.arange(0)
-
-        def to_dev(idx):
-            arrs = []
-            for key in ('in1', 'in2', 'in3', 'in4'):
-                a = X[key]
-                if isinstance(a, np.ndarray):
-                    arrs.append(torch.from_numpy(np.ascontiguousarray(a[idx], dtype=np.float32)).to(dev))
-                else:
-                    arrs.append(a[torch.as_tensor(idx, device=a.device)].to(device=dev, dtype=torch.float32).contiguous())
-            arrs.append(torch.from_numpy(np.ascontiguousarray(y[idx], dtype=np.uint8)).to(dev))
-            return arrs
-
-        Xtr, Xva = to_dev(tr_idx), to_dev(va_idx)
         ntr, nva = len(tr_idx), len(va_idx)
         bs = self.batch_size
-        world, rank = dist.world_size(), dist.rank()
+        starts = list(range(0, ntr, bs))
+        my_starts = starts[rank::world]                # lock-step schedule: step s gives rank r the batch s*world + r
+        n_steps = (len(starts) + world - 1) // world
+        va_lo, va_hi = dist.shard_range(nva)           # this rank's share of the hold-out pass
+        keys = ('in1', 'in2', 'in3', 'in4')
+
+        if compact:
+            offs, dims = X.descriptors()
+            d_vols = torch.from_numpy(np.concatenate([v.ravel() for v in X.volumes])).to(dev)
+            desc = np.zeros((len(offs), 3), np.int64)          # scs_volume: int64 offset, int32 x, y, z, reserved
+            desc_i32 = desc.view(np.int32).reshape(len(offs), 6)
+            for i, (o, d) in enumerate(zip(offs, dims)):
+                desc[i, 0] = o
+                desc_i32[i, 2:5] = d
+            d_desc = torch.from_numpy(desc).to(dev)
+            d_samples = torch.from_numpy(X.samples).to(dev)
+            d_atlas = torch.from_numpy(X.atlas).to(dev)
+            d_labvols = torch.from_numpy(np.concatenate([v.ravel() for v in X.labels])).to(dev)
+            d_y = torch.empty((X.samples.shape[0],), dtype=torch.uint8, device=dev)
+            h.gather_labels(d_labvols, d_desc, d_samples, X.samples.shape[0], d_y, stream)     # centre label, 15 -> 0, on the device
+            del d_labvols
+            d_tr = torch.from_numpy(X.index[tr_idx].astype(np.int32)).to(dev)
+            d_va = torch.from_numpy(X.index[va_idx].astype(np.int32)).to(dev)
+
+            def train_batches():
+                for lo in my_starts:
+                    hi = min(ntr, lo + bs)
+                    yield hi - lo, (lambda seed, lo=lo, hi=hi: h.train_step_volume(
+                        d_vols, d_desc, d_samples, d_atlas, d_y, d_tr[lo:hi], hi - lo, seed=seed, want_loss=False, stream=stream))
+
+            def evaluate():
+                return h.eval_batch_volume(d_vols, d_desc, d_samples, d_atlas, d_y, d_va[va_lo:va_hi], va_hi - va_lo, stream=stream)
+        else:
+            per_sample = 3 * 4096 + 60 + 1
+            on_device = all((not isinstance(X[k], np.ndarray)) and X[k].is_cuda for k in keys)     # caller's tensors already in HBM
+            resident = on_device or (ntr + nva) * per_sample <= self.fit_resident_bytes
+            sl = max(bs, (self.fit_slice // bs) * bs)              # slice = whole mini-batches
+
+            def host_rows(idx):
+                return [np.ascontiguousarray(X[k][idx] if isinstance(X[k], np.ndarray) else X[k][torch.as_tensor(idx)].cpu().numpy(),
+                                             dtype=np.float32) for k in keys] + [np.ascontiguousarray(y_all[idx], dtype=np.uint8)]
+
+            my_rows = np.concatenate([tr_idx[lo:min(ntr, lo + bs)] for lo in my_starts]) if my_starts else np.arange(0)
+            my_sizes = [min(ntr, lo + bs) - lo for lo in my_starts]
+            def device_rows(idx):
+                if not on_device:
+                    return [torch.from_numpy(a).to(dev) for a in host_rows(idx)]
+                it = torch.as_tensor(idx, device=dev)
+                return [X[k].to(dev)[it].to(torch.float32).contiguous() for k in keys] + \
+                       [torch.from_numpy(np.ascontiguousarray(y_all[idx], dtype=np.uint8)).to(dev)]
+
+            if resident:
+                r_tr, r_va = device_rows(my_rows), device_rows(va_idx[va_lo:va_hi])
+
+            def train_slices():
+                if resident:
+                    yield r_tr, my_sizes
+                    return
+                per_slice = max(1, sl // bs)                        # my mini-batches per slice
+                groups = [my_sizes[i:i + per_slice] for i in range(0, len(my_sizes), per_slice)]
+                bounds = np.concatenate([[0], np.cumsum([sum(g) for g in groups])]).astype(np.int64)
+                gen = (host_rows(my_rows[bounds[i]:bounds[i + 1]]) for i in range(len(groups)))
+                for ts, g in zip(self._uploads_ahead(gen), groups):
+                    yield ts, g
+
+            def train_batches():
+                for ts, sizes in train_slices():
+                    at = 0
+                    for nb in sizes:
+                        views = [ts[0][at:at + nb], ts[1][at:at + nb], ts[2][at:at + nb]]
+                        atl, yy = ts[3][at:at + nb], ts[4][at:at + nb]
+                        at += nb
+                        yield nb, (lambda seed, views=views, atl=atl, yy=yy, nb=nb: self._train_batch(h, views, atl, yy, nb, seed, stream, aug_rng, rank))
+
+            def evaluate():
+                if resident:
+                    return h.eval_batch(r_va[0], r_va[1], r_va[2], r_va[3], r_va[4], va_hi - va_lo, stream=stream)
+                ls, nc = 0.0, 0
+                mine = va_idx[va_lo:va_hi]
+                gen = (host_rows(mine[lo:lo + sl]) for lo in range(0, len(mine), sl))
+                for ts in self._uploads_ahead(gen):
+                    a, b = h.eval_batch(ts[0], ts[1], ts[2], ts[3], ts[4], int(ts[4].shape[0]), stream=stream)
+                    ls += a
+                    nc += b
+                return ls, nc
+
         hooks = [self._hook_save_weights, self._hook_save_history, EarlyStopping(self.patience)]
         aug_rng = torch.Generator(device=dev) if self.augment else None
         best_train, best_valid = np.inf, np.inf
@@ -398,41 +539,33 @@ class Net:
         try:
             for ep in range(epochs or self.max_epochs):
                 t0 = time.time()
-                starts = list(range(0, ntr, bs))
                 # batch losses are collected on the device and read back once per epoch (no per-step synchronisation)
-                loss_buf = torch.zeros((max(1, (len(starts) + world - 1) // world),), dtype=torch.float32, device=dev)
-                n_loss, loss_view = 0, None
-                for step, (lo, active) in enumerate(dist.shard_steps(starts, world, rank)):
+                loss_buf = torch.zeros((max(1, n_steps),), dtype=torch.float32, device=dev)
+                sizes, loss_view = [], None
+                batches = train_batches()
+                for step in range(n_steps):
+                    item = next(batches, None)
+                    active = item is not None
                     if active:
-                        hi = min(ntr, lo + bs)
+                        nb, run = item
                         self._step += 1
-                        views = [Xtr[0][lo:hi], Xtr[1][lo:hi], Xtr[2][lo:hi]]
-                        if self.augment and hi - lo > 1:
-                            aug_rng.manual_seed((self.seed << 20) + self._step * 8 + rank)
-                            idx = torch.randperm(hi - lo, generator=aug_rng, device=dev)[:(hi - lo) // 2]
-                            views = rotate_flip_views(views, idx, [torch.randint(0, 3, (idx.numel(),), generator=aug_rng, device=dev)
-                                                                   for _ in range(3)])
-                        h.train_step(views[0], views[1], views[2], Xtr[3][lo:hi], Xtr[4][lo:hi], hi - lo,
-                                     seed=(self.seed << 32) + self._step * 131 + rank, want_loss=False, stream=stream)
+                        run((self.seed << 32) + self._step * 131 + rank)
                         if loss_view is None:
                             loss_view = dist.wrap_device_floats(h.train_loss_ptr(), 1, self._dev())
-                        loss_buf[n_loss:n_loss + 1].copy_(loss_view, non_blocking=True)
-                        n_loss += 1
+                        loss_buf[len(sizes):len(sizes) + 1].copy_(loss_view, non_blocking=True)
+                        sizes.append(nb)
                     scale = dist.allreduce_grads(h, active, stream, n_active=dist.active_ranks(len(starts), step, world))
                     h.adam_apply(lr=self.update_learning_rate, grad_scale=scale, stream=stream)
-                losses = loss_buf[:n_loss].cpu().numpy().astype(np.float64).tolist()
+                losses = loss_buf[:len(sizes)].cpu().numpy().astype(np.float64)
                 self._dev_newer = True
                 dist.sync_params(h)            # reconcile per-rank BN running statistics (no-op on one GPU)
-                vloss, vcorrect = 0.0, 0
-                # validation: nolearn averages the batch losses weighted by batch size = the mean over samples, so
-                # the hold-out set goes through in large slices (one read-back each) instead of `bs` at a time
-                for lo in range(0, nva, _SUPER * 4):
-                    hi = min(nva, lo + _SUPER * 4)
-                    ls, nc = h.eval_batch(Xva[0][lo:hi], Xva[1][lo:hi], Xva[2][lo:hi], Xva[3][lo:hi], Xva[4][lo:hi],
-                                          hi - lo, stream=stream)
-                    vloss += ls
-                    vcorrect += nc
-                train_loss = dist.mean_scalar(float(np.mean(losses)) if losses else 0.0, len(losses))
+                # nolearn: train_loss / valid_loss = batch losses averaged with the batch sizes as weights (a ragged last
+                # batch counts for less); the hold-out pass sums per-sample losses, which is the same mean
+                w = np.asarray(sizes, np.float64)
+                loss_sum, cnt = dist.sum_pair(float((losses * w).sum()), float(w.sum()))
+                train_loss = loss_sum / cnt if cnt else 0.0
+                vloss, vcorrect = evaluate() if va_hi > va_lo else (0.0, 0)
+                vloss, vcorrect = dist.sum_pair(vloss, float(vcorrect))
                 valid_loss = vloss / nva if nva else 0.0
                 valid_acc = vcorrect / nva if nva else 0.0
                 best_train = min(best_train, train_loss)
@@ -450,6 +583,15 @@ class Net:
         except StopIteration:
             pass
         return self
+
+    def _train_batch(self, h, views, atl, yy, nb, seed, stream, aug_rng, rank):
+        if self.augment and nb > 1:
+            torch = self._torch()
+            dev = views[0].device
+            aug_rng.manual_seed((self.seed << 20) + self._step * 8 + rank)
+            idx = torch.randperm(nb, generator=aug_rng, device=dev)[:nb // 2]
+            views = rotate_flip_views(views, idx, [torch.randint(0, 3, (idx.numel(),), generator=aug_rng, device=dev) for _ in range(3)])
+        h.train_step(views[0], views[1], views[2], atl, yy, nb, seed=seed, want_loss=False, stream=stream)
 
     # hooks (nets.py:154-156, 238-242)
     def _hook_save_weights(self, net, history):

@@ -350,3 +350,28 @@ def test_post_processing_fast_path_equals_the_literal_procedure(seed):
     want = R.post_process_segmentation(seg, atlas)
     got = base.post_process_mask(seg, atlas)
     assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
+def test_compact_training_set_is_the_materialised_one(tmp_path):
+    """load_data_compact / generate_training_set_compact under the same seed describe exactly the arrays that load_data /
+    generate_training_set build: same voxels in the same order, same prior rows, same labels, same permutation."""
+    make_subject(str(tmp_path / 'train' / 's1'), shape=(40, 44, 36), with_labels=True)
+    make_subject(str(tmp_path / 'train' / 's2'), shape=(36, 40, 44), seed=5, with_labels=True)
+    opts = {'train_folder': str(tmp_path / 'train'), 't1_name': 'T1.nii.gz', 'roi_name': 'gt_15_classes.nii.gz',
+            'patch_size': [32, 32], 'debug': 'False', 'seed': 11}
+    x_ax, x_co, x_sa, y_ax, x_atl, _ = base.load_data(opts)
+    ref = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts)
+    data = base.load_data_compact(opts)
+    cs = base.generate_training_set_compact(data, opts)
+    assert len(cs) == ref[0].shape[0] and cs.samples.shape == (len(cs), 4) and len(cs.volumes) == 2
+    got = cs.materialize()
+    for a, b in zip(got, ref):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    part = cs.materialize(7, 50)
+    assert all(np.array_equal(p, r[7:50]) for p, r in zip(part, ref))
+    offs, dims = cs.descriptors()
+    assert offs == [0, 40 * 44 * 36] and dims == [(40, 44, 36), (36, 40, 44)]
+    # not randomised: subject order, positives before negatives
+    cs2 = base.generate_training_set_compact(data, opts, randomize=False)
+    ref2 = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts, randomize=False)
+    assert all(np.array_equal(a, b) for a, b in zip(cs2.materialize(), ref2))

@@ -52,6 +52,9 @@ def init_from_env(backend=None):
             backend = os.environ.get('SCS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             # one GPU per rank; LOCAL_RANK wraps around only in single-GPU rehearsals (gloo backend)
+            if backend == 'nccl' and world > torch.cuda.device_count():
+                raise RuntimeError('backend nccl (RCCL) needs one GPU per rank: %d ranks, %d visible device(s)'
+                                   % (world, torch.cuda.device_count()))
             local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
         td.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=world)

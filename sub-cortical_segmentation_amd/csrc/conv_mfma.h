@@ -26,9 +26,10 @@ constexpr int kW1Floats = 12 * 16 + 12 * 4 + 20;   // conv1 operands: [12][16] +
 static_assert(kW1Floats > 256 && kW1Floats <= 512, "conv1 operand staging assumes two loads per thread");
 
 // Epilogues.
-//   EPI_RAW_STATS      raw outputs plus, per (patch, band, channel), the sum and sum of squares of (output - pivot[channel])
-//                      (batch-norm statistics of the training forward pass without a second pass over the activations; the
-//                      pivot - the channel's running mean - keeps E[v^2] - E[v]^2 free of cancellation)
+//   EPI_RAW_STATS      raw outputs plus, per (patch, band, channel) unit of OUTB values, their mean and sum of squared deviations
+//                      (batch-norm statistics of the training forward pass without a second pass over the activations;
+//                      accumulated about the unit's first value and combined by the parallel-variance formula, so nothing
+//                      of the form E[v^2] - E[v]^2 is ever evaluated)
 //   EPI_RAW_BNB[_POOL] data gradient of a training conv: raw outputs dX plus, per (patch, band, channel), the partial
 //                      sums (d beta, d gamma) of the batch-norm layer BELOW (whose block output X this kernel differentiates):
 //                      dy = dX routed through that block's (max-pool and) ReLU, from its raw conv output `zlow`
@@ -133,11 +134,10 @@ struct ConvArgs {
     const int32_t* centers;       // SRC_VOLUME: [n][3]
     int dimx, dimy, dimz;
     int n;                        // patches
-    float* stats;                 // EPI_RAW_STATS / EPI_RAW_BNB*: [tower][n * NB][COUT][2] partial sums per patch band;
+    float* stats;                 // EPI_RAW_STATS: [tower][n * NB][COUT][2] (mean, M2) per patch band; EPI_RAW_BNB*: same shape, partial sums;
                                   // EPI_L1: [tower][n * NB][20][10]
     unsigned long long* stamps;   // diagnostic builds only (STAMP): [workgroup][8] s_memtime values
     // ---- training only
-    const float* pivot[kTowers];  // EPI_RAW_STATS: [COUT] statistics pivot (null: 0)
     const float* bn[kTowers];     // SRC_BN*: float2 [CIN] (scale, shift); SRC_DZ*: float4 [CIN] (sc, sh, ca, cb)
     float* xout[kTowers];         // SRC_BN*: block output X [n][CIN][HIN][HIN]; SRC_DZ*: d z [n][CIN][HSRC][HSRC] (null: not stored)
     const float* dup[kTowers];    // SRC_DZ*: upstream gradient
@@ -781,8 +781,8 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             if (live) {
                 const float* __restrict__ rp = s_o + row * C::OSTR;
                 if constexpr (C::EPI == EPI_RAW_STATS) {
-                    const float* __restrict__ pv = pick3(a.pivot, tower);
-                    const float p0 = pv ? pv[c] : 0.f;
+                    // sums about the row's own first value: no cancellation however far the channel's mean is from zero
+                    const float p0 = rp[0];
                     for (int i = sub; i < C::OUTB; i += LPR) { const float v = rp[i] - p0; sm += v; sq = fmaf(v, v, sq); }
                 } else {
                     // (d beta, d gamma) partials of the block below: dy = dX through (pool and) ReLU, xhat = (z - mean) inv_std
@@ -839,7 +839,13 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             for (int o = LPR / 2; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
             if (sub == 0 && live) {
                 float2* dst = reinterpret_cast<float2*>(sp + (((size_t)(g0 + g) * C::NB + band) * C::COUT + c) * 2);
-                *dst = make_float2(sm, sq);
+                if constexpr (C::EPI == EPI_RAW_STATS) {
+                    // (mean, sum of squared deviations) of this unit of OUTB values - combined exactly by the finalize kernel
+                    const float mu = sm * (1.f / C::OUTB);
+                    *dst = make_float2(s_o[row * C::OSTR] + mu, fmaxf(sq - sm * mu, 0.f));
+                } else {
+                    *dst = make_float2(sm, sq);
+                }
             }
         }
     }

@@ -402,10 +402,11 @@ __global__ __launch_bounds__(1024) void bn1_final_kernel(const float* __restrict
     lm[2 * c] = (float)mean; lm[2 * c + 1] = (float)inv;
 }
 
-// Batch statistics of a conv layer from the per-(patch band, channel) partials its epilogue left (sums of v - pivot and
-// (v - pivot)^2, pivot = the running mean: no cancellation), added in double in a fixed order; one workgroup per
-// (channel, tower).  Leaves scale / shift for the next conv's staging, (sc, sh, mean, inv_std) for the backward pass, and
-// moves the running averages (Lasagne BatchNormLayer, alpha 0.1, nets.py:172-177).
+// Batch statistics of a conv layer from the per-(patch band, channel) units its epilogue left - each the mean and the sum of
+// squared deviations of `per_unit` values - combined by the parallel-variance formula in double, in a fixed order:
+//   mean = avg(mean_u),  M2 = sum M2_u + per_unit * sum (mean_u - mean)^2,  var = M2 / count          (biased, as Lasagne's)
+// one workgroup per (channel, tower).  Leaves scale / shift for the next conv's staging, (sc, sh, mean, inv_std) for the
+// backward pass, and moves the running averages (Lasagne BatchNormLayer, alpha 0.1, nets.py:172-177).
 // APPLY5 (conv5 block): also applies BN + ReLU + the dropout in front of d1 to the channel's n x 9 values -> H5.
 template <bool APPLY5>
 __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const float* __restrict__ part, int units, double count, int C, float* params,
@@ -419,10 +420,14 @@ __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const float* __restri
     for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; s += v.x; q += v.y; }
     s = block_sum(s, s_red);
     q = block_sum(q, s_red);
+    const double mean = s / units;
+    double dev2 = 0;
+    for (int u = threadIdx.x; u < units; u += 256) { const double d = (double)p[(size_t)u * C].x - mean; dev2 += d * d; }
+    dev2 = block_sum(dev2, s_red);
     if (threadIdx.x == 0) {
         float* bn = params + bn_off0 + t * tower_stride;           // beta, gamma, mean, inv_std
-        const double dm = s / count, var = fmax(q / count - dm * dm, 0.0);
-        const double mean = (double)bn[2 * C + c] + dm, inv = 1.0 / sqrt(var + (double)kBnEps);
+        const double var = (q + (count / units) * dev2) / count;
+        const double inv = 1.0 / sqrt(var + (double)kBnEps);
         const float sc = bn[C + c] * (float)inv, sh = bn[c] - (float)mean * sc;
         reinterpret_cast<float2*>(sel3(ss.p, t))[c] = make_float2(sc, sh);
         reinterpret_cast<float4*>(sel3(low4.p, t))[c] = make_float4(sc, sh, (float)mean, (float)inv);
@@ -820,7 +825,6 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         a.stats = w->stat_part;
         for (int t = 0; t < kTowers; ++t) {
             a.w[t] = w->wpk[t][i]; a.out[t] = w->Z[t][i];
-            a.pivot[t] = P + T0.bn[i] + t * kTowerFloats + 2 * kCout[i];      // running mean of this layer
             if (i == 1) { a.w1[t] = w->w1p[t]; }
             else { a.in[t] = w->Z[t][i - 1]; a.bn[t] = reinterpret_cast<const float*>(w->ss[t][i - 1]); a.xout[t] = w->X[t][i]; }
         }

@@ -356,3 +356,37 @@ def test_data_parallel_rccl_two_gpus(tmp_path):
     assert np.array_equal(r0['params'], r1['params'])
     _run_ranks('dp_fit_worker.py', tmp_path, 'nccl')
     assert _check_dp_fit(tmp_path) == 'nccl'
+
+
+def test_batch_statistics_of_a_strongly_biased_channel(fresh, weights):
+    """A conv channel whose batch mean is ~600 standard deviations from zero (all-positive filter over inputs pushed up by
+    the BN shift below): E[z^2] - E[z]^2 in float32 would lose the variance entirely (error ~ 1e-7 * 700^2 = 5 %); the
+    per-unit (mean, M2) sums combined by the parallel-variance formula keep it - running statistics and gradients still
+    agree with the float64 oracle."""
+    g = gold('g5_train.npz')
+    n = g['ax'].shape[0]
+    w = {k: [a.copy() for a in v] for k, v in weights.items()}
+    w['axial_ch_conv2_bn'][0] = w['axial_ch_conv2_bn'][0] + 200.0                # beta: conv3's inputs sit near 200
+    w['axial_ch_conv3'][0][0] = 0.3                                              # channel 0: all-positive filter
+    masks = {k[5:]: g[k] for k in g.files if k.startswith('mask_')}
+    loss_ref, grads_ref, bn_ref, _ = O.train_forward_backward(w, g['ax'], g['co'], g['sa'], g['atlas'], g['y'], masks)
+    mean0, inv0 = bn_ref['axial_ch_conv3_bn'][0][0], bn_ref['axial_ch_conv3_bn'][1][0]
+    assert abs(mean0) * inv0 > 300, (mean0, inv0)                                # the scenario: |mean| >> std
+    fresh.set_params(P.params_to_flat(w))
+    st = torch.cuda.current_stream().cuda_stream
+    loss = fresh.train_step(dev(g['ax']), dev(g['co']), dev(g['sa']), dev(g['atlas']), dev(g['y'], torch.uint8), n,
+                            masks=dev(pack_masks(masks), torch.uint8), stream=st)
+    assert abs(loss - loss_ref) <= 1e-3 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    newp = P.flat_to_params(arena(fresh, 'param'))
+    run = O.bn_running_update(w, bn_ref)
+    got_inv, ref_inv = newp['axial_ch_conv3_bn'][3], np.asarray(run['axial_ch_conv3_bn'][3])
+    # inv_std enters the running average with weight 0.1: a 5 % error of the batch value would show as 5e-3 here
+    assert np.abs(got_inv - ref_inv).max() <= 2e-4 * np.abs(ref_inv).max(), np.abs(got_inv - ref_inv).max() / np.abs(ref_inv).max()
+    assert np.abs(newp['axial_ch_conv3_bn'][2] - run['axial_ch_conv3_bn'][2]).max() <= 1e-4 * np.abs(np.asarray(run['axial_ch_conv3_bn'][2])).max()
+    got = P.flat_to_params(arena(fresh, 'grad'))
+    for name in ('axial_ch_conv3', 'axial_ch_conv3_bn', 'axial_ch_conv4', 'axial_ch_conv2', 'axial_ch_conv1'):
+        for i in range(len(grads_ref[name])):
+            ref = np.asarray(grads_ref[name][i])
+            scale = max(np.abs(ref).max(), 1e-6)
+            assert np.isfinite(got[name][i]).all()
+            assert np.abs(got[name][i] - ref).max() / scale <= 2e-2, (name, i, np.abs(got[name][i] - ref).max() / scale)

@@ -60,7 +60,7 @@ static ConvArgs conv_args(int n) {
     a.n = n;
     for (int t = 0; t < kTowers; ++t) {
         a.in[t] = g_pool.in[t]; a.w[t] = g_pool.in3[t]; a.bias[t] = g_pool.coef[t]; a.out[t] = g_pool.out[t];
-        a.w1[t] = g_pool.coef[t] + 1024; a.pivot[t] = g_pool.coef[t] + 2048; a.bn[t] = g_pool.coef[t] + 512;
+        a.w1[t] = g_pool.coef[t] + 1024; a.bn[t] = g_pool.coef[t] + 512;
         a.xout[t] = (C::SRC == SRC_BN || C::SRC == SRC_BN_POOL) ? g_pool.out2[t] : nullptr;
         a.dup[t] = g_pool.in2[t]; a.zlow[t] = g_pool.in2[t]; a.bnlow[t] = g_pool.coef[t] + 3072;
         a.x0.views[t] = g_pool.in2[t];

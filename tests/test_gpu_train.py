@@ -390,3 +390,28 @@ def test_batch_statistics_of_a_strongly_biased_channel(fresh, weights):
             scale = max(np.abs(ref).max(), 1e-6)
             assert np.isfinite(got[name][i]).all()
             assert np.abs(got[name][i] - ref).max() / scale <= 2e-2, (name, i, np.abs(got[name][i] - ref).max() / scale)
+
+
+def test_rotate_flip_views_on_device_equals_the_reference_formulas():
+    """The opt-in augmentation applied to device-resident batches (what fit(augment=True) runs) against the literal
+    Rotate_batch_Iterator.transform arithmetic (/root/reference/cnn_cort/nets.py:64-84: rotate_90 = x[:,:,::-1,:] transposed,
+    rotate_180 = the same again, then the three stacked variants picked per sample and view), random draws injected."""
+    from cnn_cort.nets import rotate_flip_views
+    rng = np.random.RandomState(18)
+    n, half = 37, 18
+    views = [rng.rand(n, 1, 32, 32).astype(np.float32) for _ in range(3)]
+    indices = rng.choice(n, half, replace=False)
+    choices = [rng.randint(0, 3, size=half) for _ in range(3)]
+    d_views = [dev(v) for v in views]
+    keep = [v.clone() for v in d_views]
+    got = rotate_flip_views(d_views, torch.from_numpy(indices).to('cuda:0'), [torch.from_numpy(c).to('cuda:0') for c in choices])
+    for v in range(3):
+        x = views[v][indices]
+        rotate_90 = x[:, :, ::-1, :].transpose(0, 1, 3, 2)
+        rotate_180 = rotate_90[:, :, ::-1, :].transpose(0, 1, 3, 2)
+        augmented = np.stack([rotate_180, x[:, :, :, ::-1], rotate_180[:, :, :, ::-1]], axis=1)
+        want = views[v].copy()
+        want[indices] = np.stack([augmented[i, choices[v][i]] for i in range(half)])
+        assert got[v].is_cuda and np.array_equal(got[v].cpu().numpy(), want)
+        assert torch.equal(d_views[v], keep[v])                               # inputs untouched
+        assert all(c in choices[v] for c in (0, 1, 2))                        # every variant exercised

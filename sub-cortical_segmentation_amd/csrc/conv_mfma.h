@@ -344,19 +344,24 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 
     // EPI_L1: the band's input rows and the conv1 tap table, fetched now, parked in LDS behind the main buffers after the
     // staging (the main loop's barriers publish them long before the epilogue reads them)
+    constexpr int L1_NX = (C::EPI == EPI_L1) ? ((C::HOB + 2) * 32 + C::NTH - 1) / C::NTH : 1;      // gathered voxels per thread
     float4 l1x4 = {0.f, 0.f, 0.f, 0.f};
-    float l1xs = 0.f, l1tab = 0.f;
+    float l1xs[L1_NX], l1tab = 0.f;
     if constexpr (C::EPI == EPI_L1) {
         constexpr int XR = C::HOB + 2;
-        static_assert(XR * 32 <= C::NTH && 240 <= C::NTH, "one element per thread");
+        static_assert(XR * 8 <= C::NTH && 240 <= C::NTH, "one 16-byte piece / table entry per thread");
         const float* __restrict__ v = pick3(a.x0.views, tower);
         if (v) {
             if (tid < XR * 8) l1x4 = reinterpret_cast<const float4*>(v + (size_t)g0 * 1024 + band * C::HOB * 32)[tid];
-        } else if (tid < XR * 32) {
+        } else {
             const int r = a.x0.index ? a.x0.index[g0] : g0;
             const int4 smp = reinterpret_cast<const int4*>(a.x0.samples)[r];
             const scs_volume d = a.x0.descs[smp.x];
-            l1xs = gather_voxel(a.x0.vols + d.offset, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, band * C::HOB + (tid >> 5), tid & 31);
+#pragma unroll
+            for (int q = 0; q < L1_NX; ++q) {
+                const int e = min(tid + C::NTH * q, XR * 32 - 1);
+                l1xs[q] = gather_voxel(a.x0.vols + d.offset, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, band * C::HOB + (e >> 5), e & 31);
+            }
         }
         if (tid < 240) l1tab = pick3(a.bnlow, tower)[tid];
     }
@@ -566,7 +571,10 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         constexpr int XR = C::HOB + 2;
         float* s_x0 = smem + (C::MAIN_FLOATS > C::EPI_FLOATS ? C::MAIN_FLOATS : C::EPI_FLOATS);
         if (pick3(a.x0.views, tower)) { if (tid < XR * 8) reinterpret_cast<float4*>(s_x0)[tid] = l1x4; }
-        else if (tid < XR * 32) s_x0[tid] = l1xs;
+        else {
+#pragma unroll
+            for (int q = 0; q < L1_NX; ++q) { const int e = tid + C::NTH * q; if (e < XR * 32) s_x0[e] = l1xs[q]; }
+        }
         if (tid < 8) s_x0[XR * 32 + tid] = 0.f;
         if (tid < 240) s_x0[C::L1_X_FLOATS + tid] = l1tab;
     }

@@ -8,6 +8,7 @@
 // distinct banks), W rows padded to 112 (112 % 32 == 16).
 #pragma once
 #include "scs_common.h"
+#include <cstdint>
 
 namespace scs {
 
@@ -213,6 +214,87 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
     }
 }
 
+// The same latency configuration with 16-byte loads (training batches; every operand row a multiple of 4 floats and 16-byte
+// aligned): workgroup tile 16 rows x 64 columns, EIGHT waves split K in groups of 16.  Per group a lane loads ONE float4 of A
+// (row lr, k = 16 G + 4 kq + 0..3) and FOUR float4 of W (rows k = 16 G + 4 kq + i, columns n0 + 4 lr + 0..3) and issues 16
+// MFMAs: MFMA (i, j) contracts the k-slots {16 G + 4 q + i : q = 0..3} - the same four for the A and the B operand of a lane,
+// which is all the instruction asks - into the column set {n0 + 4 c + j : c = 0..15}.  A K = 540 layer is 5 groups = 25 loads
+// per lane, all in flight at once, instead of 136 four-byte loads.  Partial accumulators are added through LDS in wave order.
+struct GemmSplitK4 { static constexpr int BM = 16, BN = 64, NW = 8, GMAX = 5; };
+
+template <int GMAX_ = GemmSplitK4::GMAX>     // a template so that both translation units may instantiate it
+__global__ __launch_bounds__(512, 1) void gemm_splitk4_kernel(GemmArgs g) {
+    using T = GemmSplitK4;
+    __shared__ f32x4 s_r[T::NW * 4 * 64];
+    const int z = blockIdx.z;
+    const GemmProblem P = z == 0 ? g.p[0] : (z == 1 ? g.p[1] : g.p[2]);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * T::BM, n0 = blockIdx.y * T::BN;
+    const int kmax = g.K ? g.K : g.K4;
+    const int groups = (g.K4 + 15) / 16, per = (groups + T::NW - 1) / T::NW;
+    const int g_beg = min(groups, wave * per), g_end = min(groups, g_beg + per);
+    const int row = m0 + lr;
+    const bool row_ok = row < g.M;
+    const float* __restrict__ arow = P.A + (size_t)(row_ok ? row : 0) * P.lda + 4 * kq;
+    const int col0 = n0 + 4 * lr;
+    const bool col_ok = col0 < P.NS;                       // NS is a multiple of 4: a piece is inside or outside as a whole
+    const float* __restrict__ wcol = P.W + col0;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g0 = g_beg; g0 < g_end; g0 += T::GMAX) {
+        float4 av[T::GMAX], wv[T::GMAX][4];
+#pragma unroll
+        for (int u = 0; u < T::GMAX; ++u) {
+            const int k = 16 * (g0 + u) + 4 * kq;
+            const bool on = (g0 + u) < g_end;
+            av[u] = (on && row_ok && k < g.K4) ? *reinterpret_cast<const float4*>(arow + 16 * (g0 + u)) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                wv[u][i] = (on && col_ok && k + i < kmax) ? *reinterpret_cast<const float4*>(wcol + (size_t)(k + i) * P.NS) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < T::GMAX; ++u) {
+            const float a4[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float w4[4] = {wv[u][i].x, wv[u][i].y, wv[u][i].z, wv[u][i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], w4[j], acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_r[(wave * 4 + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wave < 4) {
+        const int j = wave;
+        f32x4 v = s_r[(0 * 4 + j) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < T::NW; ++q) { const f32x4 u = s_r[(q * 4 + j) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        const int col = n0 + 4 * lr + j;
+        if (col < g.N) {
+            const float bvv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = m0 + kq * 4 + r;
+                if (orow < g.M) gemm_store(P, g.relu, orow, col, v[r] + bvv);
+            }
+        }
+    }
+}
+
+inline bool gemm_vec4_ok(const GemmArgs& g, int nproblems) {
+    if (g.K4 % 4 != 0) return false;
+    for (int i = 0; i < nproblems; ++i) {
+        const GemmProblem& P = g.p[i];
+        if (P.lda % 4 != 0 || P.NS % 4 != 0 || (reinterpret_cast<uintptr_t>(P.A) & 15) || (reinterpret_cast<uintptr_t>(P.W) & 15)) return false;
+    }
+    return true;
+}
+
 // Weight (and bias) gradients of the dense layers, all layers in ONE launch (blockIdx.z = problem):
 //   C[m][n] = sum_k A[k][m] * W[k][n],  k < K = batch;  row m = M (when bias_out is set) = sum_k W[k][n]
 // A = the layer's input activations, row-major [batch][features] (read "transposed": the 16 lanes of an operand group
@@ -328,6 +410,9 @@ inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
     } else if (small_wgs > 256) {
         dim3 grid((g.M + Small::BM - 1) / Small::BM, (g.N + Small::BN - 1) / Small::BN, nproblems);
         hipLaunchKernelGGL((gemm_mfma_kernel<1, 3, 32>), grid, dim3(256), Small::LDS, st, g);
+    } else if (gemm_vec4_ok(g, nproblems)) {
+        dim3 grid((g.M + GemmSplitK4::BM - 1) / GemmSplitK4::BM, (g.N + GemmSplitK4::BN - 1) / GemmSplitK4::BN, nproblems);
+        hipLaunchKernelGGL(gemm_splitk4_kernel<>, grid, dim3(512), 0, st, g);
     } else {
         dim3 grid((g.M + Lat::BM - 1) / Lat::BM, (g.N + Lat::BN - 1) / Lat::BN, nproblems);
         hipLaunchKernelGGL(gemm_splitk_kernel<>, grid, dim3(256), 0, st, g);

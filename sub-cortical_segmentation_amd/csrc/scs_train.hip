@@ -97,6 +97,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
 namespace scs {
 
 static size_t al64(size_t f) { return (f + 63) / 64 * 64; }
+constexpr int kW2Floats = kFC1ld * kFC2ld;              // fc_2.W padded to [556][272] (16-byte rows for the float4 GEMM)
 
 void train_free(scs_ctx* h) {
     if (!h->tws) return;
@@ -139,7 +140,7 @@ static int train_ensure(scs_ctx* h, int n) {
         for (int t = 0; t < kTowers; ++t)
             for (int i = 1; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
-        SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540) * sizeof(float)));
+        SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540 + kW2Floats) * sizeof(float)));
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)4 * kTowers * kWgPartFloats * sizeof(float)));
         SCS_HIP(hipMalloc(&w->mom, (size_t)kTowers * 100 * sizeof(double)));
         SCS_HIP(hipMalloc(&w->counter, 64));
@@ -218,6 +219,7 @@ struct PrepArgs {
     TrProblem tr[kTrJobs];
     const float* atlas; const uint8_t* y; const int32_t* index; float* cat2; uint8_t* yb; int n;
     uint8_t* masks; size_t mask_total; uint64_t seed;       // masks == null: the caller supplied them
+    const float* fc2W; float* w2p;                           // fc_2.W [555][270] -> [556][272] zero padded
 };
 
 // blockIdx.y selects the job:
@@ -271,6 +273,10 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
             const int src = a.index ? a.index[row] : row;
             a.cat2[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? a.atlas[(size_t)src * 15 + c] : 0.f;
             if (c == 0) a.yb[row] = a.y[src];
+        }
+        for (int e = t0; e < kW2Floats; e += stride) {
+            const int k = e / kFC2ld, c = e - k * kFC2ld;
+            a.w2p[e] = (k < kFC1 + kAtlas && c < kFC2) ? a.fc2W[(size_t)k * kFC2 + c] : 0.f;
         }
     } else if (a.masks) {
         for (size_t e = t0; e < a.mask_total; e += stride) {
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(WgFinalArgs a) {
 // slices x bands x parts).  SCS_WG_SLICES="b,c,d,e" (conv2..conv5) overrides for tuning runs.
 struct WgSlices { int v[kConvs]; };
 static WgSlices wg_slices() {
-    WgSlices s{{0, 64, 128, 64, 64}};
+    WgSlices s{{0, 64, 64, 32, 32}};
     if (const char* e = getenv("SCS_WG_SLICES")) {
         int x[4];
         if (sscanf(e, "%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3]) == 4)
@@ -796,6 +802,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     float* wT2 = w->wT;                       // [270][540]  = fc_2.W[:540]^T
     float* wT1 = wT2 + 270 * 540;             // [540][540]  = FC1.W^T
     float* wTd = wT1 + 540 * 540;             // [3][180][540] = d1.W^T
+    float* w2p = wTd + 3 * 180 * 540;         // [556][272]  = fc_2.W zero padded
     {
         PrepArgs pa{};
         for (int t = 0; t < kTowers; ++t) {
@@ -806,6 +813,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.tr[0] = TrProblem{P + H.fc2W, kFC2, wT2, kFC1, kFC1, kFC2};
         pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat, kFlat, kFC1};
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
+        pa.fc2W = P + H.fc2W; pa.w2p = w2p;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
         run(ST_PREP, st, [&] { hipLaunchKernelGGL(prep_kernel, dim3(64, kPackJobs + kTrJobs + 2), dim3(256), 0, st, pa); });
     }
@@ -862,7 +870,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     g.p[0] = GemmProblem{w->featd, kFlat, P + H.fc1W, kFC1, P + H.fc1b, w->R1, kFC1, mask2, kFC1, nullptr, 0, w->cat2, kFC1ld};
     run(ST_FC1, st, [&] { gemm_launch(g, 1, st); });                    // R1 = relu(.), cat2[:, :540] = f2_drop(R1)
     g.K4 = kFC1ld; g.K = kFC1 + kAtlas; g.N = kFC2;
-    g.p[0] = GemmProblem{w->cat2, kFC1ld, P + H.fc2W, kFC2, P + H.fc2b, w->R2, kFC2ld};
+    g.p[0] = GemmProblem{w->cat2, kFC1ld, w2p, kFC2ld, P + H.fc2b, w->R2, kFC2ld};
     run(ST_FC2, st, [&] { gemm_launch(g, 1, st); });
     run(ST_HEAD, st, [&] {
         hipLaunchKernelGGL(head_train_kernel, dim3((n + kHeadRows - 1) / kHeadRows), dim3(kHeadThreads), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,

@@ -217,7 +217,8 @@ int main(int argc, char** argv) {
         run_conv<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 496, 2, 2>>("TF12 NB2 WPS2", n, rounds, c1 + c2);
         run_conv<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 120, 14, 6>>("TF12 NB14 WPS6", n, rounds, c1 + c2);
         run_conv<DG2>("DG2 NB5 WPS4 (shipped)", n, rounds, c2, true);
-        run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 256, 5, 5>>("DG2 NB5 WPS5", n, rounds, c2, true);
+        run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 384, 3, 3>>("DG2 NB3 WPS3", n, rounds, c2, true);
+        run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 384, 3, 4>>("DG2 NB3 WPS4", n, rounds, c2, true);
         run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 128, 15, 6>>("DG2 NB15 WPS6", n, rounds, c2, true);
         run_conv<DG3>("DG3 NB2 WPS4 (shipped)", n, rounds, c3, true);
         run_conv<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3>>("DG3 NB1 WPS3", n, rounds, c3, true);

@@ -1,8 +1,8 @@
 // kbench - A/B timing of conv3x3_mfma_kernel configurations in ONE process (cdna_hip_programming.md rule 24), plus
 // per-phase s_memtime stamps of diagnostic (STAMP) instantiations.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I sub-cortical_segmentation_amd/csrc tools/kbench.hip -o build/kbench
-// Ablation builds: add -DSCS_ABLATE=1 (no MFMA) / 2 (no activation reads) / 3 (no conv1) / 4 (no 4-wide epilogue) /
-// 5 (no copy-out) / 6 (conflict-free activation reads); their outputs are wrong on purpose, only the timings mean something.
+// (The round-1 ablation builds - kernels with one phase removed, wrong results on purpose - lived behind SCS_ABLATE in the
+// kernel source; that code is gone from the shipped headers, their timings are recorded in profiles/r01_kbench_final.txt.)
 // Inputs are random (rule 25); outputs are not checked here (tests/ do that through the C ABI).
 #include <cstdio>
 #include <cstdlib>

@@ -101,6 +101,13 @@ int scs_forward_volume_rows(scs_handle h, const float* vol_dev, int dim_x, int d
                             const int32_t* centers_dev, const float* atlas_rows_dev, int64_t n,
                             float* probs_dev, int32_t* labels_dev, void* stream);
 
+/* `iterations` steps of binary dilation of a uint8 0/1 volume [X][Y][Z] with the 6-neighbour cross, border value 0, in
+ * place (scratch_dev: X*Y*Z bytes).  Non-zero input voxels count as set; the result is 0/1.
+ * Replaces: scipy.ndimage.binary_dilation(mask, iterations=10) growing the registered sub-cortical mask into the ROI
+ * that test_scan classifies (base.py:369). */
+int scs_dilate_mask(scs_handle h, uint8_t* mask_dev, uint8_t* scratch_dev, int dim_x, int dim_y, int dim_z, int iterations,
+                    void* stream);
+
 /* Measurement hook (bench.py): scs_forward with HIP events recorded on `stream` around each stage of every
  * chunk; synchronises.  stage_ms[8] receives the summed elapsed milliseconds of
  *   0 conv1+conv2+pool1, 1 conv3, 2 conv4+pool2, 3 conv5, 4 d1 x3, 5 FC1 (+atlas concat), 6 fc_2, 7 out+softmax

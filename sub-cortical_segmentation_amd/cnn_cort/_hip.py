@@ -35,6 +35,7 @@ SIGNATURES = {
     'scs_forward_volume_rows': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
     'scs_forward_profiled': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _c.POINTER(_c.c_int)]),
     'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
+    'scs_dilate_mask': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp]),
     'scs_train_step': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
     'scs_train_step_volume': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
     'scs_gather_labels': (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
@@ -154,6 +155,10 @@ class Handle:
                                              _ptr(labels), stream or None, ms.ctypes.data, ctypes.byref(k)),
                'scs_forward_profiled')
         return ms, int(k.value)
+
+    def dilate_mask(self, mask_dev, scratch_dev, dims, iterations, stream=0):
+        _check(self.lib.scs_dilate_mask(self.h, _ptr(mask_dev), _ptr(scratch_dev), int(dims[0]), int(dims[1]), int(dims[2]),
+                                        int(iterations), stream or None), 'scs_dilate_mask')
 
     def get_activation(self, which, count):
         out = np.empty(count, np.float32)

@@ -293,10 +293,11 @@ def _crop_enabled(options):
     return bool(v)          # the reference tests the config STRING (base.py:367): any non-empty string crops
 
 
-def _scan_inputs(scan_name, options):
+def _scan_inputs(scan_name, options, dilate=None):
     """Everything test_scan / load_patch_batch need from disk: normalised volume, ROI centres, and the prior rows
     of those centres.  The 15-channel prior volume itself (~0.8 GB for a 256x256x192 subject) is never held:
-    nifti.load_rows streams the file once and keeps the ROI entries."""
+    nifti.load_rows streams the file once and keeps the ROI entries.  `dilate(mask, iterations)` replaces
+    scipy's binary_dilation when given (test_scan passes the net's GPU dilation)."""
     dir_name = os.path.dirname(scan_name)
     t1 = nifti.load(scan_name)
     image = t1.get_data()
@@ -308,7 +309,7 @@ def _scan_inputs(scan_name, options):
                                 '(register_masks, base.py:483-551, is out of scope here)' % atlas_name)
     if _crop_enabled(options):
         mask_atlas = nifti.load(mask_name).get_data()
-        b_mask = ndimage.binary_dilation(mask_atlas, iterations=10)
+        b_mask = dilate(mask_atlas, 10) if dilate else ndimage.binary_dilation(mask_atlas, iterations=10)
         centers = get_mask_voxels(b_mask.astype(bool))
     else:
         centers = get_mask_voxels(image.astype(bool))
@@ -379,7 +380,7 @@ def test_scan(net, test_scan, options):
     """Segment one T1 volume; writes out_subcortical_{prob,seg_prec,rawseg}.nii.gz next to it and returns the
     elapsed minutes (base.py:401-458)."""
     s_time = time.time()
-    inputs = _scan_inputs(test_scan, options)
+    inputs = _scan_inputs(test_scan, options, dilate=getattr(net, 'dilate_mask', None))
     labels, probs = _scan_predict(net, inputs, options)
     _scan_outputs(os.path.dirname(test_scan), inputs, labels, probs, options)
     return (time.time() - s_time) / 60.0

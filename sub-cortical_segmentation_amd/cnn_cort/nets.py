@@ -356,6 +356,20 @@ class Net:
         labels = d_lab.cpu().numpy().astype(np.int64)
         return labels, (d_pr.cpu().numpy() if want_probs else None)
 
+    def dilate_mask(self, mask, iterations=10):
+        """scipy.ndimage.binary_dilation(mask, iterations=iterations) (default 6-neighbour structure, border 0) on the GPU:
+        bool ndarray of mask's shape.  test_scan grows the registered sub-cortical mask into its ROI with it (base.py:369)."""
+        torch = self._torch()
+        m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        if m.ndim != 3:
+            raise ValueError('mask must be 3-D, got shape %r' % (m.shape,))
+        h = self._ensure_handle()
+        dev = 'cuda:%d' % self._dev()
+        d = torch.from_numpy(m).to(dev)
+        scratch = torch.empty_like(d)
+        h.dilate_mask(d, scratch, m.shape, iterations, torch.cuda.current_stream(self._dev()).cuda_stream)
+        return d.cpu().numpy().astype(bool)
+
     # ------------------------------------------------------------------ training
     def _uploads_ahead(self, host_slices):
         """Run `host_slices` (a generator of lists of host arrays) in a helper thread that uploads each list on its own

@@ -177,6 +177,33 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
     if (labels) labels[row] = best;
 }
 
+// one step of binary dilation with the 6-neighbour cross (scipy.ndimage.binary_dilation's default structure, border value
+// 0): out = in | its six face neighbours.  Four consecutive z voxels per thread (the volume is [X][Y][Z], z fastest).
+__global__ __launch_bounds__(256) void dilate_step_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int dx, int dy, int dz) {
+    const int zq = (dz + 3) / 4;
+    const long total = (long)dx * dy * zq;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+        const int q = (int)(e % zq);
+        const long xy = e / zq;
+        const int y = (int)(xy % dy), x = (int)(xy / dy);
+        const long row = ((long)x * dy + y) * dz;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = 4 * q + k;
+            if (z >= dz) break;
+            const long at = row + z;
+            uint8_t v = in[at];
+            if (z > 0) v |= in[at - 1];
+            if (z + 1 < dz) v |= in[at + 1];
+            if (y > 0) v |= in[at - dz];
+            if (y + 1 < dy) v |= in[at + dz];
+            if (x > 0) v |= in[at - (long)dy * dz];
+            if (x + 1 < dx) v |= in[at + (long)dy * dz];
+            out[at] = v ? 1 : 0;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- packed-weights arena
 static size_t align64(size_t f) { return (f + 63) / 64 * 64; }
 
@@ -624,6 +651,24 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
         SCS_ARG(count == n * per, "count does not match n*row size");
         SCS_HIP(hipMemcpy(host_out, single, n * per * sizeof(float), hipMemcpyDeviceToHost));
     }
+    return SCS_OK;
+}
+
+int scs_dilate_mask(scs_handle h, uint8_t* mask_dev, uint8_t* scratch_dev, int dx, int dy, int dz, int iterations, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(mask_dev && scratch_dev, "null pointer");
+    SCS_ARG(dx > 0 && dy > 0 && dz > 0 && iterations >= 0, "bad dims or iteration count");
+    SCS_HIP(hipSetDevice(h->device));
+    const long total = (long)dx * dy * ((dz + 3) / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16);
+    uint8_t *a = mask_dev, *b = scratch_dev;
+    for (int i = 0; i < iterations; ++i) {
+        hipLaunchKernelGGL(dilate_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, dx, dy, dz);
+        uint8_t* t = a; a = b; b = t;
+    }
+    if (a != mask_dev)            // odd iteration count: the result sits in the scratch buffer
+        SCS_HIP(hipMemcpyAsync(mask_dev, a, (size_t)dx * dy * dz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    SCS_HIP(hipGetLastError());
     return SCS_OK;
 }
 

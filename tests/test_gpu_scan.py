@@ -104,3 +104,19 @@ def test_volume_rows_equals_volume_4d(weights):
         net.predict_volume(vol, centers, want_probs=True)
     with pytest.raises(ValueError):
         net.predict_volume(vol, centers, atlas_rows=np.zeros((3, 15), np.float32))
+
+
+@pytest.mark.parametrize('shape,iters', [((23, 17, 31), 1), ((40, 44, 36), 10), ((9, 64, 5), 3), ((33, 20, 18), 0)])
+def test_gpu_dilation_equals_scipy(shape, iters):
+    """Net.dilate_mask == scipy.ndimage.binary_dilation(mask, iterations) bit for bit (6-neighbour cross, border 0), on
+    masks that touch the volume faces and on non-cubic, non-multiple-of-4 shapes (base.py:369)."""
+    from scipy import ndimage
+    from cnn_cort.nets import Net
+    rng = np.random.RandomState(sum(shape) + iters)
+    mask = rng.rand(*shape) < 0.01
+    mask[0, 0, 0] = mask[-1, -1, -1] = True
+    mask[shape[0] // 2, 0, shape[2] - 1] = True
+    net = Net(device=0)
+    got = net.dilate_mask(mask.astype(np.float32) * 3.0, iters)          # any non-zero value counts as set (the mask file is float)
+    want = ndimage.binary_dilation(mask, iterations=iters) if iters else mask
+    assert got.dtype == bool and got.shape == mask.shape and np.array_equal(got, want)

@@ -37,9 +37,9 @@ SIGNATURES = {
     'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
     'scs_dilate_mask': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp]),
     'scs_train_step': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
-    'scs_train_step_volume': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
-    'scs_gather_labels': (_c.c_int, [_vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
-    'scs_eval_batch_volume': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.POINTER(_c.c_double),
+    'scs_train_step_volume': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
+    'scs_gather_labels': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp]),
+    'scs_eval_batch_volume': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp, _vp, _c.c_int64, _c.POINTER(_c.c_double),
                                          _c.POINTER(_c.c_int64), _vp]),
     'scs_train_stage_count': (_c.c_int, []),
     'scs_train_stage_name': (_c.c_char_p, [_c.c_int]),
@@ -178,20 +178,21 @@ class Handle:
         """Gather-fused step: patches are cut inside the kernels from `vols` (concatenated volumes on the device) around
         the voxels of `samples[index]` (include/scs.h: scs_train_step_volume)."""
         loss = ctypes.c_float(0.0)
-        _check(self.lib.scs_train_step_volume(self.h, _ptr(vols), _ptr(descs), _ptr(samples), _ptr(atlas_rows), _ptr(y), _ptr(index),
-                                              int(n), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
+        _check(self.lib.scs_train_step_volume(self.h, _ptr(vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(samples.shape[0]),
+                                              _ptr(atlas_rows), _ptr(y), _ptr(index), int(n), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
                                               ctypes.addressof(loss) if want_loss else None, stream or None),
                'scs_train_step_volume')
         return float(loss.value) if want_loss else None
 
     def gather_labels(self, label_vols, descs, samples, n, y_out, stream=0):
-        _check(self.lib.scs_gather_labels(self.h, _ptr(label_vols), _ptr(descs), _ptr(samples), int(n), _ptr(y_out), stream or None),
+        _check(self.lib.scs_gather_labels(self.h, _ptr(label_vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(n), _ptr(y_out),
+                                          stream or None),
                'scs_gather_labels')
 
     def eval_batch_volume(self, vols, descs, samples, atlas_rows, y, index, n, stream=0):
         ls, nc = ctypes.c_double(0.0), ctypes.c_int64(0)
-        _check(self.lib.scs_eval_batch_volume(self.h, _ptr(vols), _ptr(descs), _ptr(samples), _ptr(atlas_rows), _ptr(y), _ptr(index),
-                                              int(n), ctypes.byref(ls), ctypes.byref(nc), stream or None), 'scs_eval_batch_volume')
+        _check(self.lib.scs_eval_batch_volume(self.h, _ptr(vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(samples.shape[0]),
+                                              _ptr(atlas_rows), _ptr(y), _ptr(index), int(n), ctypes.byref(ls), ctypes.byref(nc), stream or None), 'scs_eval_batch_volume')
         return float(ls.value), int(nc.value)
 
     def train_step_profiled(self, ax, co, sa, atlas, y, n, seed=0, stream=0):

@@ -122,7 +122,18 @@ struct X0Src {
     const scs_volume* descs;      // per volume: offset into vols, dims
     const int32_t* samples;       // [N][4]: volume, x, y, z
     const int32_t* index;         // [n] rows of `samples` that form this batch (null: rows 0..n-1)
+    int n_samples, n_vols;        // bounds: a row / volume number outside them is clamped, never dereferenced
 };
+
+// sample row of patch g: (volume, x, y, z), row and volume numbers clamped into the tables (voxels outside a volume read as
+// zero padding in gather_voxel; nothing a caller passes can make the kernels leave their buffers)
+__device__ __forceinline__ int4 x0_sample(const X0Src& s, int g) {
+    int r = s.index ? s.index[g] : g;
+    r = max(0, min(r, s.n_samples - 1));
+    int4 smp = reinterpret_cast<const int4*>(s.samples)[r];
+    smp.x = max(0, min(smp.x, s.n_vols - 1));
+    return smp;
+}
 
 struct ConvArgs {
     const float* in[kTowers];     // SRC_NCHW*: [n][CIN][HSRC][HSRC]; SRC_CONV1: [n][32][32]; SRC_VOLUME: the volume;
@@ -284,8 +295,7 @@ __device__ __forceinline__ void load_x0_rows(const X0Src& s, int tower, int g, i
             if (e < NROWS * 8) reinterpret_cast<float4*>(s_x)[e] = src[e];
         }
     } else {
-        const int r = s.index ? s.index[g] : g;
-        const int4 smp = reinterpret_cast<const int4*>(s.samples)[r];
+        const int4 smp = x0_sample(s, g);
         const scs_volume d = s.descs[smp.x];
         const float* __restrict__ vol = s.vols + d.offset;
 #pragma unroll
@@ -354,8 +364,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         if (v) {
             if (tid < XR * 8) l1x4 = reinterpret_cast<const float4*>(v + (size_t)g0 * 1024 + band * C::HOB * 32)[tid];
         } else {
-            const int r = a.x0.index ? a.x0.index[g0] : g0;
-            const int4 smp = reinterpret_cast<const int4*>(a.x0.samples)[r];
+            const int4 smp = x0_sample(a.x0, g0);
             const scs_volume d = a.x0.descs[smp.x];
 #pragma unroll
             for (int q = 0; q < L1_NX; ++q) {

@@ -97,11 +97,11 @@ __global__ void pack_dense_kernel(const float* __restrict__ W, const float* __re
 
 // ----------------------------------------------------------------------------- small kernels of the head
 // atlas -> columns 540..554 of the FC1 output rows (ConcatLayer elem_channels2, nets.py:224); column 555 = 0
-__global__ void atlas_concat_kernel(const float* __restrict__ atlas, const int32_t* __restrict__ index, float* __restrict__ fc1, int n) {
+__global__ void atlas_concat_kernel(const float* __restrict__ atlas, const int32_t* __restrict__ index, int n_rows, float* __restrict__ fc1, int n) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * 16) return;
     const int row = e >> 4, c = e & 15;
-    const int src = index ? index[row] : row;
+    const int src = index ? max(0, min(index[row], n_rows - 1)) : row;
     fc1[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? atlas[(size_t)src * 15 + c] : 0.f;
 }
 
@@ -337,7 +337,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     if (vol && atlas4d)
         hipLaunchKernelGGL(atlas_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->a_fc1, n);
     else
-        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, atlas_index, h->a_fc1, n);
+        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, atlas_index, x0 ? x0->n_samples : n, h->a_fc1, n);
     mark(6);
     // fc_2
     g.K4 = kFC1ld; g.N = kFC2;

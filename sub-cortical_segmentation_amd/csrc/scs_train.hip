@@ -217,7 +217,7 @@ constexpr int kPackJobs = kTowers * (kConvs - 1), kTrJobs = 5;
 struct PrepArgs {
     PackJob pack[kPackJobs];
     TrProblem tr[kTrJobs];
-    const float* atlas; const uint8_t* y; const int32_t* index; float* cat2; uint8_t* yb; int n;
+    const float* atlas; const uint8_t* y; const int32_t* index; float* cat2; uint8_t* yb; int n, n_rows;   // n_rows: rows atlas / y hold
     uint8_t* masks; size_t mask_total; uint64_t seed;       // masks == null: the caller supplied them
     const float* fc2W; float* w2p;                           // fc_2.W [555][270] -> [556][272] zero padded
 };
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
     } else if (job == kPackJobs + kTrJobs) {
         for (int e = t0; e < a.n * 16; e += stride) {
             const int row = e >> 4, c = e & 15;
-            const int src = a.index ? a.index[row] : row;
+            const int src = max(0, min(a.index ? a.index[row] : row, a.n_rows - 1));
             a.cat2[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? a.atlas[(size_t)src * 15 + c] : 0.f;
             if (c == 0) a.yb[row] = a.y[src];
         }
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__
 // (scs_eval_batch adds them in a fixed order)
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ R2, const float* __restrict__ W,
                                                         const float* __restrict__ b, const uint8_t* __restrict__ y, const int32_t* __restrict__ index,
-                                                        int n, float* __restrict__ rows /*[n][2]*/) {
+                                                        int n_rows, int n, float* __restrict__ rows /*[n][2]*/) {
     __shared__ float s_w[kFC2 * 15 + 16];
     for (int e = threadIdx.x; e < kFC2 * 15; e += blockDim.x) s_w[e] = W[e];
     if (threadIdx.x < 15) s_w[kFC2 * 15 + threadIdx.x] = b[threadIdx.x];
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 15; ++c) s += expf(z[c] - mx);
-    const int yi = y[index ? index[row] : row];
+    const int yi = y[index ? max(0, min(index[row], n_rows - 1)) : row];
     int best = 0; float bz = z[0], zy = 0.f;
 #pragma unroll
     for (int c = 0; c < 15; ++c) {
@@ -813,6 +813,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.tr[0] = TrProblem{P + H.fc2W, kFC2, wT2, kFC1, kFC1, kFC2};
         pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat, kFlat, kFC1};
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
+        pa.n_rows = index ? x0.n_samples : n;
         pa.fc2W = P + H.fc2W; pa.w2p = w2p;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
         run(ST_PREP, st, [&] { hipLaunchKernelGGL(prep_kernel, dim3(64, kPackJobs + kTrJobs + 2), dim3(256), 0, st, pa); });
@@ -991,11 +992,11 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     return SCS_OK;
 }
 
-__global__ void gather_labels_kernel(const uint8_t* __restrict__ lab, const scs_volume* __restrict__ descs, const int32_t* __restrict__ samples,
-                                     long n, uint8_t* __restrict__ y) {
+__global__ void gather_labels_kernel(const uint8_t* __restrict__ lab, const scs_volume* __restrict__ descs, int n_vols,
+                                     const int32_t* __restrict__ samples, long n, uint8_t* __restrict__ y) {
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int4 s = reinterpret_cast<const int4*>(samples)[e];
-        const scs_volume d = descs[s.x];
+        const scs_volume d = descs[max(0, min(s.x, n_vols - 1))];
         const bool ok = (unsigned)s.y < (unsigned)d.dim_x && (unsigned)s.z < (unsigned)d.dim_y && (unsigned)s.w < (unsigned)d.dim_z;
         const uint8_t v = ok ? lab[d.offset + ((size_t)s.y * d.dim_y + s.z) * d.dim_z + s.w] : 0;
         y[e] = v == 15 ? 0 : v;                                      // boundary negatives -> background (base.py:88-89)
@@ -1031,27 +1032,29 @@ int scs_train_step_profiled(scs_handle h, const float* ax, const float* co, cons
     return train_step_impl(h, x0, atlas, y, nullptr, (int)n64, dropout_seed, nullptr, nullptr, (hipStream_t)stream, stage_ms);
 }
 
-int scs_train_step_volume(scs_handle h, const float* vols, const scs_volume* descs, const int32_t* samples, const float* atlas_rows,
-                          const uint8_t* y, const int32_t* index, int64_t n64, uint64_t dropout_seed, const uint8_t* masks_dev,
-                          float* loss_host, void* stream) {
+int scs_train_step_volume(scs_handle h, const float* vols, const scs_volume* descs, int32_t n_vols, const int32_t* samples,
+                          int64_t n_samples, const float* atlas_rows, const uint8_t* y, const int32_t* index, int64_t n64,
+                          uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
     SCS_ARG(n64 > 0 && n64 <= (1 << 20), "n out of range");
     SCS_ARG(vols && descs && samples && atlas_rows && y, "null input pointer");
+    SCS_ARG(n_vols > 0 && n_samples > 0 && n_samples <= 0x7fffffff, "empty volume / sample table");
+    SCS_ARG(index || n64 <= n_samples, "more samples asked for than the table holds");
     X0Src x0{};
-    x0.vols = vols; x0.descs = descs; x0.samples = samples; x0.index = index;
+    x0.vols = vols; x0.descs = descs; x0.samples = samples; x0.index = index; x0.n_samples = (int)n_samples; x0.n_vols = n_vols;
     return train_step_impl(h, x0, atlas_rows, y, index, (int)n64, dropout_seed, masks_dev, loss_host, (hipStream_t)stream, nullptr);
 }
 
-int scs_gather_labels(scs_handle h, const uint8_t* label_vols, const scs_volume* descs, const int32_t* samples, int64_t n,
-                      uint8_t* y, void* stream) {
+int scs_gather_labels(scs_handle h, const uint8_t* label_vols, const scs_volume* descs, int32_t n_vols, const int32_t* samples,
+                      int64_t n, uint8_t* y, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
-    SCS_ARG(n >= 0, "n < 0");
+    SCS_ARG(n >= 0 && n_vols > 0, "n < 0 or no volumes");
     if (n == 0) return SCS_OK;
     SCS_ARG(label_vols && descs && samples && y, "null pointer");
     SCS_HIP(hipSetDevice(h->device));
     const long blocks = (n + 255) / 256;
     hipLaunchKernelGGL(gather_labels_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, label_vols,
-                       descs, samples, (long)n, y);
+                       descs, n_vols, samples, (long)n, y);
     SCS_HIP(hipGetLastError());
     return SCS_OK;
 }
@@ -1126,7 +1129,7 @@ static int eval_impl(scs_handle h, const float* ax, const float* co, const float
         const int m = (int)((n - s < estep) ? (n - s) : estep);
         if (x0) {
             X0Src xs = *x0;                                     // this chunk's rows: index + s, or samples s.. when there is no index
-            if (index) xs.index = index + s; else xs.samples += 4 * s;
+            if (index) xs.index = index + s; else { xs.samples += 4 * s; xs.n_samples -= (int)s; }
             rc = forward_chunk(h, nullptr, nullptr, nullptr, index ? atlas : atlas + s * 15, nullptr, 0, 0, 0, nullptr, nullptr, m, nullptr,
                                nullptr, st, nullptr, &xs, index ? index + s : nullptr);
         } else {
@@ -1136,7 +1139,7 @@ static int eval_impl(scs_handle h, const float* ax, const float* co, const float
         if (rc != SCS_OK) return rc;
         // loss / hit per row from the fc_2 activations of this chunk, then one ordered sum
         hipLaunchKernelGGL(softmax_ce_kernel, dim3((m + 255) / 256), dim3(256), 0, st, h->a_fc2, h->params + H.outW, h->params + H.outb,
-                           index ? y : y + s, index ? index + s : (const int32_t*)nullptr, m, w->eval_rows);
+                           index ? y : y + s, index ? index + s : (const int32_t*)nullptr, x0 ? x0->n_samples : 0, m, w->eval_rows);
         hipLaunchKernelGGL(eval_sum_kernel, dim3(1), dim3(256), 0, st, w->eval_rows, m, w->eval_acc);
     }
     double acc[2];
@@ -1156,14 +1159,17 @@ int scs_eval_batch(scs_handle h, const float* ax, const float* co, const float* 
     return eval_impl(h, ax, co, sa, nullptr, atlas, y, nullptr, n, loss_sum_host, n_correct_host, stream);
 }
 
-int scs_eval_batch_volume(scs_handle h, const float* vols, const scs_volume* descs, const int32_t* samples, const float* atlas_rows,
-                          const uint8_t* y, const int32_t* index, int64_t n, double* loss_sum_host, int64_t* n_correct_host, void* stream) {
+int scs_eval_batch_volume(scs_handle h, const float* vols, const scs_volume* descs, int32_t n_vols, const int32_t* samples,
+                          int64_t n_samples, const float* atlas_rows, const uint8_t* y, const int32_t* index, int64_t n,
+                          double* loss_sum_host, int64_t* n_correct_host, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
     SCS_ARG(n >= 0, "n < 0");
     SCS_ARG(loss_sum_host && n_correct_host, "null output pointer");
     SCS_ARG(n == 0 || (vols && descs && samples && atlas_rows && y), "null input pointer");
+    SCS_ARG(n == 0 || (n_vols > 0 && n_samples > 0 && n_samples <= 0x7fffffff), "empty volume / sample table");
+    SCS_ARG(index || n <= n_samples, "more samples asked for than the table holds");
     X0Src x0{};
-    x0.vols = vols; x0.descs = descs; x0.samples = samples; x0.index = index;
+    x0.vols = vols; x0.descs = descs; x0.samples = samples; x0.index = index; x0.n_samples = (int)n_samples; x0.n_vols = n_vols;
     return eval_impl(h, nullptr, nullptr, nullptr, &x0, atlas_rows, y, index, n, loss_sum_host, n_correct_host, stream);
 }
 

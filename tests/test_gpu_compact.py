@@ -142,3 +142,31 @@ def test_fit_compact_streamed_and_resident_agree(toy, weights):
         cnt += len(idx)
     h.close()
     assert abs(hist['resident'][0][0] - tot / cnt) <= 1e-6 * abs(tot / cnt)
+
+
+def test_out_of_range_rows_and_volume_numbers_are_clamped(toy, weights):
+    """Nothing a caller passes can make the gather kernels leave their buffers: index entries beyond the sample table and
+    volume numbers beyond the volume table are clamped on the device (voxels outside a volume already read as zero padding)."""
+    _, _, cs = toy
+    d = device_form(cs)
+    n, N = 16, cs.samples.shape[0]
+    bad_index = torch.tensor([N + 5, -3, 2 ** 30, 0] * 4, dtype=torch.int32, device='cuda:0')
+    clamped = torch.tensor([N - 1, 0, N - 1, 0] * 4, dtype=torch.int32, device='cuda:0')
+    smp = cs.samples.copy()
+    smp[:, 0] = np.where(np.arange(N) % 2 == 0, smp[:, 0], smp[:, 0] + 2)          # volume 2, 3: beyond the table of 2
+    smp[5, 1:] = [10 ** 6, -7, 3]                                                   # a voxel far outside its volume
+    ref = cs.samples.copy()
+    ref[:, 0] = np.minimum(smp[:, 0], 1)
+    ref[5, 1:] = smp[5, 1:]
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    for samples, index in ((smp, bad_index), (ref, clamped)):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        t = torch.from_numpy(np.ascontiguousarray(samples)).to('cuda:0')
+        loss = h.train_step_volume(d['vols'], d['desc'], t, d['atlas'], d['y'], index, n, seed=3, stream=st)
+        ev = h.eval_batch_volume(d['vols'], d['desc'], t, d['atlas'], d['y'], index, n, stream=st)
+        out.append((loss, arena(h, 'grad'), ev))
+        h.close()
+    assert np.isfinite(out[0][0]) and np.isfinite(out[0][1]).all()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]

@@ -306,6 +306,18 @@ __device__ __forceinline__ double block_sum(double v, double* s_red) {
     return r;
 }
 
+// three block sums with ONE exchange through LDS (fixed order: lanes by shuffle, then waves 0..3)
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double (*s_red)[3]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); c += __shfl_down(c, o); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_red[wv][0] = a; s_red[wv][1] = b; s_red[wv][2] = c; }
+    __syncthreads();
+    a = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+    b = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+    c = (s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2]);
+}
+
 // Second moments of the 32x32 inputs over the 30x30 conv1 output grid: with P[px][k] = x0[px + tap k] (k < 9) and
 // P[px][9] = 1, D = P'P holds R[k][k'] = sum_px x0[px+k] x0[px+k'], S[k] = D[k][9] and the pixel count D[9][9].  One
 // matrix product per patch (both MFMA operands are the same register), `ppb` patches per workgroup, the four waves split
@@ -418,27 +430,28 @@ template <bool APPLY5>
 __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const float* __restrict__ part, int units, double count, int C, float* params,
                                                           int bn_off0, int tower_stride, Ptr3 ss, Ptr3 low4, CPtr3 Z, Ptr3 H5,
                                                           const uint8_t* __restrict__ mask, int n) {
-    __shared__ double s_red[4];
+    __shared__ double s_red[4][3];
     __shared__ float s_ss[2];
     const int c = blockIdx.x, t = blockIdx.y;
     const float2* __restrict__ p = reinterpret_cast<const float2*>(part) + (size_t)t * units * C + c;
-    double s = 0, q = 0;
-    for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; s += v.x; q += v.y; }
-    s = block_sum(s, s_red);
-    q = block_sum(q, s_red);
-    const double mean = s / units;
-    double dev2 = 0;
-    for (int u = threadIdx.x; u < units; u += 256) { const double d = (double)p[(size_t)u * C].x - mean; dev2 += d * d; }
-    dev2 = block_sum(dev2, s_red);
+    float* bn = params + bn_off0 + t * tower_stride;               // beta, gamma, mean, inv_std
+    float b_beta = 0.f, b_gamma = 0.f, b_mean = 0.f, b_inv = 0.f;
+    if (threadIdx.x == 0) { b_beta = bn[c]; b_gamma = bn[C + c]; b_mean = bn[2 * C + c]; b_inv = bn[3 * C + c]; }   // in flight with the partials
+    // one pass: sum of unit means, of their squares (about the first unit's mean: exact in double) and of the unit M2
+    const double m0 = (double)p[0].x;
+    double s = 0, s2 = 0, q = 0;
+    for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; const double d = (double)v.x - m0; s += d; s2 += d * d; q += v.y; }
+    block_sum3(s, s2, q, s_red);
     if (threadIdx.x == 0) {
-        float* bn = params + bn_off0 + t * tower_stride;           // beta, gamma, mean, inv_std
+        const double dm = s / units, mean = m0 + dm;
+        const double dev2 = fmax(s2 - s * dm, 0.0);                // sum (mean_u - mean)^2
         const double var = (q + (count / units) * dev2) / count;
         const double inv = 1.0 / sqrt(var + (double)kBnEps);
-        const float sc = bn[C + c] * (float)inv, sh = bn[c] - (float)mean * sc;
+        const float sc = b_gamma * (float)inv, sh = b_beta - (float)mean * sc;
         reinterpret_cast<float2*>(sel3(ss.p, t))[c] = make_float2(sc, sh);
         reinterpret_cast<float4*>(sel3(low4.p, t))[c] = make_float4(sc, sh, (float)mean, (float)inv);
-        bn[2 * C + c] = (1.f - kBnAlpha) * bn[2 * C + c] + kBnAlpha * (float)mean;
-        bn[3 * C + c] = (1.f - kBnAlpha) * bn[3 * C + c] + kBnAlpha * (float)inv;
+        bn[2 * C + c] = (1.f - kBnAlpha) * b_mean + kBnAlpha * (float)mean;
+        bn[3 * C + c] = (1.f - kBnAlpha) * b_inv + kBnAlpha * (float)inv;
         s_ss[0] = sc; s_ss[1] = sh;
     }
     if constexpr (APPLY5) {
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const float* __restri
 template <bool DIRECT5>
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ part, int units, double count, int C, CPtr3 low4, Ptr3 cf4,
                                                           float* grads, int bn_off0, int tower_stride, CPtr3 Z, CPtr3 dUp, int n) {
-    __shared__ double s_red[4];
+    __shared__ double s_red[4][3];
     const int c = blockIdx.x, t = blockIdx.y;
     const float4 lo = reinterpret_cast<const float4*>(sel3(low4.p, t))[c];      // sc, sh, mean, inv
     double sb = 0, sg = 0;
@@ -491,8 +504,8 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
         const float2* __restrict__ p = reinterpret_cast<const float2*>(part) + (size_t)t * units * C + c;
         for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; sb += v.x; sg += v.y; }
     }
-    sb = block_sum(sb, s_red);
-    sg = block_sum(sg, s_red);
+    double unused = 0;
+    block_sum3(sb, sg, unused, s_red);
     if (threadIdx.x == 0) {
         float* gb = grads + bn_off0 + t * tower_stride;
         gb[c] = (float)sb; gb[C + c] = (float)sg;                                   // mean / inv_std entries stay 0

@@ -92,6 +92,16 @@ def _ptr(x):
     return x.data_ptr()
 
 
+def _need(x, count, what):
+    """A buffer handed to the library must hold at least `count` elements: the kernels trust their sizes, and a short buffer
+    is a GPU memory fault (which can take the whole node down), not an exception."""
+    if x is None:
+        return
+    have = x.size if isinstance(x, np.ndarray) else x.numel()
+    if have < count:
+        raise ValueError('%s holds %d elements, the call needs %d' % (what, have, count))
+
+
 class Handle:
     """Owns one scs_handle on one device."""
 
@@ -129,11 +139,21 @@ class Handle:
         return self.lib.scs_set_chunk(self.h, int(n))
 
     # ---- inference
+    def _check_inputs(self, ax, co, sa, atlas, n, y=None, probs=None, labels=None):
+        for name, x in (('axial view', ax), ('coronal view', co), ('sagittal view', sa)):
+            _need(x, 1024 * n, name)
+        _need(atlas, 15 * n, 'atlas rows')
+        _need(y, n, 'labels')
+        _need(probs, 15 * n, 'probs')
+        _need(labels, n, 'labels out')
+
     def forward(self, ax, co, sa, atlas, n, probs=None, labels=None, stream=0):
+        self._check_inputs(ax, co, sa, atlas, n, probs=probs, labels=labels)
         _check(self.lib.scs_forward(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), int(n), _ptr(probs),
                                     _ptr(labels), stream or None), 'scs_forward')
 
     def forward_host(self, ax, co, sa, atlas, n, probs=None, labels=None):
+        self._check_inputs(ax, co, sa, atlas, n, probs=probs, labels=labels)
         _check(self.lib.scs_forward_host(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), int(n), _ptr(probs),
                                          _ptr(labels)), 'scs_forward_host')
 
@@ -167,6 +187,8 @@ class Handle:
 
     # ---- training
     def train_step(self, ax, co, sa, atlas, y, n, seed=0, masks=None, want_loss=True, stream=0):
+        self._check_inputs(ax, co, sa, atlas, n, y=y)
+        _need(masks, 5 * 540 * n, 'dropout masks')
         loss = ctypes.c_float(0.0)
         _check(self.lib.scs_train_step(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), _ptr(y), int(n),
                                        ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
@@ -177,6 +199,10 @@ class Handle:
     def train_step_volume(self, vols, descs, samples, atlas_rows, y, index, n, seed=0, masks=None, want_loss=True, stream=0):
         """Gather-fused step: patches are cut inside the kernels from `vols` (concatenated volumes on the device) around
         the voxels of `samples[index]` (include/scs.h: scs_train_step_volume)."""
+        _need(index, n, 'batch index')
+        _need(atlas_rows, 15 * samples.shape[0], 'atlas rows')
+        _need(y, samples.shape[0], 'labels')
+        _need(masks, 5 * 540 * n, 'dropout masks')
         loss = ctypes.c_float(0.0)
         _check(self.lib.scs_train_step_volume(self.h, _ptr(vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(samples.shape[0]),
                                               _ptr(atlas_rows), _ptr(y), _ptr(index), int(n), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
@@ -190,6 +216,9 @@ class Handle:
                'scs_gather_labels')
 
     def eval_batch_volume(self, vols, descs, samples, atlas_rows, y, index, n, stream=0):
+        _need(index, n, 'batch index')
+        _need(atlas_rows, 15 * samples.shape[0], 'atlas rows')
+        _need(y, samples.shape[0], 'labels')
         ls, nc = ctypes.c_double(0.0), ctypes.c_int64(0)
         _check(self.lib.scs_eval_batch_volume(self.h, _ptr(vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(samples.shape[0]),
                                               _ptr(atlas_rows), _ptr(y), _ptr(index), int(n), ctypes.byref(ls), ctypes.byref(nc), stream or None), 'scs_eval_batch_volume')
@@ -197,6 +226,7 @@ class Handle:
 
     def train_step_profiled(self, ax, co, sa, atlas, y, n, seed=0, stream=0):
         """-> {stage name: ms}: one training step with HIP events around every launch (scs_train_step_profiled)."""
+        self._check_inputs(ax, co, sa, atlas, n, y=y)
         k = self.lib.scs_train_stage_count()
         ms = np.zeros(k, np.float32)
         _check(self.lib.scs_train_step_profiled(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), _ptr(y), int(n),
@@ -219,6 +249,7 @@ class Handle:
         _check(self.lib.scs_adam_apply(self.h, lr, b1, b2, eps, grad_scale, stream or None), 'scs_adam_apply')
 
     def eval_batch(self, ax, co, sa, atlas, y, n, stream=0):
+        self._check_inputs(ax, co, sa, atlas, n, y=y)
         ls, nc = ctypes.c_double(0.0), ctypes.c_int64(0)
         _check(self.lib.scs_eval_batch(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), _ptr(y), int(n),
                                        ctypes.byref(ls), ctypes.byref(nc), stream or None), 'scs_eval_batch')

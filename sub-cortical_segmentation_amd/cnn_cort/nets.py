@@ -371,10 +371,13 @@ class Net:
         return d.cpu().numpy().astype(bool)
 
     # ------------------------------------------------------------------ training
-    def _uploads_ahead(self, host_slices):
-        """Run `host_slices` (a generator of lists of host arrays) in a helper thread that uploads each list on its own
-        stream, one slice ahead of the consumer: the transfer of slice i+1 runs under the kernels of slice i.  Yields
-        lists of device tensors that the consumer's current stream may use."""
+    def _uploads_ahead(self, n_slices, fill):
+        """Slices of host data to the device, one slice ahead of the consumer: a helper thread calls `fill(i, alloc)` for
+        slice i - which gathers its rows straight into page-locked staging arrays obtained from `alloc(key, shape, dtype)`
+        (two rotating sets, grown on demand) and returns the keys in consumer order - and copies them to fresh device
+        tensors on its own stream, so that gather
+        and transfer of slice i+1 run under the kernels of slice i.  Yields lists of device tensors that the consumer's
+        current stream may use."""
         import queue
         import threading
         torch = self._torch()
@@ -382,14 +385,35 @@ class Net:
         main = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
         q = queue.Queue(maxsize=1)                 # one slice in flight + one being consumed = two resident slices
+        slots = [{'bufs': {}, 'free': None} for _ in range(2)]
 
         def uploader():
             try:
                 with torch.cuda.stream(side):
-                    for arrs in host_slices:
-                        ts = [torch.from_numpy(a).to('cuda:%d' % dev, non_blocking=False) for a in arrs]
+                    for i in range(n_slices):
+                        slot = slots[i % 2]
+                        if slot['free'] is not None:
+                            slot['free'].synchronize()       # the copy that last read this staging set has finished
+                        used = {}
+
+                        def alloc(k, shape, dtype):
+                            need = int(np.prod(shape))
+                            buf = slot['bufs'].get(k)
+                            if buf is None or buf.numel() < need or buf.dtype != dtype:
+                                buf = torch.empty((need,), dtype=dtype).pin_memory()
+                                slot['bufs'][k] = buf
+                            view = buf[:need].view(*shape)
+                            used[k] = view
+                            return view.numpy()
+
+                        order = fill(i, alloc)               # the keys in the order the consumer expects (the gathers
+                        views = [used[k] for k in order]     # themselves may have run in any order, in parallel)
+                        ts = [torch.empty(v.shape, dtype=v.dtype, device='cuda:%d' % dev) for v in views]
+                        for t, v in zip(ts, views):
+                            t.copy_(v, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(side)
+                        slot['free'] = ev
                         q.put((ts, ev))
                 q.put(None)
             except BaseException as e:            # surfaced in the consumer
@@ -495,9 +519,32 @@ class Net:
             resident = on_device or (ntr + nva) * per_sample <= self.fit_resident_bytes
             sl = max(bs, (self.fit_slice // bs) * bs)              # slice = whole mini-batches
 
-            def host_rows(idx):
-                return [np.ascontiguousarray(X[k][idx] if isinstance(X[k], np.ndarray) else X[k][torch.as_tensor(idx)].cpu().numpy(),
-                                             dtype=np.float32) for k in keys] + [np.ascontiguousarray(y_all[idx], dtype=np.uint8)]
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=4)           # the four row gathers of a slice run side by side (np.take drops the GIL)
+            dts = {'in1': torch.float32, 'in2': torch.float32, 'in3': torch.float32, 'in4': torch.float32}
+
+            def host_rows(idx, alloc=None):
+                """Rows `idx` of the four inputs and the labels; into page-locked staging arrays when `alloc` is given."""
+                def rows(k):
+                    a = X[k]
+                    if not isinstance(a, np.ndarray):
+                        a = a[torch.as_tensor(idx)].cpu().numpy()
+                        idx_k = None
+                    else:
+                        idx_k = idx
+                    shape = (len(idx),) + tuple(a.shape[1:])
+                    out = alloc(k, shape, dts[k]) if alloc else np.empty(shape, np.float32)
+                    if idx_k is None:
+                        out[...] = a
+                    elif a.dtype == np.float32:
+                        np.take(a, idx_k, axis=0, out=out)
+                    else:
+                        out[...] = np.take(a, idx_k, axis=0)
+                    return out
+                arrs = list(pool.map(rows, keys))
+                yo = alloc('y', (len(idx),), torch.uint8) if alloc else np.empty((len(idx),), np.uint8)
+                yo[...] = y_all[idx]
+                return list(keys) + ['y'] if alloc else arrs + [yo]
 
             my_rows = np.concatenate([tr_idx[lo:min(ntr, lo + bs)] for lo in my_starts]) if my_starts else np.arange(0)
             my_sizes = [min(ntr, lo + bs) - lo for lo in my_starts]
@@ -518,8 +565,8 @@ class Net:
                 per_slice = max(1, sl // bs)                        # my mini-batches per slice
                 groups = [my_sizes[i:i + per_slice] for i in range(0, len(my_sizes), per_slice)]
                 bounds = np.concatenate([[0], np.cumsum([sum(g) for g in groups])]).astype(np.int64)
-                gen = (host_rows(my_rows[bounds[i]:bounds[i + 1]]) for i in range(len(groups)))
-                for ts, g in zip(self._uploads_ahead(gen), groups):
+                fill = lambda i, alloc: host_rows(my_rows[bounds[i]:bounds[i + 1]], alloc)
+                for ts, g in zip(self._uploads_ahead(len(groups), fill), groups):
                     yield ts, g
 
             def train_batches():
@@ -536,8 +583,8 @@ class Net:
                     return h.eval_batch(r_va[0], r_va[1], r_va[2], r_va[3], r_va[4], va_hi - va_lo, stream=stream)
                 ls, nc = 0.0, 0
                 mine = va_idx[va_lo:va_hi]
-                gen = (host_rows(mine[lo:lo + sl]) for lo in range(0, len(mine), sl))
-                for ts in self._uploads_ahead(gen):
+                los = list(range(0, len(mine), sl))
+                for ts in self._uploads_ahead(len(los), lambda i, alloc: host_rows(mine[los[i]:los[i] + sl], alloc)):
                     a, b = h.eval_batch(ts[0], ts[1], ts[2], ts[3], ts[4], int(ts[4].shape[0]), stream=stream)
                     ls += a
                     nc += b

@@ -1,0 +1,26 @@
+"""Net.fit end to end (samples/s per epoch) on a synthetic training set: materialised arrays on the host (streamed in slices),
+the same arrays small enough to be resident, and the compact form are timed; the Python loop and the host gathers must
+keep up with the GPU step rate (bench.py --mode train)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'sub-cortical_segmentation_amd')):
+    sys.path.insert(0, p)
+from cnn_cort import synth
+from cnn_cort.nets import Net
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 120000
+rng = np.random.RandomState(0)
+ax, co, sa, at = synth.patch_batch(4096, seed=1)
+rep = (n + 4095) // 4096
+X = {'in1': np.tile(ax, (rep, 1, 1, 1))[:n], 'in2': np.tile(co, (rep, 1, 1, 1))[:n], 'in3': np.tile(sa, (rep, 1, 1, 1))[:n],
+     'in4': np.tile(at, (rep, 1))[:n]}
+y = rng.randint(0, 15, n).astype(np.uint8)
+for bs in (128, 256):
+    for mode, resident in (('streamed from the host', 0), ('resident', 1 << 40)):
+        net = Net(max_epochs=2, patience=50, eval_size=0.25, batch_size=bs, verbose=0, device=0, seed=1, fit_resident_bytes=resident)
+        t0 = time.time()
+        net.fit(X, y)
+        durs = [r['dur'] for r in net.train_history_]
+        print('batch %d, %s: %d samples, epoch times %s s -> %.0f samples/s (second epoch, training + hold-out pass)'
+              % (bs, mode, n, ['%.2f' % d for d in durs], n / durs[-1]), flush=True)

@@ -265,6 +265,8 @@ int main(int argc, char** argv) {
         stamps<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 4, 1>>("TF12", n);
         stamps<ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 208, 1, 4, 1>>("TF3", n);
         stamps<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4, 1>>("TF4", n);
+        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1>>("TF5", n);
+        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1>>("DG5", n);
     }
     if (all || !strcmp(what, "wg")) {
         run_wg<WG2>("WG2 (shipped)", n, 64, rounds, c2);

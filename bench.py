@@ -70,12 +70,16 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(weights, budget_s=12.0, batch=128):
+CPU_BUDGET_S = float(os.environ.get('SCS_BENCH_CPU_BUDGET', '12'))     # seconds of host work per cpu_baseline sample
+
+
+def cpu_baseline(weights, budget_s=None, batch=128):
     """float32 torch-CPU port on the host cores, bounded sample (kind 'port': the reference's Theano CPU path
     cannot run here - BASELINE.md section 3)."""
     import torch
     from oracle import torch_ref as T
     from cnn_cort import synth
+    budget_s = CPU_BUDGET_S if budget_s is None else budget_s
     cores = usable_cpus()
     torch.set_num_threads(cores)
     net = T.FoldedCPUNet(weights)
@@ -91,7 +95,7 @@ def cpu_baseline(weights, budget_s=12.0, batch=128):
                       % (done, batch, dt)}
 
 
-def cpu_baseline_volume(weights, budget_s=12.0, chunk=4096, batch=128):
+def cpu_baseline_volume(weights, budget_s=None, chunk=4096, batch=128):
     """Whole-subject stand-in: the literal per-voxel patch extraction of
     load_patch_batch / get_patches (oracle/patches_ref.py; one np.pad of the volume per view and chunk, then one slice
     per voxel - the reference does this per 100 000-voxel chunk) + the torch-CPU forward in nolearn's batches of 128,
@@ -99,6 +103,7 @@ def cpu_baseline_volume(weights, budget_s=12.0, chunk=4096, batch=128):
     import torch
     from oracle import patches_ref as R, torch_ref as T
     from cnn_cort import synth
+    budget_s = CPU_BUDGET_S if budget_s is None else budget_s
     cores = usable_cpus()
     torch.set_num_threads(cores)
     shape = (256, 256, 192)
@@ -121,12 +126,13 @@ def cpu_baseline_volume(weights, budget_s=12.0, chunk=4096, batch=128):
                       % (done, chunk, batch, dt, 400000 * dt / done)}
 
 
-def cpu_baseline_train(weights, budget_s=12.0, batch=256):
+def cpu_baseline_train(weights, budget_s=None, batch=256):
     """Training-step stand-in on the host cores: the torch-CPU restatement (autograd backward) + Adam, float32,
     batch 256, explicit dropout masks - BASELINE.md section 3, config 3."""
     import torch
     from oracle import np_oracle as O, torch_ref as T
     from cnn_cort import params as P, synth
+    budget_s = CPU_BUDGET_S if budget_s is None else budget_s
     cores = usable_cpus()
     torch.set_num_threads(cores)
     ax, co, sa, at = synth.patch_batch(batch, seed=0)

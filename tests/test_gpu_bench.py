@@ -1,0 +1,40 @@
+"""bench.py's output contract on the MI355X: one JSON line with the keys the driver reads, a `roofline` for the dominant
+kernel (event-timed) and a `cpu_baseline`, in the forward and in the training mode."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+        'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
+
+
+def run_bench(args):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['SCS_BENCH_CPU_BUDGET'] = '2'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('mode', ['forward', 'train'])
+def test_bench_line(mode):
+    out = run_bench(['--mode', mode, '--steps', '3', '--warmup', '1'] + (['--batch', '8192'] if mode == 'forward' else []))
+    assert KEYS <= set(out), KEYS - set(out)
+    assert out['n_gpus'] == 1 and out['steps'] == 3 and out['warmup'] == 1 and out['unit'] == 'patches/s'
+    assert out['dtype'] == 'f32' and out['data'] == 'synthetic' and out['vs_baseline'] is None and out['scaling'] == 'weak'
+    assert out['value'] > 1e4 and abs(out['ms_per_step'] * out['value'] / 1e3 - out['config']['per_gpu_batch']) < 1e-6 * out['config']['per_gpu_batch'] + 1
+    rf = out['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and rf['peak'] == 157.3 and 0.05 < rf['frac'] < 1.0
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['launch_ms'] > 0
+    cb = out['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'patches/s' and cb['sample']
+    if mode == 'train':
+        assert out['launches_per_step'] <= 33 and 'conv2 dgrad + layer-1 sums' in out['stages']

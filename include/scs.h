@@ -145,14 +145,17 @@ int scs_train_step(scs_handle h, const float* ax_dev, const float* co_dev, const
  *   atlas_rows_dev float32 [N][15], y_dev uint8 [N]: prior vector and class id (0..14) of every sample
  *   index_dev      int32 [n]: the rows of samples / atlas_rows / y that form THIS batch - generate_training_set's permutation
  *                  (base.py:92-103) as an index array - or NULL for rows 0..n-1
+ *   flips_dev      uint8 [n] or NULL: per batch row two bits per view t (bit 2t: mirror the patch rows, bit 2t+1: mirror its
+ *                  columns) - the rotate-180 / flip variants of the reference's Rotate_batch_Iterator (nets.py:64-84), applied
+ *                  inside the gather
  *   n_vols, n_samples  sizes of the two tables: a volume number or index entry outside them is clamped on the device,
  *                  never dereferenced (voxels outside a volume read as zero padding)
  * Replaces: load_patch_vectors + generate_training_set materialising [N,1,32,32] x 3 (base.py:120-184, 53-117) in front of
  * net.fit.  Results are bit-identical to scs_train_step on the materialised patches. */
 int scs_train_step_volume(scs_handle h, const float* vols_dev, const scs_volume* descs_dev, int32_t n_vols,
                           const int32_t* samples_dev, int64_t n_samples, const float* atlas_rows_dev, const uint8_t* y_dev,
-                          const int32_t* index_dev, int64_t n, uint64_t dropout_seed, const uint8_t* masks_dev,
-                          float* loss_host, void* stream);
+                          const int32_t* index_dev, const uint8_t* flips_dev, int64_t n, uint64_t dropout_seed,
+                          const uint8_t* masks_dev, float* loss_host, void* stream);
 
 /* Class id of every sample: the label volume at the sample's voxel, with the boundary class 15 mapped to background 0
  * (generate_training_set, base.py:85-89).  label_vols_dev: uint8, concatenated like vols_dev (same descs). */

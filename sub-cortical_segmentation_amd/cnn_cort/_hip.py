@@ -37,7 +37,7 @@ SIGNATURES = {
     'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
     'scs_dilate_mask': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp]),
     'scs_train_step': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
-    'scs_train_step_volume': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
+    'scs_train_step_volume': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
     'scs_gather_labels': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp]),
     'scs_eval_batch_volume': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp, _vp, _c.c_int64, _c.POINTER(_c.c_double),
                                          _c.POINTER(_c.c_int64), _vp]),
@@ -196,16 +196,17 @@ class Handle:
                'scs_train_step')
         return float(loss.value) if want_loss else None
 
-    def train_step_volume(self, vols, descs, samples, atlas_rows, y, index, n, seed=0, masks=None, want_loss=True, stream=0):
+    def train_step_volume(self, vols, descs, samples, atlas_rows, y, index, n, seed=0, masks=None, want_loss=True, stream=0, flips=None):
         """Gather-fused step: patches are cut inside the kernels from `vols` (concatenated volumes on the device) around
         the voxels of `samples[index]` (include/scs.h: scs_train_step_volume)."""
         _need(index, n, 'batch index')
+        _need(flips, n, 'flip flags')
         _need(atlas_rows, 15 * samples.shape[0], 'atlas rows')
         _need(y, samples.shape[0], 'labels')
         _need(masks, 5 * 540 * n, 'dropout masks')
         loss = ctypes.c_float(0.0)
         _check(self.lib.scs_train_step_volume(self.h, _ptr(vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(samples.shape[0]),
-                                              _ptr(atlas_rows), _ptr(y), _ptr(index), int(n), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
+                                              _ptr(atlas_rows), _ptr(y), _ptr(index), _ptr(flips), int(n), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
                                               ctypes.addressof(loss) if want_loss else None, stream or None),
                'scs_train_step_volume')
         return float(loss.value) if want_loss else None

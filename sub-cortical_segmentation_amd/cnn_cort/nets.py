@@ -505,11 +505,26 @@ class Net:
             d_tr = torch.from_numpy(X.index[tr_idx].astype(np.int32)).to(dev)
             d_va = torch.from_numpy(X.index[va_idx].astype(np.int32)).to(dev)
 
+            def compact_batch(seed, lo, hi):
+                flips = None
+                if self.augment and hi - lo > 1:
+                    # the same draws as _train_batch makes for materialised patches; variant r of Rotate_batch_Iterator as
+                    # mirror flags of the gather: 0 rotate_180 = rows + columns, 1 flipped = columns, 2 rotate_180 flipped = rows
+                    nb = hi - lo
+                    aug_rng.manual_seed((self.seed << 20) + self._step * 8 + rank)
+                    idx = torch.randperm(nb, generator=aug_rng, device=dev)[:nb // 2]
+                    code = torch.tensor([3, 2, 1], dtype=torch.uint8, device=dev)
+                    flips = torch.zeros((nb,), dtype=torch.uint8, device=dev)
+                    for v in range(3):
+                        r = torch.randint(0, 3, (idx.numel(),), generator=aug_rng, device=dev)
+                        flips[idx] |= code[r] << (2 * v)
+                h.train_step_volume(d_vols, d_desc, d_samples, d_atlas, d_y, d_tr[lo:hi], hi - lo, seed=seed, want_loss=False,
+                                    stream=stream, flips=flips)
+
             def train_batches():
                 for lo in my_starts:
                     hi = min(ntr, lo + bs)
-                    yield hi - lo, (lambda seed, lo=lo, hi=hi: h.train_step_volume(
-                        d_vols, d_desc, d_samples, d_atlas, d_y, d_tr[lo:hi], hi - lo, seed=seed, want_loss=False, stream=stream))
+                    yield hi - lo, (lambda seed, lo=lo, hi=hi: compact_batch(seed, lo, hi))
 
             def evaluate():
                 return h.eval_batch_volume(d_vols, d_desc, d_samples, d_atlas, d_y, d_va[va_lo:va_hi], va_hi - va_lo, stream=stream)
@@ -643,6 +658,9 @@ class Net:
                     hook(self, self.train_history_)
         except StopIteration:
             pass
+        finally:
+            if not compact:
+                pool.shutdown(wait=False)
         return self
 
     def _train_batch(self, h, views, atl, yy, nb, seed, stream, aug_rng, rank):

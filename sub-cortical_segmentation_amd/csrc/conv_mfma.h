@@ -123,6 +123,8 @@ struct X0Src {
     const int32_t* samples;       // [N][4]: volume, x, y, z
     const int32_t* index;         // [n] rows of `samples` that form this batch (null: rows 0..n-1)
     int n_samples, n_vols;        // bounds: a row / volume number outside them is clamped, never dereferenced
+    const uint8_t* flips;         // [n] or null: per batch row, two bits per view (bit 2t: mirror the patch rows, bit 2t+1: mirror
+                                  // its columns) - the rotate / flip augmentation of nets.py:41-124 applied inside the gather
 };
 
 // sample row of patch g: (volume, x, y, z), row and volume numbers clamped into the tables (voxels outside a volume read as
@@ -298,10 +300,12 @@ __device__ __forceinline__ void load_x0_rows(const X0Src& s, int tower, int g, i
         const int4 smp = x0_sample(s, g);
         const scs_volume d = s.descs[smp.x];
         const float* __restrict__ vol = s.vols + d.offset;
+        const int fl = s.flips ? (s.flips[g] >> (2 * tower)) & 3 : 0;
+        const int fi = (fl & 1) ? 31 : 0, fj = (fl & 2) ? 31 : 0;          // mirrored index = 31 - index = index ^ 31
 #pragma unroll
         for (int e0 = 0; e0 < NROWS * 32; e0 += NTH) {
             const int e = e0 + tid;
-            if (e < NROWS * 32) s_x[e] = gather_voxel(vol, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, row0 + (e >> 5), e & 31);
+            if (e < NROWS * 32) s_x[e] = gather_voxel(vol, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, (row0 + (e >> 5)) ^ fi, (e & 31) ^ fj);
         }
     }
 }
@@ -366,10 +370,13 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         } else {
             const int4 smp = x0_sample(a.x0, g0);
             const scs_volume d = a.x0.descs[smp.x];
+            const int fl = a.x0.flips ? (a.x0.flips[g0] >> (2 * tower)) & 3 : 0;
+            const int fi = (fl & 1) ? 31 : 0, fj = (fl & 2) ? 31 : 0;
 #pragma unroll
             for (int q = 0; q < L1_NX; ++q) {
                 const int e = min(tid + C::NTH * q, XR * 32 - 1);
-                l1xs[q] = gather_voxel(a.x0.vols + d.offset, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, band * C::HOB + (e >> 5), e & 31);
+                l1xs[q] = gather_voxel(a.x0.vols + d.offset, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w,
+                                       (band * C::HOB + (e >> 5)) ^ fi, (e & 31) ^ fj);
             }
         }
         if (tid < 240) l1tab = pick3(a.bnlow, tower)[tid];

@@ -220,6 +220,7 @@ struct PrepArgs {
     const float* atlas; const uint8_t* y; const int32_t* index; float* cat2; uint8_t* yb; int n, n_rows;   // n_rows: rows atlas / y hold
     uint8_t* masks; size_t mask_total; uint64_t seed;       // masks == null: the caller supplied them
     const float* fc2W; float* w2p;                           // fc_2.W [555][270] -> [556][272] zero padded
+    unsigned int* ticket;                                    // head_train_kernel's last-workgroup ticket, re-armed every step
 };
 
 // blockIdx.y selects the job:
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
             a.cat2[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? a.atlas[(size_t)src * 15 + c] : 0.f;
             if (c == 0) a.yb[row] = a.y[src];
         }
+        if (t0 == 0) *a.ticket = 0u;
         for (int e = t0; e < kW2Floats; e += stride) {
             const int k = e / kFC2ld, c = e - k * kFC2ld;
             a.w2p[e] = (k < kFC1 + kAtlas && c < kFC2) ? a.fc2W[(size_t)k * kFC2 + c] : 0.f;
@@ -827,7 +829,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat, kFlat, kFC1};
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
         pa.n_rows = index ? x0.n_samples : n;
-        pa.fc2W = P + H.fc2W; pa.w2p = w2p;
+        pa.fc2W = P + H.fc2W; pa.w2p = w2p; pa.ticket = w->counter;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
         run(ST_PREP, st, [&] { hipLaunchKernelGGL(prep_kernel, dim3(64, kPackJobs + kTrJobs + 2), dim3(256), 0, st, pa); });
     }
@@ -1046,8 +1048,8 @@ int scs_train_step_profiled(scs_handle h, const float* ax, const float* co, cons
 }
 
 int scs_train_step_volume(scs_handle h, const float* vols, const scs_volume* descs, int32_t n_vols, const int32_t* samples,
-                          int64_t n_samples, const float* atlas_rows, const uint8_t* y, const int32_t* index, int64_t n64,
-                          uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, void* stream) {
+                          int64_t n_samples, const float* atlas_rows, const uint8_t* y, const int32_t* index, const uint8_t* flips,
+                          int64_t n64, uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
     SCS_ARG(n64 > 0 && n64 <= (1 << 20), "n out of range");
     SCS_ARG(vols && descs && samples && atlas_rows && y, "null input pointer");
@@ -1055,6 +1057,7 @@ int scs_train_step_volume(scs_handle h, const float* vols, const scs_volume* des
     SCS_ARG(index || n64 <= n_samples, "more samples asked for than the table holds");
     X0Src x0{};
     x0.vols = vols; x0.descs = descs; x0.samples = samples; x0.index = index; x0.n_samples = (int)n_samples; x0.n_vols = n_vols;
+    x0.flips = flips;
     return train_step_impl(h, x0, atlas_rows, y, index, (int)n64, dropout_seed, masks_dev, loss_host, (hipStream_t)stream, nullptr);
 }
 
@@ -1077,16 +1080,18 @@ int scs_get_train_buffer(scs_handle h, int which, float* host_out, size_t count)
     if (!h->tws || !h->tws->base) { set_error("no training step has run"); return SCS_ERR_STATE; }
     TrainWs* w = h->tws;
     const float* src = nullptr;
+    size_t ld = 0;
     switch (which) {
-        case 0: src = w->dR2; break;     // [n][272]
-        case 1: src = w->dcat; break;    // [n][540]
-        case 2: src = w->dfeat; break;   // [n][540]
-        case 3: src = w->featd; break;   // [n][540]
-        case 4: src = w->R1; break;      // [n][540]
-        case 5: src = w->cat2; break;    // [n][556]
-        case 6: src = w->dlog; break;    // [n][16]
+        case 0: src = w->dR2; ld = kFC2ld; break;     // [n][272]
+        case 1: src = w->dcat; ld = kFC1; break;      // [n][540]
+        case 2: src = w->dfeat; ld = kFlat; break;    // [n][540]
+        case 3: src = w->featd; ld = kFlat; break;    // [n][540]
+        case 4: src = w->R1; ld = kFC1; break;        // [n][540]
+        case 5: src = w->cat2; ld = kFC1ld; break;    // [n][556]
+        case 6: src = w->dlog; ld = 16; break;        // [n][16]
         default: SCS_ARG(false, "unknown buffer id");
     }
+    SCS_ARG(count <= (size_t)w->cap * ld, "count exceeds the buffer");
     SCS_HIP(hipSetDevice(h->device));
     SCS_HIP(hipDeviceSynchronize());
     SCS_HIP(hipMemcpy(host_out, src, count * sizeof(float), hipMemcpyDeviceToHost));

@@ -170,3 +170,46 @@ def test_out_of_range_rows_and_volume_numbers_are_clamped(toy, weights):
         h.close()
     assert np.isfinite(out[0][0]) and np.isfinite(out[0][1]).all()
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
+def test_augmented_step_and_fit_from_volumes_equal_the_materialised_ones(toy, weights):
+    """The opt-in rotate / flip augmentation: as mirror flags inside the gather (compact path) it produces the same step as
+    rotate_flip_views applied to the materialised batch, and fit(augment=True) walks the same history on both forms."""
+    from cnn_cort.nets import Net, rotate_flip_views
+    _, mat, cs = toy
+    d = device_form(cs)
+    n, lo = 40, 3
+    rng = np.random.RandomState(4)
+    idx = rng.choice(n, n // 2, replace=False)
+    choices = [rng.randint(0, 3, size=idx.size) for _ in range(3)]
+    flips = np.zeros(n, np.uint8)
+    for v in range(3):
+        flips[idx] |= (np.array([3, 2, 1], np.uint8)[choices[v]] << (2 * v)).astype(np.uint8)
+    views = rotate_flip_views([dev(mat[v][lo:lo + n]) for v in range(3)], torch.from_numpy(idx).to('cuda:0'),
+                              [torch.from_numpy(c).to('cuda:0') for c in choices])
+    st = torch.cuda.current_stream().cuda_stream
+    out = []
+    for compact in (False, True):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        if compact:
+            loss = h.train_step_volume(d['vols'], d['desc'], d['samples'], d['atlas'], d['y'], d['index'][lo:lo + n], n, seed=9, stream=st,
+                                       flips=torch.from_numpy(flips).to('cuda:0'))
+        else:
+            loss = h.train_step(views[0].contiguous(), views[1].contiguous(), views[2].contiguous(), dev(mat[3][lo:lo + n]),
+                                dev(mat[4][lo:lo + n], torch.uint8), n, seed=9, stream=st)
+        out.append((loss, arena(h, 'grad')))
+        h.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    assert (flips != 0).sum() == n // 2
+    hist = []
+    for X, y in ((cs, None), ({'in1': mat[0], 'in2': mat[1], 'in3': mat[2], 'in4': mat[3]}, mat[4])):
+        net = Net(max_epochs=2, patience=20, eval_size=0.25, batch_size=48, verbose=0, device=0, seed=6, augment=True)
+        net.load_params_from({k: [a.copy() for a in v] for k, v in weights.items()})
+        net.fit(X, y)
+        hist.append([(r['train_loss'], r['valid_loss']) for r in net.train_history_])
+    assert hist[0] == hist[1]
+    plain = Net(max_epochs=1, patience=20, eval_size=0.25, batch_size=48, verbose=0, device=0, seed=6)
+    plain.load_params_from({k: [a.copy() for a in v] for k, v in weights.items()})
+    plain.fit(cs)
+    assert plain.train_history_[0]['train_loss'] != hist[0][0][0]                  # the augmentation does change the batches

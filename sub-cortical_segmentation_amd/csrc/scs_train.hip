@@ -627,44 +627,49 @@ __global__ __launch_bounds__(256) void eval_sum_kernel(const float* __restrict__
     if (threadIdx.x == 0) { acc[0] += l; acc[1] += hct; }
 }
 
-// Training head in one pass per row: out_layer (270 -> 15) + softmax + cross-entropy, d logits = (p - onehot)/n, and
-// the gradient that flows back through fc_2's ReLU:  dR2[row][k] = (R2[row][k] > 0) * sum_c dlog[c] * W[k][c].
-// 16 lanes per row (lane = class), kHeadRows rows per workgroup (small workgroups: at batch 256 the kernel is one latency
-// chain per workgroup, so more of them in parallel is what shortens it).  The workgroup that finishes last adds the per-row
-// losses in a fixed order into the batch mean (no extra launch; the ticket is an integer atomic, the sum itself is ordered).
-constexpr int kHeadRows = 8, kHeadThreads = 16 * kHeadRows;
-__global__ __launch_bounds__(kHeadThreads) void head_train_kernel(const float* __restrict__ R2, const float* __restrict__ W,
-                                                                 const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
-                                                                 float* __restrict__ probs /*[n][16]*/, float* __restrict__ dlog /*[n][16]*/,
-                                                                 float* __restrict__ loss_rows /*[n]*/, float* __restrict__ dR2 /*[n][kFC2ld]*/,
-                                                                 float* __restrict__ loss_mean, unsigned int* ticket) {
-    __shared__ __attribute__((aligned(16))) float s_w[kFC2 * 15 + 18];
-    __shared__ __attribute__((aligned(16))) float s_x[kHeadRows][kFC2ld];
-    __shared__ float s_d[kHeadRows][16];
-    __shared__ double s_red[kHeadThreads / 64];
+// Training head, 16 rows per workgroup, both small products on the matrix cores:
+//   logits[16][15] = R2[16][270] W[270][15] + b      (the four waves split K, partial tiles added through LDS in wave order)
+//   softmax + cross-entropy per row, d logits = (p - onehot)/n                                  (nets.py:231, 235)
+//   dR2[16][270]  = (R2 > 0) * d logits[16][15] W'[15][270]   - the gradient through fc_2's ReLU (the waves split the columns)
+// The workgroup that finishes last adds the per-row losses in a fixed order into the batch mean (no extra launch; the ticket is
+// an integer atomic, the sum itself is ordered).
+__global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict__ R2, const float* __restrict__ W,
+                                                        const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
+                                                        float* __restrict__ probs /*[n][16]*/, float* __restrict__ dlog /*[n][16]*/,
+                                                        float* __restrict__ loss_rows /*[n]*/, float* __restrict__ dR2 /*[n][kFC2ld]*/,
+                                                        float* __restrict__ loss_mean, unsigned int* ticket) {
+    __shared__ f32x4 s_p[4][64];
+    __shared__ float s_d[16][17];
+    __shared__ double s_red[4];
     __shared__ bool s_last;
-    constexpr int NT = kHeadThreads;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < kFC2 * 15; e += NT) s_w[e] = W[e];
-    if (tid < 15) s_w[kFC2 * 15 + tid] = b[tid];
-    const int r = tid >> 4, c = tid & 15;
-    const int row0 = blockIdx.x * kHeadRows, row = row0 + r;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    // ---- logits: wave w owns k-steps [17 w, 17 w + 17) of the 68 (K = 270 padded to 272)
     {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(R2 + (size_t)row0 * kFC2ld);      // kFC2ld = 272 = 68 float4 per row
-        const int rows_here = min(kHeadRows, n - row0);
-        for (int e = tid; e < kHeadRows * (kFC2ld / 4); e += NT)
-            reinterpret_cast<float4*>(&s_x[0][0])[e] = (e < rows_here * (kFC2ld / 4)) ? src[e] : float4{0.f, 0.f, 0.f, 0.f};
+        constexpr int SPW = 17;
+        const int arow = min(row0 + lr, n - 1);
+        const float* __restrict__ ap = R2 + (size_t)arow * kFC2ld + kq;
+        float av[SPW], bv[SPW];
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int k = 4 * (wave * SPW + i) + kq;
+            av[i] = k < kFC2 ? ap[4 * (wave * SPW + i)] : 0.f;
+            bv[i] = (k < kFC2 && lr < 15) ? W[k * 15 + lr] : 0.f;
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+        s_p[wave][lane] = acc;                                       // D[row 4 kq + r][class lr]
     }
     __syncthreads();
-    const int cc = c < 15 ? c : 14;                                // lane 15 shadows class 14, its results are dropped
-    float z0 = s_w[kFC2 * 15 + cc], z1 = 0.f;
-#pragma unroll 5
-    for (int k = 0; k < kFC2; k += 2) {                            // two independent chains (same order of additions per chain)
-        z0 = fmaf(s_x[r][k], s_w[k * 15 + cc], z0);
-        z1 = fmaf(s_x[r][k + 1], s_w[(k + 1) * 15 + cc], z1);
-    }
-    const float z = z0 + z1;
-    float mx = z;
+    // ---- softmax / cross-entropy: thread (r, c) = (row, class); its logit sits in lane (c, r >> 2), register r & 3
+    const int r = tid >> 4, c = tid & 15;
+    const int row = row0 + r;
+    const int src = (r >> 2) * 16 + c;
+    const float z = (c < 15 ? b[c] : 0.f) + ((s_p[0][src][r & 3] + s_p[1][src][r & 3]) + (s_p[2][src][r & 3] + s_p[3][src][r & 3]));
+    float mx = c < 15 ? z : -3.0e38f;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     const float e = c < 15 ? expf(z - mx) : 0.f;
@@ -681,14 +686,27 @@ __global__ __launch_bounds__(kHeadThreads) void head_train_kernel(const float* _
         if (c == yi) loss_rows[row] = -(z - mx - logf(sum));       // -log softmax, stable
     }
     __syncthreads();
-    if (row < n) {
-        for (int k = c; k < kFC2ld; k += 16) {
-            float g = 0.f;
-            if (k < kFC2 && s_x[r][k] > 0.f) {
+    // ---- dR2: 17 column tiles of 16, wave w owns tiles w, w + 4, ...; K = the 15 classes (4 k-steps)
+    {
+        float a4[4];
 #pragma unroll
-                for (int j = 0; j < 15; ++j) g = fmaf(s_d[r][j], s_w[k * 15 + j], g);
+        for (int s4 = 0; s4 < 4; ++s4) a4[s4] = s_d[lr][4 * s4 + kq];             // d logits[row lr][class 4 s + kq] (class 15 = 0)
+        for (int t = wave; t < 17; t += 4) {
+            const int col = 16 * t + lr;
+            float w4[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { const int cl = 4 * s4 + kq; w4[s4] = (col < kFC2 && cl < 15) ? W[col * 15 + cl] : 0.f; }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], w4[s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int orow = row0 + 4 * kq + i;
+                if (orow < n) {
+                    const float gate = col < kFC2 ? R2[(size_t)orow * kFC2ld + col] : 0.f;
+                    dR2[(size_t)orow * kFC2ld + col] = gate > 0.f ? acc[i] : 0.f;          // columns 270, 271: zero
+                }
             }
-            dR2[(size_t)row * kFC2ld + k] = g;
         }
     }
     // ---- batch mean of the losses by the last workgroup
@@ -698,10 +716,10 @@ __global__ __launch_bounds__(kHeadThreads) void head_train_kernel(const float* _
     __syncthreads();
     if (!s_last) return;
     __threadfence();                                               // acquire: the other workgroups' rows
-    double s = 0;
-    for (int i = tid; i < n; i += NT) s += (double)__builtin_nontemporal_load(loss_rows + i);
-    s = block_sum(s, s_red);
-    if (tid == 0) { loss_mean[0] = (float)(s / n); *ticket = 0u; }
+    double sacc = 0;
+    for (int i = tid; i < n; i += 256) sacc += (double)__builtin_nontemporal_load(loss_rows + i);
+    sacc = block_sum(sacc, s_red);
+    if (tid == 0) { loss_mean[0] = (float)(sacc / n); *ticket = 0u; }
 }
 
 // sum of the partial weight gradients of ALL conv layers in a fixed order (deterministic): blockIdx.z = layer, 64 elements x
@@ -889,7 +907,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     g.p[0] = GemmProblem{w->cat2, kFC1ld, w2p, kFC2ld, P + H.fc2b, w->R2, kFC2ld};
     run(ST_FC2, st, [&] { gemm_launch(g, 1, st); });
     run(ST_HEAD, st, [&] {
-        hipLaunchKernelGGL(head_train_kernel, dim3((n + kHeadRows - 1) / kHeadRows), dim3(kHeadThreads), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,
+        hipLaunchKernelGGL(head_train_kernel, dim3((n + 15) / 16), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,
                            w->loss_rows, w->dR2, w->loss_dev, w->counter);
     });
 

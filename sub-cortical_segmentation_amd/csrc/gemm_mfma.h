@@ -309,12 +309,28 @@ struct WgProblem {
     int M, N;
 };
 constexpr int kWgProblems = 6;
-struct WgGroupArgs { WgProblem p[kWgProblems]; int K; };
+struct WgGroupArgs {
+    WgProblem p[kWgProblems]; int K;
+    const float* loss_rows; float* loss_mean;      // one extra workgroup (blockIdx.z = kWgProblems): mean of the K per-row losses
+};
 
 template <int CH_ = 32>
 __global__ __launch_bounds__(256, 2) void dense_wgrad_kernel(WgGroupArgs g) {
     constexpr int NT = 3, CH = CH_;
     __shared__ f32x4 s_r[4 * NT * 64];
+    if ((int)blockIdx.z == kWgProblems) {
+        // the batch-mean loss: one workgroup, double, fixed order (lanes by shuffle, then waves 0..3)
+        if (blockIdx.x != 0 || blockIdx.y != 0 || !g.loss_rows) return;
+        double v = 0;
+        for (int i = threadIdx.x; i < g.K; i += 256) v += (double)g.loss_rows[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        double* s_d = reinterpret_cast<double*>(s_r);
+        if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) g.loss_mean[0] = (float)(((s_d[0] + s_d[1]) + (s_d[2] + s_d[3])) / g.K);
+        return;
+    }
     WgProblem P = g.p[0];
 #pragma unroll
     for (int i = 1; i < kWgProblems; ++i) if ((int)blockIdx.z == i) P = g.p[i];
@@ -377,7 +393,7 @@ inline void dense_wgrad_launch(const WgGroupArgs& g, int nproblems, hipStream_t 
         const int rows = g.p[i].M + (g.p[i].bias_out ? 1 : 0);
         mr = rows > mr ? rows : mr; mc = g.p[i].N > mc ? g.p[i].N : mc;
     }
-    hipLaunchKernelGGL(dense_wgrad_kernel<>, dim3((mr + 15) / 16, (mc + 47) / 48, nproblems), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(dense_wgrad_kernel<>, dim3((mr + 15) / 16, (mc + 47) / 48, nproblems + (g.loss_rows ? 1 : 0)), dim3(256), 0, st, g);
 }
 
 #ifndef SCS_GEMM_BK

@@ -83,7 +83,6 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* l1m[kTowers]{};                     // [20][2]: mean, inv_std of conv1's batch statistics
     double* mom = nullptr;                     // [3][100] R (9x9), S (column 9), count
     float* wg_part = nullptr;                  // [4 layers][3][kWgPartFloats] partial weight gradients
-    unsigned int* counter = nullptr;           // ticket of head_train_kernel's last-block loss mean
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
     hipStream_t side = nullptr;
@@ -111,7 +110,6 @@ void train_free(scs_ctx* h) {
     if (w->wg_part) (void)hipFree(w->wg_part);
     if (w->small) (void)hipFree(w->small);
     if (w->mom) (void)hipFree(w->mom);
-    if (w->counter) (void)hipFree(w->counter);
     if (w->side) (void)hipStreamDestroy(w->side);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     if (w->ev_join) (void)hipEventDestroy(w->ev_join);
@@ -143,8 +141,6 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540 + kW2Floats) * sizeof(float)));
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)4 * kTowers * kWgPartFloats * sizeof(float)));
         SCS_HIP(hipMalloc(&w->mom, (size_t)kTowers * 100 * sizeof(double)));
-        SCS_HIP(hipMalloc(&w->counter, 64));
-        SCS_HIP(hipMemset(w->counter, 0, 64));
         // coefficient tables: per tower and conv layer 64 x (float2 + float4 + float4), then the conv1 tables
         size_t so = 0;
         auto stake = [&](size_t f) { size_t o = so; so += al64(f); return o; };
@@ -220,7 +216,6 @@ struct PrepArgs {
     const float* atlas; const uint8_t* y; const int32_t* index; float* cat2; uint8_t* yb; int n, n_rows;   // n_rows: rows atlas / y hold
     uint8_t* masks; size_t mask_total; uint64_t seed;       // masks == null: the caller supplied them
     const float* fc2W; float* w2p;                           // fc_2.W [555][270] -> [556][272] zero padded
-    unsigned int* ticket;                                    // head_train_kernel's last-workgroup ticket, re-armed every step
 };
 
 // blockIdx.y selects the job:
@@ -275,7 +270,6 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
             a.cat2[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? a.atlas[(size_t)src * 15 + c] : 0.f;
             if (c == 0) a.yb[row] = a.y[src];
         }
-        if (t0 == 0) *a.ticket = 0u;
         for (int e = t0; e < kW2Floats; e += stride) {
             const int k = e / kFC2ld, c = e - k * kFC2ld;
             a.w2p[e] = (k < kFC1 + kAtlas && c < kFC2) ? a.fc2W[(size_t)k * kFC2 + c] : 0.f;
@@ -631,17 +625,13 @@ __global__ __launch_bounds__(256) void eval_sum_kernel(const float* __restrict__
 //   logits[16][15] = R2[16][270] W[270][15] + b      (the four waves split K, partial tiles added through LDS in wave order)
 //   softmax + cross-entropy per row, d logits = (p - onehot)/n                                  (nets.py:231, 235)
 //   dR2[16][270]  = (R2 > 0) * d logits[16][15] W'[15][270]   - the gradient through fc_2's ReLU (the waves split the columns)
-// The workgroup that finishes last adds the per-row losses in a fixed order into the batch mean (no extra launch; the ticket is
-// an integer atomic, the sum itself is ordered).
+// (The batch-mean loss is one ordered sum of loss_rows inside the grouped dense weight-gradient launch, gemm_mfma.h.)
 __global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict__ R2, const float* __restrict__ W,
                                                         const float* __restrict__ b, const uint8_t* __restrict__ y, int n,
                                                         float* __restrict__ probs /*[n][16]*/, float* __restrict__ dlog /*[n][16]*/,
-                                                        float* __restrict__ loss_rows /*[n]*/, float* __restrict__ dR2 /*[n][kFC2ld]*/,
-                                                        float* __restrict__ loss_mean, unsigned int* ticket) {
+                                                        float* __restrict__ loss_rows /*[n]*/, float* __restrict__ dR2 /*[n][kFC2ld]*/) {
     __shared__ f32x4 s_p[4][64];
     __shared__ float s_d[16][17];
-    __shared__ double s_red[4];
-    __shared__ bool s_last;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
@@ -709,17 +699,6 @@ __global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict
             }
         }
     }
-    // ---- batch mean of the losses by the last workgroup
-    __threadfence();                                               // this workgroup's loss_rows are visible device-wide
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                               // acquire: the other workgroups' rows
-    double sacc = 0;
-    for (int i = tid; i < n; i += 256) sacc += (double)__builtin_nontemporal_load(loss_rows + i);
-    sacc = block_sum(sacc, s_red);
-    if (tid == 0) { loss_mean[0] = (float)(sacc / n); *ticket = 0u; }
 }
 
 // sum of the partial weight gradients of ALL conv layers in a fixed order (deterministic): blockIdx.z = layer, 64 elements x
@@ -847,7 +826,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat, kFlat, kFC1};
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
         pa.n_rows = index ? x0.n_samples : n;
-        pa.fc2W = P + H.fc2W; pa.w2p = w2p; pa.ticket = w->counter;
+        pa.fc2W = P + H.fc2W; pa.w2p = w2p;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
         run(ST_PREP, st, [&] { hipLaunchKernelGGL(prep_kernel, dim3(64, kPackJobs + kTrJobs + 2), dim3(256), 0, st, pa); });
     }
@@ -908,7 +887,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     run(ST_FC2, st, [&] { gemm_launch(g, 1, st); });
     run(ST_HEAD, st, [&] {
         hipLaunchKernelGGL(head_train_kernel, dim3((n + 15) / 16), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,
-                           w->loss_rows, w->dR2, w->loss_dev, w->counter);
+                           w->loss_rows, w->dR2);
     });
 
     // ---- backward: dense head.  d logits and dR2 (through fc_2's ReLU) came out of head_train_kernel's pass.  Data
@@ -926,6 +905,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     {
         WgGroupArgs wg{};
         wg.K = n;
+        wg.loss_rows = w->loss_rows; wg.loss_mean = w->loss_dev;
         wg.p[0] = WgProblem{w->R2, kFC2ld, w->dlog, 16, G + H.outW, kClasses, G + H.outb, kFC2, kClasses};
         wg.p[1] = WgProblem{w->cat2, kFC1ld, w->dR2, kFC2ld, G + H.fc2W, kFC2, G + H.fc2b, kFC1 + kAtlas, kFC2};
         wg.p[2] = WgProblem{w->featd, kFlat, w->dcat, kFC1, G + H.fc1W, kFC1, G + H.fc1b, kFlat, kFC1};

@@ -51,9 +51,12 @@ enum ConvEpi { EPI_BIAS_RELU = 0, EPI_BIAS_RELU_POOL = 1, EPI_RAW = 2, EPI_RAW_S
 enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3, SRC_BN = 4, SRC_BN_POOL = 5, SRC_DZ_PAD2 = 6,
                SRC_DZ_POOL_PAD2 = 7, SRC_X0 = 8 };
 
-template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4>
+// FIN_ = 1 (EPI_RAW_STATS / EPI_RAW_BNB*): the workgroup of a tower that finishes last also finalizes the batch-norm sums
+// (what a separate tiny launch would do: at training batch sizes a dependent launch costs ~10 us of latency, the tail ~2 us)
+template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4, int FIN_ = 0>
 struct ConvCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_;
+    static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_, FIN = FIN_;
+    static_assert(!FIN_ || (NW_ == 4 && (EPI_ == EPI_RAW_STATS || EPI_ == EPI_RAW_BNB || EPI_ == EPI_RAW_BNB_POOL)), "in-kernel finalize: 256-thread statistics kernels");
     static constexpr int NW = NW_, NTH = 64 * NW_;          // waves / threads per workgroup
     static constexpr bool PAD2 = (SRC_ == SRC_NCHW_PAD2 || SRC_ == SRC_DZ_PAD2 || SRC_ == SRC_DZ_POOL_PAD2);
     static constexpr bool FUSED1 = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME || SRC_ == SRC_X0);
@@ -137,6 +140,108 @@ __device__ __forceinline__ int4 x0_sample(const X0Src& s, int g) {
     return smp;
 }
 
+// what the last workgroup of a tower needs to turn the partial sums into batch-norm coefficients (FIN configurations)
+struct FinArgs {
+    unsigned int* counter;        // [kTowers] arrival tickets, zero between launches
+    double count;                 // values per channel over the batch
+    float* bn[kTowers];           // forward: this layer's (beta, gamma, mean, inv_std) in the parameter arena; backward: the
+                                  // layer below's (d beta, d gamma, -, -) slot in the gradient arena
+    float* ss[kTowers];           // forward: float2 [COUT] (scale, shift) out
+    float* coef[kTowers];         // forward: float4 [COUT] (sc, sh, mean, inv_std) out; backward: float4 [COUT] (sc, sh, ca, cb) out
+};
+
+// Cross-workgroup hand-off of the partial sums without any fence on the producers: the sums are stored write-through
+// (`sc1`: they never sit dirty in an XCD's L2), every storing wave drains its stores, and one lane per workgroup takes a
+// ticket; the workgroup whose ticket completes the count invalidates its L1 once and reads the sums with `sc1` loads.
+__device__ __forceinline__ void st_sc1(float2* p, float2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_sc1(const float2* p) {
+    return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ bool arrive_last(unsigned int* counter, unsigned int expected, volatile int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial sums have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = (t == expected - 1);
+        if (last) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// Forward finalize (same arithmetic as scs_train.hip: bn_fwd_final_kernel): units of (mean, M2) over `per_unit` values each ->
+// batch mean / biased variance by the parallel-variance formula in double, fixed order; TPC threads share a channel.
+template <int CH>
+__device__ __forceinline__ void bn_fin_forward(const float2* __restrict__ part /*[units][CH]*/, int units, double count, float* bn,
+                                               float2* __restrict__ ss, float4* __restrict__ low4, double* s_acc /*[256][3]*/) {
+    constexpr int TPC = 256 / CH;
+    const int tid = threadIdx.x, c = tid / TPC, sub = tid - c * TPC;
+    double s = 0, s2 = 0, q = 0, m0 = 0;
+    if (c < CH) {
+        m0 = (double)ld_sc1(part + c).x;
+        for (int u0 = sub; u0 < units; u0 += 8 * TPC) {
+            float2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * TPC, units - 1) * CH + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (u0 + k * TPC < units) { const double d = (double)v[k].x - m0; s += d; s2 += d * d; q += v[k].y; }
+        }
+    }
+    s_acc[tid * 3] = s; s_acc[tid * 3 + 1] = s2; s_acc[tid * 3 + 2] = q;
+    __syncthreads();
+    if (c < CH && sub == 0) {
+        s = s2 = q = 0;
+        for (int k = 0; k < TPC; ++k) { s += s_acc[(tid + k) * 3]; s2 += s_acc[(tid + k) * 3 + 1]; q += s_acc[(tid + k) * 3 + 2]; }
+        const double dm = s / units, mean = m0 + dm;
+        const double var = (q + (count / units) * fmax(s2 - s * dm, 0.0)) / count;
+        const double inv = 1.0 / sqrt(var + (double)kBnEps);
+        const float sc = bn[CH + c] * (float)inv, sh = bn[c] - (float)mean * sc;
+        ss[c] = make_float2(sc, sh);
+        low4[c] = make_float4(sc, sh, (float)mean, (float)inv);
+        bn[2 * CH + c] = (1.f - kBnAlpha) * bn[2 * CH + c] + kBnAlpha * (float)mean;
+        bn[3 * CH + c] = (1.f - kBnAlpha) * bn[3 * CH + c] + kBnAlpha * (float)inv;
+    }
+}
+
+// Backward finalize (bn_bwd_final_kernel): (d beta, d gamma) partial sums -> gradients + the coefficients of
+// d z = [y > 0] sc dUp + ca z + cb,  ca = -sc inv mg,  cb = sc (inv mean mg - mb),  mb = d beta / M,  mg = d gamma / M.
+template <int CH>
+__device__ __forceinline__ void bn_fin_backward(const float2* __restrict__ part /*[units][CH]*/, int units, double count,
+                                                const float4* __restrict__ low4, float* __restrict__ gbn, float4* __restrict__ cf4,
+                                                double* s_acc /*[256][3]*/) {
+    constexpr int TPC = 256 / CH;
+    const int tid = threadIdx.x, c = tid / TPC, sub = tid - c * TPC;
+    double sb = 0, sg = 0;
+    if (c < CH) {
+        for (int u0 = sub; u0 < units; u0 += 8 * TPC) {
+            float2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * TPC, units - 1) * CH + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (u0 + k * TPC < units) { sb += v[k].x; sg += v[k].y; }
+        }
+    }
+    s_acc[tid * 3] = sb; s_acc[tid * 3 + 1] = sg;
+    __syncthreads();
+    if (c < CH && sub == 0) {
+        sb = sg = 0;
+        for (int k = 0; k < TPC; ++k) { sb += s_acc[(tid + k) * 3]; sg += s_acc[(tid + k) * 3 + 1]; }
+        gbn[c] = (float)sb; gbn[CH + c] = (float)sg;                                // mean / inv_std entries stay 0
+        const float4 lo = low4[c];                                                  // sc, sh, mean, inv
+        const double mb = sb / count, mg = sg / count, sc = lo.x, inv = lo.w, mean = lo.z;
+        cf4[c] = make_float4(lo.x, lo.y, (float)(-sc * inv * mg), (float)(sc * (inv * mean * mg - mb)));
+    }
+}
+
 struct ConvArgs {
     const float* in[kTowers];     // SRC_NCHW*: [n][CIN][HSRC][HSRC]; SRC_CONV1: [n][32][32]; SRC_VOLUME: the volume;
                                   // SRC_BN*: raw conv output of the layer below; SRC_DZ*: raw conv output of THIS layer
@@ -159,6 +264,7 @@ struct ConvArgs {
                                   // conv1 filters (9), sc, sh, pad
     X0Src x0;                     // SRC_X0 / EPI_L1: the input patches
     int tower0;                   // first tower of this launch (grid.y towers from here; per-tower streams launch one each)
+    FinArgs fin;                  // FIN configurations
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -863,13 +969,30 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             for (int o = LPR / 2; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
             if (sub == 0 && live) {
                 float2* dst = reinterpret_cast<float2*>(sp + (((size_t)(g0 + g) * C::NB + band) * C::COUT + c) * 2);
+                float2 val;
                 if constexpr (C::EPI == EPI_RAW_STATS) {
-                    // (mean, sum of squared deviations) of this unit of OUTB values - combined exactly by the finalize kernel
+                    // (mean, sum of squared deviations) of this unit of OUTB values - combined exactly by the finalize step
                     const float mu = sm * (1.f / C::OUTB);
-                    *dst = make_float2(s_o[row * C::OSTR] + mu, fmaxf(sq - sm * mu, 0.f));
+                    val = make_float2(s_o[row * C::OSTR] + mu, fmaxf(sq - sm * mu, 0.f));
                 } else {
-                    *dst = make_float2(sm, sq);
+                    val = make_float2(sm, sq);
                 }
+                if constexpr (C::FIN) st_sc1(dst, val); else *dst = val;
+            }
+        }
+        if constexpr (C::FIN) {
+            static_assert(C::LDS_BYTES >= 256 * 3 * 8 + 16, "finalize scratch");
+            __syncthreads();                                               // s_o has been read: the LDS is free
+            double* s_acc = reinterpret_cast<double*>(smem);
+            if (arrive_last(a.fin.counter + tower, gridDim.x, reinterpret_cast<volatile int*>(smem + 256 * 6))) {
+                const float2* part = reinterpret_cast<const float2*>(sp);
+                const int units = a.n * C::NB;
+                if constexpr (C::EPI == EPI_RAW_STATS)
+                    bn_fin_forward<C::COUT>(part, units, a.fin.count, pick3(a.fin.bn, tower), reinterpret_cast<float2*>(pick3(a.fin.ss, tower)),
+                                            reinterpret_cast<float4*>(pick3(a.fin.coef, tower)), s_acc);
+                else
+                    bn_fin_backward<C::COUT>(part, units, a.fin.count, reinterpret_cast<const float4*>(pick3(a.bnlow, tower)),
+                                             pick3(a.fin.bn, tower), reinterpret_cast<float4*>(pick3(a.fin.coef, tower)), s_acc);
             }
         }
     }

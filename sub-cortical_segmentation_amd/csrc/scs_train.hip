@@ -82,6 +82,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* l1p[kTowers]{};                     // [20][12]: flipped conv1 taps (9), sc, sh, pad
     float* l1m[kTowers]{};                     // [20][2]: mean, inv_std of conv1's batch statistics
     double* mom = nullptr;                     // [3][100] R (9x9), S (column 9), count
+    unsigned int* fin_counter = nullptr;       // [3] arrival tickets of the in-kernel finalize steps (zero between launches)
     float* wg_part = nullptr;                  // [4 layers][3][kWgPartFloats] partial weight gradients
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
@@ -110,6 +111,7 @@ void train_free(scs_ctx* h) {
     if (w->wg_part) (void)hipFree(w->wg_part);
     if (w->small) (void)hipFree(w->small);
     if (w->mom) (void)hipFree(w->mom);
+    if (w->fin_counter) (void)hipFree(w->fin_counter);
     if (w->side) (void)hipStreamDestroy(w->side);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     if (w->ev_join) (void)hipEventDestroy(w->ev_join);
@@ -141,6 +143,8 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540 + kW2Floats) * sizeof(float)));
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)4 * kTowers * kWgPartFloats * sizeof(float)));
         SCS_HIP(hipMalloc(&w->mom, (size_t)kTowers * 100 * sizeof(double)));
+        SCS_HIP(hipMalloc(&w->fin_counter, 64));
+        SCS_HIP(hipMemset(w->fin_counter, 0, 64));
         // coefficient tables: per tower and conv layer 64 x (float2 + float4 + float4), then the conv1 tables
         size_t so = 0;
         auto stake = [&](size_t f) { size_t o = so; so += al64(f); return o; };
@@ -850,14 +854,22 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             else { a.in[t] = w->Z[t][i - 1]; a.bn[t] = reinterpret_cast<const float*>(w->ss[t][i - 1]); a.xout[t] = w->X[t][i]; }
         }
         a.x0 = x0;
+        const int C = kCout[i], Hh = kHout[i];
+        const double count = (double)n * Hh * Hh;
+        a.fin.counter = w->fin_counter; a.fin.count = count;
+        for (int t = 0; t < kTowers; ++t) {
+            a.fin.bn[t] = P + T0.bn[i] + t * kTowerFloats;
+            a.fin.ss[t] = reinterpret_cast<float*>(w->ss[t][i]); a.fin.coef[t] = reinterpret_cast<float*>(w->low4[t][i]);
+        }
+        constexpr bool kFwdFin[kConvs] = {false, TF12::FIN != 0, TF3::FIN != 0, TF4::FIN != 0, TF5::FIN != 0};
         if (i == 1) run(ST_CONV12, st, [&] { conv_launch<TF12>(a, st); });
         else if (i == 2) run(ST_CONV3, st, [&] { conv_launch<TF3>(a, st); });
         else if (i == 3) run(ST_CONV4, st, [&] { conv_launch<TF4>(a, st); });
         else run(ST_CONV5, st, [&] { conv_launch<TF5>(a, st); });
-        const int C = kCout[i], Hh = kHout[i];
-        const double count = (double)n * Hh * Hh;
         const int units = n * kStatBands[i];
-        if (i < kConvs - 1) {
+        if (kFwdFin[i]) {
+            // the conv kernel's last workgroup has already finalized this layer's statistics
+        } else if (i < kConvs - 1) {
             run(ST_FIN2 + 2 * (i - 1), st, [&] {
                 hipLaunchKernelGGL(bn_fwd_final_kernel<false>, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, units, count, C, P, T0.bn[i],
                                    kTowerFloats, p3(w->ss, i), p3(w->low4, i), CPtr3{}, Ptr3{}, (const uint8_t*)nullptr, n);
@@ -929,6 +941,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     WgFinalArgs fa{};
     fa.grads = G; fa.tower_stride = kTowerFloats;
     constexpr int kDgBands[kConvs] = {0, DG2::NB, DG3::NB, DG4::NB, DG5::NB};
+    constexpr bool kDgFin[kConvs + 1] = {false, DG2::FIN != 0, DG3::FIN != 0, DG4::FIN != 0, DG5::FIN != 0, false};
     for (int i = kConvs - 1; i >= 1; --i) {
         const int C = kCout[i], Hh = kHout[i];
         const double count = (double)n * Hh * Hh;
@@ -939,12 +952,12 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
                 hipLaunchKernelGGL(bn_bwd_final_kernel<true>, dim3(C, kTowers), dim3(256), 0, st, (const float*)nullptr, 0, count, C, c3(w->low4, i),
                                    p3(w->cf4, i), G, T0.bn[i], kTowerFloats, c3(w->Z, i), dUp, n);
             });
-        } else {
+        } else if (!kDgFin[i + 1]) {
             run(ST_FINB4 + 2 * (kConvs - 2 - i), st, [&] {
                 hipLaunchKernelGGL(bn_bwd_final_kernel<false>, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, n * kDgBands[i + 1], count, C,
                                    c3(w->low4, i), p3(w->cf4, i), G, T0.bn[i], kTowerFloats, CPtr3{}, CPtr3{}, n);
             });
-        }
+        }                                                               // else: the data-gradient kernel of layer i+1 finalized layer i
         // data gradient (d z_i while staging, stored for the weight gradient; epilogue: partial sums of layer i-1)
         ConvArgs a{};
         a.n = n;
@@ -956,6 +969,13 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         }
         a.stats = (i >= 2) ? w->stat_part : w->l1_part;
         a.x0 = x0;
+        if (i >= 2) {                                                   // finalize of the layer below, done by the kernel's last workgroup
+            a.fin.counter = w->fin_counter; a.fin.count = (double)n * kHout[i - 1] * kHout[i - 1];
+            for (int t = 0; t < kTowers; ++t) {
+                a.fin.bn[t] = G + T0.bn[i - 1] + t * kTowerFloats;
+                a.fin.coef[t] = reinterpret_cast<float*>(w->cf4[t][i - 1]);
+            }
+        }
         if (i == 4) run(ST_DG5, st, [&] { conv_launch<DG5>(a, st); });
         else if (i == 3) run(ST_DG4, st, [&] { conv_launch<DG4>(a, st); });
         else if (i == 2) run(ST_DG3, st, [&] { conv_launch<DG3>(a, st); });

@@ -415,3 +415,30 @@ def test_rotate_flip_views_on_device_equals_the_reference_formulas():
         assert got[v].is_cuda and np.array_equal(got[v].cpu().numpy(), want)
         assert torch.equal(d_views[v], keep[v])                               # inputs untouched
         assert all(c in choices[v] for c in (0, 1, 2))                        # every variant exercised
+
+
+def test_long_run_is_deterministic_under_uneven_load(weights):
+    """150 steps at batch 256, run twice - the second time with a busy neighbour on another stream: parameters end bit-identical.
+    A stale read in a cross-workgroup hand-off (the batch-norm finalize done by the last workgroup of a conv kernel, the side
+    stream joins) would be load-dependent and show up as a difference."""
+    from cnn_cort import _hip, synth
+    B, steps = 256, 150
+    ax, co, sa, at = [dev(a) for a in synth.patch_batch(B, seed=0)]
+    y = dev(np.random.RandomState(0).randint(0, 15, B).astype(np.uint8), torch.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    big = torch.randn((2048, 2048), device='cuda:0')
+    out = []
+    for run in range(2):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        for i in range(steps):
+            if run == 1 and i % 3 == 0:
+                with torch.cuda.stream(side):
+                    big = big @ big.t() * 1e-4
+            h.train_step(ax, co, sa, at, y, B, seed=i, want_loss=False, stream=st)
+            h.adam_apply(stream=st)
+        torch.cuda.synchronize()
+        out.append(h.get_params())
+        h.close()
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])

@@ -57,6 +57,7 @@ template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_,
 struct ConvCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_, FIN = FIN_;
     static_assert(!FIN_ || (NW_ == 4 && (EPI_ == EPI_RAW_STATS || EPI_ == EPI_RAW_BNB || EPI_ == EPI_RAW_BNB_POOL)), "in-kernel finalize: 256-thread statistics kernels");
+    static_assert(!FIN_ || NB_ == 1, "in-kernel finalize: the ticket words are sized for one workgroup per patch");
     static constexpr int NW = NW_, NTH = 64 * NW_;          // waves / threads per workgroup
     static constexpr bool PAD2 = (SRC_ == SRC_NCHW_PAD2 || SRC_ == SRC_DZ_PAD2 || SRC_ == SRC_DZ_POOL_PAD2);
     static constexpr bool FUSED1 = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME || SRC_ == SRC_X0);
@@ -142,13 +143,20 @@ __device__ __forceinline__ int4 x0_sample(const X0Src& s, int g) {
 
 // what the last workgroup of a tower needs to turn the partial sums into batch-norm coefficients (FIN configurations)
 struct FinArgs {
-    unsigned int* counter;        // [kTowers] arrival tickets, zero between launches
+    unsigned int* counter;        // arrival tickets, zero between launches: fin_counter_words(workgroups per tower) words per tower
     double count;                 // values per channel over the batch
     float* bn[kTowers];           // forward: this layer's (beta, gamma, mean, inv_std) in the parameter arena; backward: the
                                   // layer below's (d beta, d gamma, -, -) slot in the gradient arena
     float* ss[kTowers];           // forward: float2 [COUT] (scale, shift) out
     float* coef[kTowers];         // forward: float4 [COUT] (sc, sh, mean, inv_std) out; backward: float4 [COUT] (sc, sh, ca, cb) out
 };
+
+// Arrival tickets are a two-level tree: groups of kFinGroup workgroups share a counter (each on its own 128-byte line), the
+// workgroup that completes a group takes a ticket on the tower's top counter.  Same-address device-scope atomics retire one
+// at a time (~50 ns each on MI355X, tools/gridbar.hip): a flat counter makes the last of 256 simultaneously finishing
+// workgroups wait ~13 us for its ticket, the tree ~1.5 us.
+constexpr int kFinGroup = 16, kFinLine = 32;
+constexpr size_t fin_counter_words(size_t wgs_per_tower) { return (1 + (wgs_per_tower + kFinGroup - 1) / kFinGroup) * kFinLine; }
 
 // Cross-workgroup hand-off of the partial sums without any fence on the producers: the sums are stored write-through
 // (`sc1`: they never sit dirty in an XCD's L2), every storing wave drains its stores, and one lane per workgroup takes a
@@ -159,16 +167,22 @@ __device__ __forceinline__ void st_sc1(float2* p, float2 v) {
 __device__ __forceinline__ float2 ld_sc1(const float2* p) {
     return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__device__ __forceinline__ bool arrive_last(unsigned int* counter, unsigned int expected, volatile int* s_flag) {
+__device__ __forceinline__ bool arrive_last(unsigned int* counter /* this tower's words */, unsigned int nwg, unsigned int wg, volatile int* s_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial sums have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = (t == expected - 1);
-        if (last) {
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int g = wg / kFinGroup, groups = (nwg + kFinGroup - 1) / kFinGroup;
+        const unsigned int gsize = min((unsigned int)kFinGroup, nwg - g * kFinGroup);
+        unsigned int* gc = counter + (size_t)kFinLine * (1 + g);
+        bool last = false;
+        if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // re-armed for the next launch
+            if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
+                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                last = true;
+            }
         }
         *s_flag = last ? 1 : 0;
     }
@@ -176,30 +190,34 @@ __device__ __forceinline__ bool arrive_last(unsigned int* counter, unsigned int 
     return *s_flag != 0;
 }
 
-// Forward finalize (same arithmetic as scs_train.hip: bn_fwd_final_kernel): units of (mean, M2) over `per_unit` values each ->
-// batch mean / biased variance by the parallel-variance formula in double, fixed order; TPC threads share a channel.
+// Finalize by the last workgroup (256 threads).  Thread (j, c) = (tid / CH, tid % CH) walks units j, j + J, ... of channel
+// c (J = 256 / CH): a wave's loads cover whole rows of the [units][CH] table, and kFinBatch of them are in flight at once.
+constexpr int kFinBatch = 20;
+
+// Forward (same arithmetic as scs_train.hip: bn_fwd_final_kernel): units of (mean, M2) over count / units values each ->
+// batch mean / biased variance by the parallel-variance formula in double, fixed order.
 template <int CH>
 __device__ __forceinline__ void bn_fin_forward(const float2* __restrict__ part /*[units][CH]*/, int units, double count, float* bn,
                                                float2* __restrict__ ss, float4* __restrict__ low4, double* s_acc /*[256][3]*/) {
-    constexpr int TPC = 256 / CH;
-    const int tid = threadIdx.x, c = tid / TPC, sub = tid - c * TPC;
+    constexpr int J = 256 / CH;
+    const int tid = threadIdx.x, j = tid / CH, c = tid - j * CH;
     double s = 0, s2 = 0, q = 0, m0 = 0;
-    if (c < CH) {
+    if (j < J) {
         m0 = (double)ld_sc1(part + c).x;
-        for (int u0 = sub; u0 < units; u0 += 8 * TPC) {
-            float2 v[8];
+        for (int u0 = j; u0 < units; u0 += kFinBatch * J) {
+            float2 v[kFinBatch];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * TPC, units - 1) * CH + c);
+            for (int k = 0; k < kFinBatch; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * J, units - 1) * CH + c);
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (u0 + k * TPC < units) { const double d = (double)v[k].x - m0; s += d; s2 += d * d; q += v[k].y; }
+            for (int k = 0; k < kFinBatch; ++k)
+                if (u0 + k * J < units) { const double d = (double)v[k].x - m0; s += d; s2 += d * d; q += v[k].y; }
         }
     }
     s_acc[tid * 3] = s; s_acc[tid * 3 + 1] = s2; s_acc[tid * 3 + 2] = q;
     __syncthreads();
-    if (c < CH && sub == 0) {
+    if (tid < CH) {
         s = s2 = q = 0;
-        for (int k = 0; k < TPC; ++k) { s += s_acc[(tid + k) * 3]; s2 += s_acc[(tid + k) * 3 + 1]; q += s_acc[(tid + k) * 3 + 2]; }
+        for (int k = 0; k < J; ++k) { s += s_acc[(tid + k * CH) * 3]; s2 += s_acc[(tid + k * CH) * 3 + 1]; q += s_acc[(tid + k * CH) * 3 + 2]; }
         const double dm = s / units, mean = m0 + dm;
         const double var = (q + (count / units) * fmax(s2 - s * dm, 0.0)) / count;
         const double inv = 1.0 / sqrt(var + (double)kBnEps);
@@ -217,24 +235,24 @@ template <int CH>
 __device__ __forceinline__ void bn_fin_backward(const float2* __restrict__ part /*[units][CH]*/, int units, double count,
                                                 const float4* __restrict__ low4, float* __restrict__ gbn, float4* __restrict__ cf4,
                                                 double* s_acc /*[256][3]*/) {
-    constexpr int TPC = 256 / CH;
-    const int tid = threadIdx.x, c = tid / TPC, sub = tid - c * TPC;
+    constexpr int J = 256 / CH;
+    const int tid = threadIdx.x, j = tid / CH, c = tid - j * CH;
     double sb = 0, sg = 0;
-    if (c < CH) {
-        for (int u0 = sub; u0 < units; u0 += 8 * TPC) {
-            float2 v[8];
+    if (j < J) {
+        for (int u0 = j; u0 < units; u0 += kFinBatch * J) {
+            float2 v[kFinBatch];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * TPC, units - 1) * CH + c);
+            for (int k = 0; k < kFinBatch; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * J, units - 1) * CH + c);
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (u0 + k * TPC < units) { sb += v[k].x; sg += v[k].y; }
+            for (int k = 0; k < kFinBatch; ++k)
+                if (u0 + k * J < units) { sb += v[k].x; sg += v[k].y; }
         }
     }
     s_acc[tid * 3] = sb; s_acc[tid * 3 + 1] = sg;
     __syncthreads();
-    if (c < CH && sub == 0) {
+    if (tid < CH) {
         sb = sg = 0;
-        for (int k = 0; k < TPC; ++k) { sb += s_acc[(tid + k) * 3]; sg += s_acc[(tid + k) * 3 + 1]; }
+        for (int k = 0; k < J; ++k) { sb += s_acc[(tid + k * CH) * 3]; sg += s_acc[(tid + k * CH) * 3 + 1]; }
         gbn[c] = (float)sb; gbn[CH + c] = (float)sg;                                // mean / inv_std entries stay 0
         const float4 lo = low4[c];                                                  // sc, sh, mean, inv
         const double mb = sb / count, mg = sg / count, sc = lo.x, inv = lo.w, mean = lo.z;
@@ -984,7 +1002,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             static_assert(C::LDS_BYTES >= 256 * 3 * 8 + 16, "finalize scratch");
             __syncthreads();                                               // s_o has been read: the LDS is free
             double* s_acc = reinterpret_cast<double*>(smem);
-            if (arrive_last(a.fin.counter + tower, gridDim.x, reinterpret_cast<volatile int*>(smem + 256 * 6))) {
+            if (arrive_last(a.fin.counter + tower * fin_counter_words(gridDim.x), gridDim.x, blockIdx.x, reinterpret_cast<volatile int*>(smem + 256 * 6))) {
                 const float2* part = reinterpret_cast<const float2*>(sp);
                 const int units = a.n * C::NB;
                 if constexpr (C::EPI == EPI_RAW_STATS)

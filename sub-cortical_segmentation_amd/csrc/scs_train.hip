@@ -82,7 +82,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* l1p[kTowers]{};                     // [20][12]: flipped conv1 taps (9), sc, sh, pad
     float* l1m[kTowers]{};                     // [20][2]: mean, inv_std of conv1's batch statistics
     double* mom = nullptr;                     // [3][100] R (9x9), S (column 9), count
-    unsigned int* fin_counter = nullptr;       // [3] arrival tickets of the in-kernel finalize steps (zero between launches)
+    unsigned int* fin_counter = nullptr;       // arrival tickets of the in-kernel finalize steps (inside `base`; zero between launches)
     float* wg_part = nullptr;                  // [4 layers][3][kWgPartFloats] partial weight gradients
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
@@ -111,7 +111,6 @@ void train_free(scs_ctx* h) {
     if (w->wg_part) (void)hipFree(w->wg_part);
     if (w->small) (void)hipFree(w->small);
     if (w->mom) (void)hipFree(w->mom);
-    if (w->fin_counter) (void)hipFree(w->fin_counter);
     if (w->side) (void)hipStreamDestroy(w->side);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     if (w->ev_join) (void)hipEventDestroy(w->ev_join);
@@ -143,8 +142,6 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540 + kW2Floats) * sizeof(float)));
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)4 * kTowers * kWgPartFloats * sizeof(float)));
         SCS_HIP(hipMalloc(&w->mom, (size_t)kTowers * 100 * sizeof(double)));
-        SCS_HIP(hipMalloc(&w->fin_counter, 64));
-        SCS_HIP(hipMemset(w->fin_counter, 0, 64));
         // coefficient tables: per tower and conv layer 64 x (float2 + float4 + float4), then the conv1 tables
         size_t so = 0;
         auto stake = [&](size_t f) { size_t o = so; so += al64(f); return o; };
@@ -190,7 +187,8 @@ static int train_ensure(scs_ctx* h, int n) {
                  o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
                  o_sp = take((size_t)kTowers * c * 8 * 64 * 2),     // up to 8 bands x 64 channels x 2 sums
-                 o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * 256 * 128);
+                 o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * 256 * 128),
+                 o_fc = take(kTowers * fin_counter_words(c));                 // one workgroup per patch in the FIN configurations
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
     for (int t = 0; t < kTowers; ++t) {
@@ -204,6 +202,7 @@ static int train_ensure(scs_ctx* h, int n) {
     w->R2 = w->base + o_R2; w->probs = w->base + o_probs; w->dlog = w->base + o_dlog; w->dR2 = w->base + o_dR2;
     w->dcat = w->base + o_dcat; w->dfeat = w->base + o_dfeat; w->loss_rows = w->base + o_lr; w->loss_dev = w->base + o_ld;
     w->stat_part = w->base + o_sp; w->l1_part = w->base + o_l1; w->mom_part = w->base + o_mp;
+    w->fin_counter = reinterpret_cast<unsigned int*>(w->base + o_fc);
     SCS_HIP(hipMalloc(&w->masks, c * kFlat * 5 + c));
     w->yb = w->masks + c * kFlat * 5;
     w->cap = (int)c;

@@ -24,7 +24,7 @@ static float* dev_random(size_t n, unsigned seed, float lo = -1.f, float hi = 1.
     return d;
 }
 
-struct Pool { float* in[3]; float* in2[3]; float* in3[3]; float* out[3]; float* out2[3]; float* coef[3]; float* stats; float* part; size_t per; };
+struct Pool { float* in[3]; float* in2[3]; float* in3[3]; float* out[3]; float* out2[3]; float* coef[3]; float* fin[3]; unsigned int* counter; float* stats; float* part; size_t per; };
 static Pool g_pool;
 static void make_pool(int n) {
     g_pool.per = (size_t)n * 20 * 1024;
@@ -32,7 +32,9 @@ static void make_pool(int n) {
         g_pool.in[t] = dev_random(g_pool.per, 1 + t); g_pool.in2[t] = dev_random(g_pool.per, 11 + t); g_pool.in3[t] = dev_random(g_pool.per, 21 + t);
         CK(hipMalloc(&g_pool.out[t], g_pool.per * 4)); CK(hipMalloc(&g_pool.out2[t], g_pool.per * 4));
         g_pool.coef[t] = dev_random(4096, 31 + t, 0.2f, 1.2f);
+        g_pool.fin[t] = dev_random(4096, 41 + t, 0.2f, 1.2f);      // finalize outputs of the FIN configurations
     }
+    CK(hipMalloc(&g_pool.counter, 3 * fin_counter_words(n) * 4)); CK(hipMemset(g_pool.counter, 0, 3 * fin_counter_words(n) * 4));
     CK(hipMalloc(&g_pool.stats, (size_t)3 * n * 32 * 256 * 4));      // up to 32 bands x 256 floats per patch and tower
     CK(hipMalloc(&g_pool.part, (size_t)3 * 1024 * 60 * 40 * 9 * 4));     // up to 1024 partials of the largest layer per tower
 }
@@ -64,7 +66,9 @@ static ConvArgs conv_args(int n) {
         a.xout[t] = (C::SRC == SRC_BN || C::SRC == SRC_BN_POOL) ? g_pool.out2[t] : nullptr;
         a.dup[t] = g_pool.in2[t]; a.zlow[t] = g_pool.in2[t]; a.bnlow[t] = g_pool.coef[t] + 3072;
         a.x0.views[t] = g_pool.in2[t];
+        a.fin.bn[t] = g_pool.fin[t]; a.fin.ss[t] = g_pool.fin[t] + 1024; a.fin.coef[t] = g_pool.fin[t] + 2048;
     }
+    a.fin.counter = g_pool.counter; a.fin.count = (double)n * C::PIX;
     a.stats = g_pool.stats;
     return a;
 }
@@ -208,6 +212,20 @@ int main(int argc, char** argv) {
         run_conv<DG3>("DG3 + d z stored", n, rounds, c3, true);
         run_conv<DG4>("DG4 + d z stored", n, rounds, c4, true);
         run_conv<DG5>("DG5 + d z stored", n, rounds, c5, true);
+    }
+    if (!strcmp(what, "fin")) {
+        // what the in-kernel finalize (last workgroup of a tower) adds to the statistics kernels
+        run_conv<TF3>("TF3 (shipped, FIN)", n, rounds, c3);
+        run_conv<ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 208, 1, 4>>("TF3 without finalize", n, rounds, c3);
+        run_conv<TF4>("TF4 (shipped, FIN)", n, rounds, c4);
+        run_conv<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4>>("TF4 without finalize", n, rounds, c4);
+        run_conv<DG5>("DG5 (shipped, FIN)", n, rounds, c5, true);
+        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4>>("DG5 without finalize", n, rounds, c5, true);
+        run_conv<DG4>("DG4 (shipped, FIN)", n, rounds, c4, true);
+        run_conv<ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3>>("DG4 without finalize", n, rounds, c4, true);
+        run_conv<DG3>("DG3 (shipped, FIN)", n, rounds, c3, true);
+        run_conv<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3>>("DG3 without finalize", n, rounds, c3, true);
+        return 0;
     }
     if (!strcmp(what, "sweep")) {
         run_conv<TF12>("TF12 NB7 WPS4 (shipped)", n, rounds, c1 + c2);

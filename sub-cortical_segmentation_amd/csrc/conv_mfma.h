@@ -596,6 +596,51 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                 s_in[pl * C::PLANE + wdx] = y;
                 if (xo && pl < planes) xo[(size_t)pl * W + wdx] = y;
             });
+    } else if constexpr (C::SRC == SRC_DZ_PAD2 && C::NB == 1 && C::HSRC % 4 == 0) {
+        // training backward, whole planes whose rows are float4 multiples: d z = [sc z + sh > 0] sc dUp + ca z + cb from 16-byte
+        // pieces of z and dUp (ONE round of loads; the scalar walk over the padded plane below takes four), the zero
+        // border is written while the loads are in flight
+        constexpr int HS = C::HSRC, HS4 = HS / 4, HW4 = HS * HS4, TOTAL = C::G * C::CIN * HW4;
+        constexpr int ITER = (TOTAL + C::NTH - 1) / C::NTH;
+        static_assert(ITER <= 8, "one round of loads");
+        static_assert(C::PLANE % 2 == 0 && C::WIN % 2 == 0, "8-byte LDS stores");
+        const float4* __restrict__ z4 = reinterpret_cast<const float4*>(insrc + (size_t)g0 * C::CIN * HS * HS);
+        const float4* __restrict__ d4 = reinterpret_cast<const float4*>(pick3(a.dup, tower) + (size_t)g0 * C::CIN * HS * HS);
+        const float4* __restrict__ bn4 = reinterpret_cast<const float4*>(pick3(a.bn, tower));
+        float* __restrict__ dzo = pick3(a.xout, tower);
+        float4* __restrict__ dzo4 = dzo ? reinterpret_cast<float4*>(dzo + (size_t)g0 * C::CIN * HS * HS) : nullptr;
+        const int planes = ng * C::CIN;
+        float4 vz[ITER], vd[ITER], vc[ITER];
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int e = min(tid + C::NTH * k, TOTAL - 1), pl = e / HW4;
+            const bool ok = pl < planes;
+            vz[k] = ok ? z4[e] : float4{0.f, 0.f, 0.f, 0.f};
+            vd[k] = ok ? d4[e] : float4{0.f, 0.f, 0.f, 0.f};
+            vc[k] = ok ? bn4[pl % C::CIN] : float4{0.f, 0.f, 0.f, 0.f};
+        }
+        {
+            float4* z0 = reinterpret_cast<float4*>(s_in);
+            for (int e = tid; e < C::IN_FLOATS_AL / 4; e += C::NTH) z0[e] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+            const int e = tid + C::NTH * k;
+            if (e < TOTAL) {
+                const int pl = e / HW4, r = e - pl * HW4, ys = r / HS4, x4 = r - ys * HS4;
+                const float4 z = vz[k], d = vd[k], cf = vc[k];
+                float4 o;
+                o.x = ((fmaf(z.x, cf.x, cf.y) > 0.f) ? cf.x * d.x : 0.f) + fmaf(cf.z, z.x, cf.w);
+                o.y = ((fmaf(z.y, cf.x, cf.y) > 0.f) ? cf.x * d.y : 0.f) + fmaf(cf.z, z.y, cf.w);
+                o.z = ((fmaf(z.z, cf.x, cf.y) > 0.f) ? cf.x * d.z : 0.f) + fmaf(cf.z, z.z, cf.w);
+                o.w = ((fmaf(z.w, cf.x, cf.y) > 0.f) ? cf.x * d.w : 0.f) + fmaf(cf.z, z.w, cf.w);
+                float* q = s_in + pl * C::PLANE + (ys + 2) * C::WIN + 4 * x4 + 2;             // even offset: two 8-byte stores
+                *reinterpret_cast<float2*>(q) = float2{o.x, o.y};
+                *reinterpret_cast<float2*>(q + 2) = float2{o.z, o.w};
+                if (dzo4 && pl < planes) dzo4[e] = o;
+            }
+        }
     } else if constexpr (C::SRC == SRC_DZ_PAD2) {
         // training backward: d z = [sc z + sh > 0] sc dUp + ca z + cb, zero padded by 2; rows the band owns are stored
         constexpr int HS = C::HSRC, HW = HS * HS, BW = C::HINB * C::WIN;

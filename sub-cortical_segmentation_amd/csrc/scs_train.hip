@@ -36,11 +36,11 @@
 namespace scs {
 
 // profiling stages of scs_train_step_profiled (one per launch)
-enum Stage { ST_PREP, ST_MOMENTS, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
+enum Stage { ST_PREP, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
              ST_FC2, ST_HEAD, ST_DCAT, ST_DFEAT, ST_DH5, ST_BN5B, ST_DG5, ST_FINB4, ST_DG4, ST_FINB3, ST_DG3, ST_FINB2, ST_DG2,
              ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_COUNT };
 static const char* const kStageNames[ST_COUNT] = {
-    "prep (weight packs, dropout masks, atlas columns)", "input moments", "bn1 finalize", "conv1+conv2 fwd", "bn2 finalize",
+    "prep (weight packs, dropout masks, atlas columns) + input moments", "bn1 finalize", "conv1+conv2 fwd", "bn2 finalize",
     "conv3 fwd", "bn3 finalize", "conv4 fwd", "bn4 finalize", "conv5 fwd", "bn5 + dropout", "d1 x3 fwd", "FC1 fwd", "fc_2 fwd",
     "out + softmax + CE", "fc_2 dgrad", "FC1 dgrad", "d1 x3 dgrad", "bn5 backward", "conv5 dgrad", "bn4 bwd finalize", "conv4 dgrad",
     "bn3 bwd finalize", "conv3 dgrad", "bn2 bwd finalize", "conv2 dgrad + layer-1 sums", "layer-1 gradients", "dense wgrad (grouped)",
@@ -227,10 +227,10 @@ struct PrepArgs {
 //   [12, 17) dense weights transposed for the data-gradient GEMMs
 //   17       atlas -> columns 540..555 of the fc_2 input rows (ConcatLayer elem_channels2, nets.py:224) + batch labels
 //   18       counter-based dropout keep-masks: one hash per element (splitmix64 finaliser), keep when the top bit is set
-__global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
+constexpr int kPrepJobs = kPackJobs + kTrJobs + 2, kPrepBlocks = 64;      // the first kPrepBlocks workgroups of a job row work on it
+__device__ __forceinline__ void prep_body(const PrepArgs& a, int job) {
     __shared__ float tile[32][33];
-    const int job = blockIdx.y;
-    const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    const int stride = kPrepBlocks * 256, t0 = blockIdx.x * 256 + threadIdx.x;
     if (job < kPackJobs) {
         const PackJob J = a.pack[job];
         const int tot = (J.cin / 4) * conv_chunk_floats(J.cout);
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void prep_kernel(PrepArgs a) {
         const TrProblem P = a.tr[job - kPackJobs];           // out[c][r] = in[r][c]
         const int tr_ = (P.rows + 31) / 32, tc_ = (P.cols + 31) / 32;
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        for (int tl = blockIdx.x; tl < tr_ * tc_; tl += gridDim.x) {
+        for (int tl = blockIdx.x; tl < tr_ * tc_; tl += kPrepBlocks) {
             const int r0 = (tl / tc_) * 32, c0 = (tl % tc_) * 32;
             __syncthreads();
 #pragma unroll
@@ -321,12 +321,12 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
 // P[px][9] = 1, D = P'P holds R[k][k'] = sum_px x0[px+k] x0[px+k'], S[k] = D[k][9] and the pixel count D[9][9].  One
 // matrix product per patch (both MFMA operands are the same register), `ppb` patches per workgroup, the four waves split
 // the rows.  Everything conv1's batch statistics and weight gradient need from the inputs (see bn1_final / l1_final).
-__global__ __launch_bounds__(256) void moments_kernel(X0Src x0, float* __restrict__ part /*[t][units][128]*/, int n, int ppb) {
+__device__ __forceinline__ void moments_body(const X0Src& x0, float* __restrict__ part /*[t][units][128]*/, int n, int ppb, int units, int t) {
     __shared__ __attribute__((aligned(16))) float s_x[1024 + 8];
     __shared__ float s_red[4][256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, kq = lane >> 4, t = blockIdx.y;
+    const int lr = lane & 15, kq = lane >> 4;
     const int toff = lr < 9 ? (lr / 3) * 32 + lr % 3 : 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int g0 = blockIdx.x * ppb, g1 = min(n, g0 + ppb);
@@ -348,7 +348,15 @@ __global__ __launch_bounds__(256) void moments_kernel(X0Src x0, float* __restric
     __syncthreads();
     const int m = tid >> 4, k = tid & 15;
     if (m < 10 && k < 10)
-        part[((size_t)t * gridDim.x + blockIdx.x) * 128 + m * 10 + k] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        part[((size_t)t * units + blockIdx.x) * 128 + m * 10 + k] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+}
+
+// First launch of a step: rows [0, kPrepJobs) of the grid are the prep jobs, rows kPrepJobs + t the input moments of tower t
+// (nothing in either half depends on the other; one launch instead of two on the step's critical path).
+__global__ __launch_bounds__(256) void prep_moments_kernel(PrepArgs a, X0Src x0, float* __restrict__ mom_part, int n, int ppb, int units) {
+    const int job = blockIdx.y;
+    if (job < kPrepJobs) { if ((int)blockIdx.x < kPrepBlocks) prep_body(a, job); }
+    else if ((int)blockIdx.x < units) moments_body(x0, mom_part, n, ppb, units, job - kPrepJobs);
 }
 
 // conv1's batch statistics from the input moments (z = sum_k wf[k] x0[. + k], wf = flipped filter):
@@ -810,6 +818,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // has been zero since the arena was allocated
 
     // ---- prep: operand packs (unfolded), transposed dense weights, atlas columns + batch labels, dropout masks
+    const int units1 = moment_units(n), ppb = (n + units1 - 1) / units1;
     const uint8_t* masks = masks_dev ? masks_dev : w->masks;
     const uint8_t* mask5 = masks;                                  // [3][n][540]
     const uint8_t* mask1 = masks + (size_t)3 * n * kFlat;          // f1_drop [n][540]
@@ -831,12 +840,12 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.n_rows = index ? x0.n_samples : n;
         pa.fc2W = P + H.fc2W; pa.w2p = w2p;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
-        run(ST_PREP, st, [&] { hipLaunchKernelGGL(prep_kernel, dim3(64, kPackJobs + kTrJobs + 2), dim3(256), 0, st, pa); });
+        // ---- forward, training mode: the input moments ride in the same launch
+        run(ST_PREP, st, [&] {
+            hipLaunchKernelGGL(prep_moments_kernel, dim3(std::max(units1, kPrepBlocks), kPrepJobs + kTowers), dim3(256), 0, st, pa, x0, w->mom_part, n,
+                               ppb, units1);
+        });
     }
-
-    // ---- forward, training mode
-    const int units1 = moment_units(n), ppb = (n + units1 - 1) / units1;
-    run(ST_MOMENTS, st, [&] { hipLaunchKernelGGL(moments_kernel, dim3(units1, kTowers), dim3(256), 0, st, x0, w->mom_part, n, ppb); });
     Ptr3 w1p{{w->w1p[0], w->w1p[1], w->w1p[2]}}, l1p{{w->l1p[0], w->l1p[1], w->l1p[2]}}, l1m{{w->l1m[0], w->l1m[1], w->l1m[2]}};
     run(ST_FIN1, st, [&] {
         hipLaunchKernelGGL(bn1_final_kernel, dim3(kTowers), dim3(1024), 0, st, w->mom_part, units1, n, P, T0.convW[0], T0.bn[0], kTowerFloats,

@@ -227,6 +227,21 @@ int main(int argc, char** argv) {
         run_conv<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3>>("DG3 without finalize", n, rounds, c3, true);
         return 0;
     }
+    if (!strcmp(what, "plane")) {
+        // LDS plane strides: the four k lanes of an A operand read planes 4c..4c+3, a stride of 16 mod 32 floats keeps the
+        // two planes of a half-wave on disjoint banks
+        run_conv<DG3>("DG3 (shipped)", n, rounds, c3, true);
+        run_conv<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 272, 1, 3, 0, 4, 1>>("DG3 PLANE 272", n, rounds, c3, true);
+        run_conv<DG2>("DG2 (shipped)", n, rounds, c2, true);
+        run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 272, 5, 4>>("DG2 PLANE 272", n, rounds, c2, true);
+        run_conv<TF12>("TF12 (shipped)", n, rounds, c1 + c2);
+        run_conv<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 208, 7, 4>>("TF12 PLANE 208", n, rounds, c1 + c2);
+        run_conv<TF5>("TF5 (shipped)", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 48, 1, 4>>("TF5 PLANE 48", n, rounds, c5);
+        run_conv<DG5>("DG5 (shipped)", n, rounds, c5, true);
+        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 80, 1, 4, 0, 4, 1>>("DG5 PLANE 80", n, rounds, c5, true);
+        return 0;
+    }
     if (!strcmp(what, "sweep")) {
         run_conv<TF12>("TF12 NB7 WPS4 (shipped)", n, rounds, c1 + c2);
         run_conv<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 6>>("TF12 NB7 WPS6", n, rounds, c1 + c2);

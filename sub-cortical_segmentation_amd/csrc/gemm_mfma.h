@@ -241,6 +241,20 @@ __global__ __launch_bounds__(512, 1) void gemm_splitk4_kernel(GemmArgs g) {
     const int col0 = n0 + 4 * lr;
     const bool col_ok = col0 < P.NS;                       // NS is a multiple of 4: a piece is inside or outside as a whole
     const float* __restrict__ wcol = P.W + col0;
+    // what the epilogue of waves 0..3 needs (bias, dropout mask, ReLU gate of its 4 outputs) is fetched with the operands:
+    // one global round trip per launch, not two
+    const int ecol = n0 + 4 * lr + wave;
+    float e_bias = 0.f, e_gate[4] = {1.f, 1.f, 1.f, 1.f};
+    unsigned char e_mask[4] = {1, 1, 1, 1};
+    if (wave < 4 && ecol < g.N) {
+        if (P.bias) e_bias = P.bias[ecol];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int orow = min(m0 + kq * 4 + r, g.M - 1);
+            if (P.mask) e_mask[r] = P.mask[(size_t)orow * P.ldm + ecol];
+            if (P.gate) e_gate[r] = P.gate[(size_t)orow * P.ldg + ecol];
+        }
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -274,13 +288,22 @@ __global__ __launch_bounds__(512, 1) void gemm_splitk4_kernel(GemmArgs g) {
         f32x4 v = s_r[(0 * 4 + j) * 64 + lane];
 #pragma unroll
         for (int q = 1; q < T::NW; ++q) { const f32x4 u = s_r[(q * 4 + j) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
-        const int col = n0 + 4 * lr + j;
-        if (col < g.N) {
-            const float bvv = P.bias ? P.bias[col] : 0.f;
+        if (ecol < g.N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int orow = m0 + kq * 4 + r;
-                if (orow < g.M) gemm_store(P, g.relu, orow, col, v[r] + bvv);
+                if (orow < g.M) {                                   // gemm_store with the prefetched mask / gate
+                    float o = v[r] + e_bias;
+                    if (g.relu) o = fmaxf(o, 0.f);
+                    if (P.C2) {
+                        P.C[(size_t)orow * P.ldc + ecol] = o;
+                        P.C2[(size_t)orow * P.ldc2 + ecol] = e_mask[r] ? 2.f * o : 0.f;
+                    } else {
+                        if (P.mask) o = e_mask[r] ? 2.f * o : 0.f;
+                        if (P.gate) o = e_gate[r] > 0.f ? o : 0.f;
+                        P.C[(size_t)orow * P.ldc + ecol] = o;
+                    }
+                }
             }
         }
     }

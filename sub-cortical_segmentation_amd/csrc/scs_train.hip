@@ -38,13 +38,13 @@ namespace scs {
 // profiling stages of scs_train_step_profiled (one per launch)
 enum Stage { ST_PREP, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
              ST_FC2, ST_HEAD, ST_DCAT, ST_DFEAT, ST_DH5, ST_BN5B, ST_DG5, ST_FINB4, ST_DG4, ST_FINB3, ST_DG3, ST_FINB2, ST_DG2,
-             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_COUNT };
+             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_COUNT };
 static const char* const kStageNames[ST_COUNT] = {
     "prep (weight packs, dropout masks, atlas columns) + input moments", "bn1 finalize", "conv1+conv2 fwd", "bn2 finalize",
     "conv3 fwd", "bn3 finalize", "conv4 fwd", "bn4 finalize", "conv5 fwd", "bn5 + dropout", "d1 x3 fwd", "FC1 fwd", "fc_2 fwd",
     "out + softmax + CE", "fc_2 dgrad", "FC1 dgrad", "d1 x3 dgrad", "bn5 backward", "conv5 dgrad", "bn4 bwd finalize", "conv4 dgrad",
     "bn3 bwd finalize", "conv3 dgrad", "bn2 bwd finalize", "conv2 dgrad + layer-1 sums", "layer-1 gradients", "dense wgrad (grouped)",
-    "conv5 wgrad", "conv4 wgrad", "conv3 wgrad", "conv2 wgrad", "conv wgrad reduce"};
+    "conv5 wgrad", "conv4 wgrad", "conv3 wgrad", "conv2 wgrad", "conv3..5 wgrad reduce", "conv2 wgrad reduce"};
 
 }  // namespace scs
 
@@ -372,6 +372,13 @@ __global__ __launch_bounds__(1024) void bn1_final_kernel(const float* __restrict
     if (e < 100) {
         const float* __restrict__ p = part + (size_t)t * units * 128 + e;
         int u = hh;
+        for (; u + 248 < units; u += 256) {                 // 32 units in flight: the 256 units of a training batch are one round trip
+            float r[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) r[q] = p[(size_t)(u + 8 * q) * 128];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) s += r[q];
+        }
         for (; u + 56 < units; u += 64) {
             float r[8];
 #pragma unroll
@@ -715,12 +722,12 @@ __global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict
 // sum of the partial weight gradients of ALL conv layers in a fixed order (deterministic): blockIdx.z = layer, 64 elements x
 // 4 groups of partials per block, 8 independent loads in flight per thread
 struct WgFinalJob { const float* part; int nsplit, cin, cout, w_off0; };
-struct WgFinalArgs { WgFinalJob j[4]; float* grads; int tower_stride; };
+struct WgFinalArgs { WgFinalJob j[4]; float* grads; int tower_stride; int z0; };      // blockIdx.z + z0 selects the job
 __global__ __launch_bounds__(256) void wgrad_final_kernel(WgFinalArgs a) {
     __shared__ float s_red[4][64];
     WgFinalJob J = a.j[0];
 #pragma unroll
-    for (int i = 1; i < 4; ++i) if ((int)blockIdx.z == i) J = a.j[i];
+    for (int i = 1; i < 4; ++i) if ((int)blockIdx.z + a.z0 == i) J = a.j[i];
     const int t = blockIdx.y, tot = J.cout * J.cin * 9;
     if ((int)blockIdx.x * 64 >= tot) return;
     const int ex = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -1005,14 +1012,21 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         else if (i == 2) run(ST_WG3, sd, [&] { wgrad_launch<WG3>(wa, sd); });
         else run(ST_WG2, sd, [&] { wgrad_launch<WG2>(wa, sd); });
         fa.j[i - 1] = WgFinalJob{part, wa.slices * kParts[i], kCin[i], C, T0.convW[i]};
+        if (i == 2) {
+            // partial sums of conv5..conv3 are reduced now, beside the conv2 data gradient (the conv2 weight gradient cannot start
+            // before that one ends): only conv2's own reduction is left for the tail of the step
+            fa.z0 = 1;
+            run(ST_WGFINAL, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, sd, fa); });
+        }
     }
-    // conv1 block: gradients from the layer-1 sums and the input moments (caller's stream); all conv weight-gradient
-    // partials are reduced by one launch on the side stream
+    // conv1 block: gradients from the layer-1 sums and the input moments (caller's stream); the conv2 weight-gradient
+    // partials are reduced on the side stream
     run(ST_L1FINAL, st, [&] {
         hipLaunchKernelGGL(l1_final_kernel, dim3(20, kTowers), dim3(256), 0, st, w->l1_part, n * kL1Bands, n, w->mom,
                            CPtr3{{w->l1p[0], w->l1p[1], w->l1p[2]}}, CPtr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, G, T0.convW[0], T0.bn[0], kTowerFloats);
     });
-    run(ST_WGFINAL, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 4), dim3(256), 0, sd, fa); });
+    fa.z0 = 0;
+    run(ST_WGFINAL2, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((20 * 20 * 9 + 63) / 64, kTowers, 1), dim3(256), 0, sd, fa); });
     join();                                   // every gradient is in the arena before the caller's stream goes on
     SCS_HIP(hipGetLastError());
     h->packed_dirty = true;          // BN running statistics moved

@@ -53,12 +53,14 @@ enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3, S
 
 // FIN_ = 1 (EPI_RAW_STATS / EPI_RAW_BNB*): the workgroup of a tower that finishes last also finalizes the batch-norm sums
 // (what a separate tiny launch would do: at training batch sizes a dependent launch costs ~10 us of latency, the tail ~2 us)
-template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4, int FIN_ = 0>
+template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4, int FIN_ = 0,
+          int NSPLIT_ = 0>
 struct ConvCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_, FIN = FIN_;
     static_assert(!FIN_ || (NW_ == 4 && (EPI_ == EPI_RAW_STATS || EPI_ == EPI_RAW_BNB || EPI_ == EPI_RAW_BNB_POOL)), "in-kernel finalize: 256-thread statistics kernels");
     static_assert(!FIN_ || NB_ == 1, "in-kernel finalize: the ticket words are sized for one workgroup per patch");
     static constexpr int NW = NW_, NTH = 64 * NW_;          // waves / threads per workgroup
+    static constexpr bool NSPLIT = NSPLIT_ != 0;            // one or two M tiles: the waves split the output channels (see the kernel)
     static constexpr bool PAD2 = (SRC_ == SRC_NCHW_PAD2 || SRC_ == SRC_DZ_PAD2 || SRC_ == SRC_DZ_POOL_PAD2);
     static constexpr bool FUSED1 = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME || SRC_ == SRC_X0);
     // PAD2: the global input is (HIN_-4)^2 and is zero-padded by 2 on every side in LDS (dgrad)
@@ -101,7 +103,8 @@ struct ConvCfg {
     static constexpr int L1_X_FLOATS = (HOB + 2) * 32 + 8, L1_TAB_FLOATS = 240, L1_RED_FLOATS = NW_ * 20 * 16;
     static constexpr int L1_PRE_FLOATS = EPI_ == EPI_L1 ? L1_X_FLOATS + L1_TAB_FLOATS : 0;
     static constexpr int EPI_FLOATS = OUT_FLOATS + (EPI_ == EPI_L1 ? L1_RED_FLOATS : 0);
-    static constexpr int MAIN_FLOATS = IN_FLOATS_AL + 2 * WCHUNK + XS_FLOATS;
+    static constexpr int WBUF_FLOATS = NSPLIT_ ? 0 : 2 * WCHUNK;   // double-buffered weight chunks (NSPLIT: operands come straight from global memory)
+    static constexpr int MAIN_FLOATS = IN_FLOATS_AL + WBUF_FLOATS + XS_FLOATS;
     static_assert(EPI_ != EPI_L1 || EPI_FLOATS <= MAIN_FLOATS, "EPI_L1 scratch must not reach the prefetched input rows");
     static constexpr size_t LDS_BYTES = (size_t)((MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS) + L1_PRE_FLOATS) * 4;
     static_assert(CIN_ % 4 == 0, "k-steps are groups of 4 input channels");
@@ -116,6 +119,9 @@ struct ConvCfg {
     static_assert(SRC_ != SRC_DZ_POOL_PAD2 || (HINB % 2 == 0 && HIN_ % 2 == 0 && PLANE_ % 2 == 0 && (NB_ == 1 || HOB % 2 == 0)),
                   "pooled d z staging walks 2x2 windows");
     static_assert(EPI_ != EPI_L1 || (COUT_ == 20 && HO == 30 && G_ == 1 && NW_ == 4), "EPI_L1 is the conv2 data gradient");
+    static_assert(!NSPLIT_ || (NW_ == 4 && RAW && !FUSED1 && EPI_ != EPI_L1 && NT16 == NT4 &&
+                               ((TILES == 1 && NT16 <= 4) || (TILES == 2 && NT16 == 2))),
+                  "NSPLIT: raw training kernels with one M tile (a wave per 16 + 4 channel block pair) or two (tile x pair)");
 };
 
 // the 32x32 input patches of a training batch: given as three [n][32][32] arrays, or cut on the fly from z-scored
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + C::IN_FLOATS_AL;
-    float* s_x = s_w + 2 * C::WCHUNK;     // only when XS_FLOATS > 0: raw rows of the 32x32 patch
+    float* s_x = s_w + C::WBUF_FLOATS;    // only when XS_FLOATS > 0: raw rows of the 32x32 patch
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -462,10 +468,12 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     // (named registers, clamped indices: an indexed array here ends up in scratch behind a vmcnt(0))
     static_assert(C::WPT <= 3, "weight chunk prefetch holds at most 3 float4 per thread");
     const int wi0 = min(tid, C::WCHUNK4 - 1), wi1 = min(tid + C::NTH, C::WCHUNK4 - 1), wi2 = min(tid + 2 * C::NTH, C::WCHUNK4 - 1);
-    float4 wr0, wr1, wr2;
-    wr0 = reinterpret_cast<const float4*>(wsrc)[wi0];
-    if constexpr (C::WPT > 1) wr1 = reinterpret_cast<const float4*>(wsrc)[wi1];
-    if constexpr (C::WPT > 2) wr2 = reinterpret_cast<const float4*>(wsrc)[wi2];
+    float4 wr0 = {0.f, 0.f, 0.f, 0.f}, wr1 = wr0, wr2 = wr0;
+    if constexpr (!C::NSPLIT) {
+        wr0 = reinterpret_cast<const float4*>(wsrc)[wi0];
+        if constexpr (C::WPT > 1) wr1 = reinterpret_cast<const float4*>(wsrc)[wi1];
+        if constexpr (C::WPT > 2) wr2 = reinterpret_cast<const float4*>(wsrc)[wi2];
+    }
 
     // per-lane epilogue bias, fetched now so its latency hides under the staging
     float bvs[C::NT16 > 0 ? C::NT16 : 1], bv4[C::NT4 > 0 ? C::NT4 : 1];
@@ -764,13 +772,92 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         if (tid < 240) s_x0[C::L1_X_FLOATS + tid] = l1tab;
     }
     // ---- weight chunk 0 -> LDS
-    {
+    if constexpr (!C::NSPLIT) {
         float4* dst = reinterpret_cast<float4*>(s_w);
         if (tid < C::WCHUNK4) dst[tid] = wr0;
         if constexpr (C::WPT > 1) { if (tid + C::NTH < C::WCHUNK4) dst[tid + C::NTH] = wr1; }
         if constexpr (C::WPT > 2) { if (tid + 2 * C::NTH < C::WCHUNK4) dst[tid + 2 * C::NTH] = wr2; }
     }
 
+    if constexpr (C::NSPLIT) {
+        // One or two M tiles per workgroup (the 3x3 / 5x5 outputs of the conv5 block): with tiles dealt to waves, one or two
+        // waves would do all the matrix work behind a barrier per weight chunk.  Instead wave w owns the channel pair
+        // (16-block p, 4-block p) of tile t: one tile -> (t, p) = (0, w), two tiles -> (w & 1, w >> 1).  Its B operands come
+        // straight from global memory (they are shared by every workgroup and sit in L2), four chunks ahead in registers:
+        // no weight buffer in LDS, no barrier inside the loop.
+        constexpr bool TWO = C::TILES == 2;
+#ifndef SCS_NS_DEPTH
+#define SCS_NS_DEPTH 4
+#endif
+        constexpr int DEPTH = SCS_NS_DEPTH;
+        const int tj = TWO ? (wave & 1) : 0, pr = TWO ? (wave >> 1) : wave;
+        const bool active = pr < C::NT16;
+        int abase_n;
+        {
+            const int m = min(tj * 16 + lr, C::MTOT - 1);
+            const int g = m / C::PIXB, r = m - g * C::PIXB, y = r / C::HO, x = r - y * C::HO;
+            abase_n = (g * C::CIN + kq) * C::PLANE + y * C::WIN + x;
+        }
+        const int prc = min(pr, C::NT16 - 1);
+        const float* __restrict__ wb = wsrc + kq * C::NS16 + lr + prc * 16;                          // W[k = 4s + kq][cout = 16 p + lr]
+        const float* __restrict__ wl = wsrc + 36 * C::NS16 + kq * C::L4 + (lane & 3) + prc * 4;      // W[k = 4s + kq][cout = 16 NT16 + 4 p + (lane & 3)]
+        f32x4 accn = {0.f, 0.f, 0.f, 0.f}, acc4n = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                     // the staged planes are visible
+        if constexpr (C::STAMP) { if (tid == 0) stp[2] = __builtin_amdgcn_s_memtime(); }
+        if (active) {
+            float bq[DEPTH][9], lq[DEPTH][9];
+#pragma unroll
+            for (int c = 0; c < DEPTH - 1; ++c)
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int cc = min(c, C::NC4 - 1);
+                    bq[c][tap] = wb[cc * C::WCHUNK + tap * 4 * C::NS16];
+                    lq[c][tap] = wl[cc * C::WCHUNK + tap * 4 * C::L4];
+                }
+            // the A operands of a chunk (9 LDS reads) are requested one chunk ahead as well: a wave has nothing else to
+            // hide an LDS round trip per MFMA behind
+            float aq[2][9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) aq[0][tap] = s_in[abase_n + (tap / 3) * C::WIN + (tap % 3)];
+#pragma unroll
+            for (int c4 = 0; c4 < C::NC4; ++c4) {
+                if (c4 + DEPTH - 1 < C::NC4) {
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        bq[(c4 + DEPTH - 1) % DEPTH][tap] = wb[(c4 + DEPTH - 1) * C::WCHUNK + tap * 4 * C::NS16];
+                        lq[(c4 + DEPTH - 1) % DEPTH][tap] = wl[(c4 + DEPTH - 1) * C::WCHUNK + tap * 4 * C::L4];
+                    }
+                }
+                if (c4 + 1 < C::NC4) {
+                    const float* __restrict__ sa = s_in + (c4 + 1) * 4 * C::PLANE + abase_n;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) aq[(c4 + 1) & 1][tap] = sa[(tap / 3) * C::WIN + (tap % 3)];
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float av = aq[c4 & 1][tap];
+                    accn = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[c4 % DEPTH][tap], accn, 0, 0, 0);
+                    acc4n = __builtin_amdgcn_mfma_f32_4x4x1f32(lq[c4 % DEPTH][tap], av, acc4n, 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (C::STAMP) { if (tid == 0) stp[3] = __builtin_amdgcn_s_memtime(); }
+        __syncthreads();                                     // every wave has read its planes: the LDS becomes the output stage
+        float* s_o = smem;
+        const float val4 = ksub_reduce(acc4n, kq, (lane ^ 32) << 2);                                // this lane: cout 16 NT16 + 4 p + kq
+        if (active) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int m = tj * 16 + kq * 4 + r4;
+                if (m < C::MTOT) { const int g = m / C::PIXB, r = m - g * C::PIXB; s_o[(g * C::COUT + pr * 16 + lr) * C::OSTR + r] = accn[r4]; }
+            }
+            const int m = tj * 16 + (lane & 15);
+            if (m < C::MTOT) { const int g = m / C::PIXB, r = m - g * C::PIXB; s_o[(g * C::COUT + C::NT16 * 16 + pr * 4 + kq) * C::OSTR + r] = val4; }
+        }
+        if constexpr (C::STAMP) { if (tid == 0) stp[6] = __builtin_amdgcn_s_memtime(); }
+        __syncthreads();
+        if constexpr (C::STAMP) { if (tid == 0) stp[7] = __builtin_amdgcn_s_memtime(); }
+    } else {
     // ---- per-lane A base offsets (floats) for the wave's tiles; out-of-range tiles are clamped, never stored
     int abase[C::TPW];
 #pragma unroll
@@ -931,6 +1018,8 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     if constexpr (C::STAMP) { if (tid == 0) stp[6] = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
     if constexpr (C::STAMP) { if (tid == 0) stp[7] = __builtin_amdgcn_s_memtime(); }
+    }   // !NSPLIT
+    float* s_o = smem;
     if constexpr (C::EPI != EPI_L1) {
         float* __restrict__ outp = pick3(a.out, tower) + (size_t)g0 * C::COUT * C::OUTPIX + band * C::OUTB;
         if constexpr (C::OUT_VEC4) {

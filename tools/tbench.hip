@@ -242,6 +242,17 @@ int main(int argc, char** argv) {
         run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 80, 1, 4, 0, 4, 1>>("DG5 PLANE 80", n, rounds, c5, true);
         return 0;
     }
+    if (!strcmp(what, "ns")) {
+        // conv5 block (one / two M tiles per patch): tiles dealt to waves + weight chunks through LDS, against the waves
+        // splitting the output channels with operands straight from L2 (NSPLIT)
+        run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4>>("TF5 tiles over waves", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 0, 4, 0, 1>>("TF5 NSPLIT", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 6, 0, 4, 0, 1>>("TF5 NSPLIT WPS6", n, rounds, c5);
+        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1>>("DG5 tiles over waves (FIN)", n, rounds, c5, true);
+        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1, 1>>("DG5 NSPLIT (FIN)", n, rounds, c5, true);
+        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 6, 0, 4, 1, 1>>("DG5 NSPLIT WPS6 (FIN)", n, rounds, c5, true);
+        return 0;
+    }
     if (!strcmp(what, "sweep")) {
         run_conv<TF12>("TF12 NB7 WPS4 (shipped)", n, rounds, c1 + c2);
         run_conv<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 6>>("TF12 NB7 WPS6", n, rounds, c1 + c2);
@@ -300,6 +311,8 @@ int main(int argc, char** argv) {
         stamps<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4, 1>>("TF4", n);
         stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1>>("TF5", n);
         stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1>>("DG5", n);
+        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1, 4, 0, 1>>("DG5 NSPLIT", n);
+        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1, 4, 0, 1>>("TF5 NSPLIT", n);
     }
     if (all || !strcmp(what, "wg")) {
         run_wg<WG2>("WG2 (shipped)", n, 64, rounds, c2);

@@ -87,6 +87,10 @@ struct ConvCfg {
     static constexpr int TILES = (MTOT + 15) / 16;
     static constexpr int TPW = (TILES + NW - 1) / NW;   // tiles per wave (wave w owns tiles w, w+NW, ...)
     static constexpr bool LAST_RAGGED = (NW - 1 + NW * (TPW - 1)) >= TILES;   // some waves lack their last tile
+    // TILES = NW * q + 1 (9 or 13 tiles on 4 waves): instead of one wave owning the odd tile - and every other wave waiting
+    // for it - its channel blocks are dealt to the waves: 16-block b to wave b, the 4-blocks to wave NT16 (training kernels)
+    static constexpr bool SHARED = (EPI_ >= EPI_RAW) && !NSPLIT_ && !POOL && TILES > NW && TILES % NW == 1 &&
+                                   (nt16(COUT_) + (nt4(COUT_) > 0 ? 1 : 0)) <= NW;
     static constexpr int WCHUNK = conv_chunk_floats(COUT_);   // floats per weight chunk
     static constexpr int WCHUNK4 = WCHUNK / 4;
     static constexpr int WPT = (WCHUNK4 + NTH - 1) / NTH;   // float4 per thread per chunk
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     int abase[C::TPW];
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
-        int m = (wave + C::NW * j) * 16 + lr;
+        int m = ((C::SHARED && j == C::TPW - 1) ? C::TILES - 1 : wave + C::NW * j) * 16 + lr;
         int g, y, x;
         if constexpr (C::POOL) {
             int widx = min(m >> 2, C::G * C::WB - 1);
@@ -916,7 +920,23 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             for (int u = 0; u < C::NT4; ++u) b4[u] = sw[loff + tap * 4 * C::L4 + u * 4];
 #pragma unroll
             for (int j = 0; j < C::TPW; ++j) {
-                if (C::LAST_RAGGED && j == C::TPW - 1 && !last_ok) continue;   // wave-uniform: this wave has no such tile
+                if constexpr (C::SHARED) {
+                    if (j == C::TPW - 1) {                                     // the odd tile: this wave's share of its channel blocks
+                        if (wave <= C::NT16) {
+                            const float av = sa[abase[j] + toff];
+#pragma unroll
+                            for (int nt = 0; nt < C::NT16; ++nt)
+                                if (wave == nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[j][nt], 0, 0, 0);
+                            if (wave == C::NT16) {
+#pragma unroll
+                                for (int u = 0; u < C::NT4; ++u)
+                                    acc4[j][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[j][u], 0, 0, 0);
+                            }
+                        }
+                        continue;
+                    }
+                }
+                if (!C::SHARED && C::LAST_RAGGED && j == C::TPW - 1 && !last_ok) continue;   // wave-uniform: this wave has no such tile
                 const float av = sa[abase[j] + toff];
 #pragma unroll
                 for (int nt = 0; nt < C::NT16; ++nt)
@@ -945,10 +965,12 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     float* s_o = smem;
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
-        const int t = wave + C::NW * j;
+        const bool odd = C::SHARED && j == C::TPW - 1;
+        const int t = odd ? C::TILES - 1 : wave + C::NW * j;
         if (t >= C::TILES) continue;
 #pragma unroll
         for (int nt = 0; nt < C::NT16; ++nt) {
+            if (odd && wave != nt) continue;                                   // the odd tile: wave nt holds this block
             const int co = nt * 16 + lr;
             const float bv = bvs[nt];
             if constexpr (C::POOL) {
@@ -990,8 +1012,9 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         }
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
-        const int t = wave + C::NW * j;
-        if (t >= C::TILES) continue;
+        const bool odd = C::SHARED && j == C::TPW - 1;
+        const int t = odd ? C::TILES - 1 : wave + C::NW * j;
+        if (t >= C::TILES || (odd && wave != C::NT16)) continue;               // the odd tile: wave NT16 holds the 4-blocks
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
             float val = lval[j][u];

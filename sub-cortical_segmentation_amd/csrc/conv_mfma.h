@@ -444,6 +444,59 @@ __device__ __forceinline__ void load_x0_rows(const X0Src& s, int tower, int g, i
     }
 }
 
+// The same rows held in registers between the request and the LDS write (software-pipelined callers: wgrad_mfma.h)
+template <int NROWS, int NTH>
+struct X0RowRegs {
+    static constexpr int N4 = (NROWS * 8 + NTH - 1) / NTH, NS = (NROWS * 32 + NTH - 1) / NTH;
+    float4 v4[N4];
+    float vs[NS];
+    bool dense;
+    __device__ __forceinline__ void load(const X0Src& s, int tower, int g, int row0, int tid) {
+        const float* __restrict__ v = pick3(s.views, tower);
+        dense = v != nullptr;
+        if (dense) {
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(v + (size_t)g * 1024 + row0 * 32);
+#pragma unroll
+            for (int k = 0; k < N4; ++k) v4[k] = src[min(k * NTH + tid, NROWS * 8 - 1)];
+        } else {
+            const int4 smp = x0_sample(s, g);
+            const scs_volume d = s.descs[smp.x];
+            const float* __restrict__ vol = s.vols + d.offset;
+            const int fl = s.flips ? (s.flips[g] >> (2 * tower)) & 3 : 0;
+            const int fi = (fl & 1) ? 31 : 0, fj = (fl & 2) ? 31 : 0;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int e = min(k * NTH + tid, NROWS * 32 - 1);
+                vs[k] = gather_voxel(vol, d.dim_x, d.dim_y, d.dim_z, tower, smp.y, smp.z, smp.w, (row0 + (e >> 5)) ^ fi, (e & 31) ^ fj);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ s_x, int tid) const {
+        if (dense) {
+#pragma unroll
+            for (int k = 0; k < N4; ++k) { const int e = k * NTH + tid; if (e < NROWS * 8) reinterpret_cast<float4*>(s_x)[e] = v4[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { const int e = k * NTH + tid; if (e < NROWS * 32) s_x[e] = vs[k]; }
+        }
+    }
+};
+
+// TOTAL elements of type V, element e = tid + NTH k, held in registers between load() and store()
+template <int TOTAL, class V, int NTH = 256>
+struct StagedRegs {
+    static constexpr int ITER = (TOTAL + NTH - 1) / NTH;
+    V v[ITER];
+    template <class SrcF> __device__ __forceinline__ void load(int tid, SrcF&& src_of) {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) v[k] = src_of(min(tid + NTH * k, TOTAL - 1));
+    }
+    template <class DstF> __device__ __forceinline__ void store(int tid, DstF&& dst_of) const {
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) { const int e = tid + NTH * k; if (e < TOTAL) dst_of(e, v[k]); }
+    }
+};
+
 template <class C>
 __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -26,7 +26,7 @@ constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 // forming it again here costs 3-15 us per layer - tools/tbench.hip); conv2's X is the recomputed conv1 block output.
 using WG2 = WgCfg<20, 20, 30, 4, 3, 1, 0, 1>;
 using WG3 = WgCfg<20, 40, 14, 2, 3, 0, 0, 1>;
-using WG4 = WgCfg<40, 40, 12, 5, 3, 0, 0, 1>;
+using WG4 = WgCfg<40, 40, 12, 5, 2, 0, 0, 1, 1>;     // software-pipelined staging (8 patches per workgroup)
 using WG5 = WgCfg<40, 60, 5, 1, 2, 0, 0, 1>;
 constexpr size_t kWgPartFloats = (size_t)256 * 60 * 40 * 9;   // per tower and layer: room for 256 partials of the largest layer
 constexpr int kL1Bands = DG2::NB;

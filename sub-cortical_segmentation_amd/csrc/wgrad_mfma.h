@@ -18,13 +18,17 @@
 //   ZSRC 1  d z = [sc z + sh > 0] sc dUp + ca z + cb is computed while staging from the layer's raw output z and the
 //           upstream gradient dUp (same form as conv_mfma.h SRC_DZ_PAD2);  ZSRC 2: the same through a 2x2 max-pool.
 #pragma once
+#include <type_traits>
+
 #include "conv_mfma.h"
 
 namespace scs {
 
-template <int CIN_, int COUT_, int HIN_, int NB_ = 1, int WPC_ = 1, int XSRC_ = 0, int ZSRC_ = 0, int GP_ = 1>
+template <int CIN_, int COUT_, int HIN_, int NB_ = 1, int WPC_ = 1, int XSRC_ = 0, int ZSRC_ = 0, int GP_ = 1, int PIPE_ = 0>
 struct WgCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2, XSRC = XSRC_, ZSRC = ZSRC_, GP = GP_;
+    static constexpr bool PIPE = PIPE_ != 0;                 // one patch per round, the next patch's loads in flight during the matrix phase
+    static_assert(!PIPE_ || (GP_ == 1 && ZSRC_ == 0), "the pipelined walk stages one patch from stored d z");
     // a workgroup owns band `b` of NB bands of output rows (HOB rows of dz, HOB + 2 rows of X) of the patches of its
     // batch slice: smaller LDS footprint -> WPC workgroups share a CU and overlap staging with the matrix phase
     static constexpr int NB = NB_, WPC = WPC_, HOB = HO / NB_, HXB = HOB + 2;
@@ -104,6 +108,82 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
         for (int u = 0; u < C::NT4; ++u) acc4[m][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // the matrix phase of one staged patch (all of its band's output rows)
+    auto mma_patch = [&](int g) {
+#pragma unroll 1
+        for (int y = 0; y < C::HOB; ++y) {
+            const float* __restrict__ sxr = s_x + g * C::X_FLOATS + y * C::HIN;
+            const float* __restrict__ szr = s_z + g * C::Z_FLOATS + y * C::WOP;
+#pragma unroll
+            for (int xg = 0; xg < C::WOP / 4; ++xg) {
+                float b[C::NT16 > 0 ? C::NT16 : 1], b4[C::NT4 > 0 ? C::NT4 : 1];
+#pragma unroll
+                for (int nt = 0; nt < C::NT16; ++nt) b[nt] = szr[zoff16 + nt * 16 * C::ZPL + 4 * xg];
+#pragma unroll
+                for (int u = 0; u < C::NT4; ++u) b4[u] = szr[zoff4 + u * 4 * C::ZPL + 4 * xg];
+#pragma unroll
+                for (int m = 0; m < C::MTW; ++m) {
+                    if ((3 + 4 * m) >= C::MT && (wave + 4 * m) >= C::MT) continue;   // wave-uniform: no such row tile
+                    const float av = sxr[xbase[m] + 4 * xg];
+#pragma unroll
+                    for (int nt = 0; nt < C::NT16; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[m][nt], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < C::NT4; ++u)
+                        acc4[m][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[m][u], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if constexpr (C::PIPE) {
+        // One patch per round, software-pipelined: the global loads of patch p + 1 are issued before the matrix phase of patch p
+        // and land in LDS after it (a workgroup walks 4-8 patches; without this every one of them exposes a global round trip
+        // that only the one or two other workgroups of the CU could hide).
+        constexpr int HW = C::HIN * C::HIN, XB = C::HXB * C::HIN, PZ = C::HO * C::HO, ZB = C::HOB * C::HO;
+        constexpr int XV = (HW % 4 == 0 && XB % 4 == 0 && (C::HOB * C::HIN) % 4 == 0) ? 4
+                         : (HW % 2 == 0 && XB % 2 == 0 && (C::HOB * C::HIN) % 2 == 0) ? 2 : 1;
+        constexpr int ZV = (C::WOP == C::HO && PZ % 4 == 0 && ZB % 4 == 0) ? 4 : 1;
+        using VX = typename std::conditional<XV == 4, float4, typename std::conditional<XV == 2, float2, float>::type>::type;
+        using VZ = typename std::conditional<ZV == 4, float4, float>::type;
+        StagedRegs<C::XSRC == 1 ? 1 : C::CIN * XB / XV, VX> rx;
+        StagedRegs<C::COUT * ZB / ZV, VZ> rz;
+        X0RowRegs<C::X0_ROWS, 256> r0;
+        auto request = [&](int nb) {
+            if constexpr (C::XSRC == 1) {
+                r0.load(a.x0, tower, nb, y0, tid);
+            } else {
+                const float* __restrict__ xs = pick3(a.X, tower) + (size_t)nb * C::CIN * HW + y0 * C::HIN;
+                rx.load(tid, [&](int e) { const int pl = e / (XB / XV), r = e - pl * (XB / XV); return reinterpret_cast<const VX*>(xs + (size_t)pl * HW)[r]; });
+            }
+            const float* __restrict__ zs = pick3(a.dZ, tower) + (size_t)nb * C::COUT * PZ + y0 * C::HO;
+            rz.load(tid, [&](int e) { const int pl = e / (ZB / ZV), r = e - pl * (ZB / ZV); return reinterpret_cast<const VZ*>(zs + (size_t)pl * PZ)[r]; });
+        };
+        auto commit = [&]() {
+            if constexpr (C::XSRC == 1) {
+                r0.store(s_x0, tid);
+            } else {
+                rx.store(tid, [&](int e, VX v) { const int c = e / (XB / XV), r = e - c * (XB / XV); reinterpret_cast<VX*>(s_x)[c * (C::XPL / XV) + r] = v; });
+            }
+            if constexpr (ZV == 4) {
+                rz.store(tid, [&](int e, VZ v) { const int o = e / (ZB / 4), r = e - o * (ZB / 4); reinterpret_cast<VZ*>(s_z)[o * (C::ZPL / 4) + r] = v; });
+            } else {
+                rz.store(tid, [&](int e, VZ v) { const int o = e / ZB, r = e - o * ZB, y = r / C::HO, x = r - y * C::HO; s_z[o * C::ZPL + y * C::WOP + x] = v; });
+            }
+        };
+        if (n0 < n1) request(n0);
+        for (int nb = n0; nb < n1; ++nb) {
+            __syncthreads();                                               // previous patch consumed (and the zero fill)
+            commit();
+            __syncthreads();
+            if constexpr (C::XSRC == 1) {
+                conv1_to_lds<C::XPL, C::HXB, 4>(s_x0, s_w1, s_x, wave, lane);
+                __syncthreads();
+            }
+            if (nb + 1 < n1) request(nb + 1);
+            mma_patch(0);
+        }
+    } else
     for (int nb = n0; nb < n1; nb += C::GP) {
         __syncthreads();                                                   // previous round consumed (and the zero fill)
         const int ng = min(C::GP, n1 - nb);                                // patches of this round; the others keep d z = 0

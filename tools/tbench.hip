@@ -253,6 +253,18 @@ int main(int argc, char** argv) {
         run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 6, 0, 4, 1, 1>>("DG5 NSPLIT WPS6 (FIN)", n, rounds, c5, true);
         return 0;
     }
+    if (!strcmp(what, "wgs")) {
+        // weight-gradient kernels with and without the software-pipelined staging, over the number of batch slices
+        for (int sl : {64, 32}) run_wg<WgCfg<20, 20, 30, 4, 3, 1, 0, 1, 0>>("WG2", n, sl, rounds, c2);
+        for (int sl : {64, 32}) run_wg<WgCfg<20, 20, 30, 4, 3, 1, 0, 1, 1>>("WG2 pipelined", n, sl, rounds, c2);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<20, 40, 14, 2, 3, 0, 0, 1, 0>>("WG3", n, sl, rounds, c3);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<20, 40, 14, 2, 3, 0, 0, 1, 1>>("WG3 pipelined", n, sl, rounds, c3);
+        for (int sl : {64, 32, 16}) run_wg<WgCfg<40, 40, 12, 5, 3, 0, 0, 1, 0>>("WG4", n, sl, rounds, c4);
+        for (int sl : {64, 32, 16}) run_wg<WgCfg<40, 40, 12, 5, 2, 0, 0, 1, 1>>("WG4 pipelined WPC2", n, sl, rounds, c4);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 1, 0>>("WG5", n, sl, rounds, c5);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 1, 1>>("WG5 pipelined", n, sl, rounds, c5);
+        return 0;
+    }
     if (!strcmp(what, "sweep")) {
         run_conv<TF12>("TF12 NB7 WPS4 (shipped)", n, rounds, c1 + c2);
         run_conv<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 6>>("TF12 NB7 WPS6", n, rounds, c1 + c2);

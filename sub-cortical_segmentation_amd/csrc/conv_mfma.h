@@ -915,11 +915,19 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         __syncthreads();
         if constexpr (C::STAMP) { if (tid == 0) stp[7] = __builtin_amdgcn_s_memtime(); }
     } else {
+    // Tile ownership rotates with the workgroup: wave w of workgroup b owns tiles (w + b) mod NW, + NW, ...  When the tiles do
+    // not divide by the waves (25 = 7 + 6 + 6 + 6, 7 = 2 + 2 + 2 + 1) the short share would otherwise always fall on the same
+    // waves - and with one wave of every workgroup per SIMD, always on the same SIMDs of the CU.
+#ifndef SCS_TILE_ROT
+#define SCS_TILE_ROT 1
+#endif
+    const int wt = SCS_TILE_ROT ? ((wave + (int)blockIdx.x) & (C::NW - 1)) : wave;
+    static_assert((C::NW & (C::NW - 1)) == 0, "waves per workgroup: a power of two");
     // ---- per-lane A base offsets (floats) for the wave's tiles; out-of-range tiles are clamped, never stored
     int abase[C::TPW];
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
-        int m = ((C::SHARED && j == C::TPW - 1) ? C::TILES - 1 : wave + C::NW * j) * 16 + lr;
+        int m = ((C::SHARED && j == C::TPW - 1) ? C::TILES - 1 : wt + C::NW * j) * 16 + lr;
         int g, y, x;
         if constexpr (C::POOL) {
             int widx = min(m >> 2, C::G * C::WB - 1);
@@ -953,7 +961,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 
     const int boff = kq * C::NS16 + lr;                       // main part: W[k = 4s + kq][cout = 16 nt + lr]
     const int loff = 36 * C::NS16 + kq * C::L4 + (lane & 3);   // leftover: W[k = 4s + kq][cout = 16 NT16 + 4u + (lane&3)]
-    const bool last_ok = (wave + C::NW * (C::TPW - 1)) < C::TILES;
+    const bool last_ok = (wt + C::NW * (C::TPW - 1)) < C::TILES;
     for (int c4 = 0; c4 < C::NC4; ++c4) {
         if (c4 + 1 < C::NC4) {
             const float4* __restrict__ src = reinterpret_cast<const float4*>(wsrc + (size_t)(c4 + 1) * C::WCHUNK);
@@ -975,12 +983,12 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             for (int j = 0; j < C::TPW; ++j) {
                 if constexpr (C::SHARED) {
                     if (j == C::TPW - 1) {                                     // the odd tile: this wave's share of its channel blocks
-                        if (wave <= C::NT16) {
+                        if (wt <= C::NT16) {
                             const float av = sa[abase[j] + toff];
 #pragma unroll
                             for (int nt = 0; nt < C::NT16; ++nt)
-                                if (wave == nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[j][nt], 0, 0, 0);
-                            if (wave == C::NT16) {
+                                if (wt == nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[j][nt], 0, 0, 0);
+                            if (wt == C::NT16) {
 #pragma unroll
                                 for (int u = 0; u < C::NT4; ++u)
                                     acc4[j][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[j][u], 0, 0, 0);
@@ -1019,11 +1027,11 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
         const bool odd = C::SHARED && j == C::TPW - 1;
-        const int t = odd ? C::TILES - 1 : wave + C::NW * j;
+        const int t = odd ? C::TILES - 1 : wt + C::NW * j;
         if (t >= C::TILES) continue;
 #pragma unroll
         for (int nt = 0; nt < C::NT16; ++nt) {
-            if (odd && wave != nt) continue;                                   // the odd tile: wave nt holds this block
+            if (odd && wt != nt) continue;                                   // the odd tile: wave nt holds this block
             const int co = nt * 16 + lr;
             const float bv = bvs[nt];
             if constexpr (C::POOL) {
@@ -1066,8 +1074,8 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 #pragma unroll
     for (int j = 0; j < C::TPW; ++j) {
         const bool odd = C::SHARED && j == C::TPW - 1;
-        const int t = odd ? C::TILES - 1 : wave + C::NW * j;
-        if (t >= C::TILES || (odd && wave != C::NT16)) continue;               // the odd tile: wave NT16 holds the 4-blocks
+        const int t = odd ? C::TILES - 1 : wt + C::NW * j;
+        if (t >= C::TILES || (odd && wt != C::NT16)) continue;               // the odd tile: wave NT16 holds the 4-blocks
 #pragma unroll
         for (int u = 0; u < C::NT4; ++u) {
             float val = lval[j][u];

@@ -921,8 +921,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
 #ifndef SCS_TILE_ROT
 #define SCS_TILE_ROT 1
 #endif
-    const int wt = SCS_TILE_ROT ? ((wave + (int)blockIdx.x) & (C::NW - 1)) : wave;
-    static_assert((C::NW & (C::NW - 1)) == 0, "waves per workgroup: a power of two");
+    const int wt = (SCS_TILE_ROT && (C::NW & (C::NW - 1)) == 0) ? ((wave + (int)blockIdx.x) & (C::NW - 1)) : wave;
     // ---- per-lane A base offsets (floats) for the wave's tiles; out-of-range tiles are clamped, never stored
     int abase[C::TPW];
 #pragma unroll

@@ -1284,7 +1284,10 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         f32x4 am4[4], al4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { am4[q] = f32x4{0.f, 0.f, 0.f, 0.f}; al4[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        for (int r = wave; r < C::HOB; r += C::NW) {
+#pragma unroll
+        for (int ri = 0; ri < (C::HOB + C::NW - 1) / C::NW; ++ri) {     // unrolled: a runtime trip count makes the eight accumulators
+            const int r = wave + C::NW * ri;                             // loop-carried copies (32 v_mov per round)
+            if (r >= C::HOB) break;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int x = 4 * j + kq;

@@ -52,7 +52,12 @@ enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3, S
                SRC_DZ_POOL_PAD2 = 7, SRC_X0 = 8 };
 
 // FIN_ = 1 (EPI_RAW_STATS / EPI_RAW_BNB*): the workgroup of a tower that finishes last also finalizes the batch-norm sums
-// (what a separate tiny launch would do: at training batch sizes a dependent launch costs ~10 us of latency, the tail ~2 us)
+// (what a separate tiny launch would do: in the stream that launch costs ~9 us, the tail 5-6 us - two-level arrival tickets,
+// see arrive_last).
+// NSPLIT_ = 1 (one or two M tiles per workgroup - the conv5 block): the waves split the output channels instead of the
+// tiles, B operands come straight from global memory; no weight buffer in LDS.
+// Derived: SHARED (4q + 1 tiles on 4 waves: the odd tile's channel blocks are dealt to the waves); tile ownership rotates
+// with the workgroup index (see the kernel).
 template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4, int FIN_ = 0,
           int NSPLIT_ = 0>
 struct ConvCfg {

@@ -315,16 +315,16 @@ int main(int argc, char** argv) {
     if (all || !strcmp(what, "stamps")) {
         stamps<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 256, 5, 4, 1>>("DG2", n);
         stamps<ConvCfg<20, 20, 32, 1, EPI_RAW, SRC_NCHW_PAD2, 256, 5, 4, 1>>("DG2 plain", n);
-        stamps<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 144, 2, 4, 1>>("DG3", n);
-        stamps<ConvCfg<40, 20, 16, 1, EPI_RAW, SRC_NCHW_PAD2, 144, 2, 4, 1>>("DG3 plain", n);
+        stamps<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3, 1>>("DG3", n);
+        stamps<ConvCfg<40, 20, 16, 1, EPI_RAW, SRC_NCHW_PAD2, 256, 1, 3, 1>>("DG3 plain", n);
         stamps<ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3, 1>>("DG4", n);
         stamps<ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 4, 1>>("TF12", n);
         stamps<ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 208, 1, 4, 1>>("TF3", n);
         stamps<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4, 1>>("TF4", n);
-        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1>>("TF5", n);
-        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1>>("DG5", n);
-        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1, 4, 0, 1>>("DG5 NSPLIT", n);
-        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1, 4, 0, 1>>("TF5 NSPLIT", n);
+        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1>>("TF5 tiles over waves", n);
+        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1>>("DG5 tiles over waves", n);
+        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1, 4, 0, 1>>("DG5 (NSPLIT, as shipped)", n);
+        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1, 4, 0, 1>>("TF5 (NSPLIT, as shipped)", n);
     }
     if (all || !strcmp(what, "wg")) {
         run_wg<WG2>("WG2 (shipped)", n, 64, rounds, c2);

@@ -219,6 +219,14 @@ class CompactTrainingSet:
         n = self.samples.shape[0]
         if not (self.atlas.shape[0] == n and self.y.shape[0] == n and self.index.shape[0] <= n):
             raise ValueError('samples, atlas rows, labels and index disagree on the number of samples')
+        # the device reads the label volumes with the image volumes' geometry (scs_gather_labels): a mismatch would be an
+        # out-of-bounds read there, so it is refused here
+        if len(self.labels) != len(self.volumes) or any(v.ndim != 3 or lb.shape != v.shape for v, lb in zip(self.volumes, self.labels)):
+            raise ValueError('every label volume must have the shape of its image volume (3-D)')
+        if n and not (0 <= int(self.samples[:, 0].min()) and int(self.samples[:, 0].max()) < len(self.volumes)):
+            raise ValueError('sample rows name a volume outside the set')
+        if self.index.size and not (0 <= int(self.index.min()) and int(self.index.max()) < n):
+            raise ValueError('index entries must be rows of `samples`')
 
     def __len__(self):
         return int(self.index.shape[0])

@@ -375,3 +375,21 @@ def test_compact_training_set_is_the_materialised_one(tmp_path):
     cs2 = base.generate_training_set_compact(data, opts, randomize=False)
     ref2 = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts, randomize=False)
     assert all(np.array_equal(a, b) for a, b in zip(cs2.materialize(), ref2))
+
+
+def test_compact_training_set_refuses_inconsistent_geometry():
+    """The device reads label volumes with the image volumes' geometry and follows sample / index rows: what would be an
+    out-of-bounds read there is a ValueError at construction."""
+    from cnn_cort.base import CompactTrainingSet
+    vol = [np.zeros((8, 9, 10), np.float32)]
+    samples = np.array([[0, 1, 2, 3], [0, 4, 5, 6]], np.int32)
+    atlas = np.full((2, 15), 1 / 15.0, np.float32)
+    y = np.zeros(2, np.uint8)
+    ok = CompactTrainingSet(vol, [np.zeros((8, 9, 10), np.uint8)], samples, atlas, y, np.array([1, 0], np.int32))
+    assert len(ok) == 2
+    with pytest.raises(ValueError):
+        CompactTrainingSet(vol, [np.zeros((1, 1, 1), np.uint8)], samples, atlas, y, np.array([1, 0], np.int32))
+    with pytest.raises(ValueError):
+        CompactTrainingSet(vol, [np.zeros((8, 9, 10), np.uint8)], np.array([[1, 1, 2, 3], [0, 4, 5, 6]], np.int32), atlas, y, np.array([0], np.int32))
+    with pytest.raises(ValueError):
+        CompactTrainingSet(vol, [np.zeros((8, 9, 10), np.uint8)], samples, atlas, y, np.array([2], np.int32))

@@ -24,3 +24,20 @@ for bs in (128, 256):
         durs = [r['dur'] for r in net.train_history_]
         print('batch %d, %s: %d samples, epoch times %s s -> %.0f samples/s (second epoch, training + hold-out pass)'
               % (bs, mode, n, ['%.2f' % d for d in durs], n / durs[-1]), flush=True)
+
+# the compact form: 4 synthetic z-scored volumes, n voxel rows (77 bytes per sample), patches cut inside the kernels
+from cnn_cort.base import CompactTrainingSet
+vols = [rng.randn(160, 192, 160).astype(np.float32) for _ in range(4)]
+labs = [np.zeros(v.shape, np.uint8) for v in vols]
+samples = np.stack([rng.randint(0, 4, n), rng.randint(0, 160, n), rng.randint(0, 192, n), rng.randint(0, 160, n)], 1).astype(np.int32)
+e = rng.rand(n, 15).astype(np.float32)
+for i, lb in enumerate(labs):
+    m = samples[:, 0] == i
+    lb[samples[m, 1], samples[m, 2], samples[m, 3]] = y[m]            # the device gathers the labels from these volumes
+cs = CompactTrainingSet(vols, labs, samples, e / e.sum(1, keepdims=True), y, rng.permutation(n).astype(np.int32))
+for bs in (128, 256):
+    net = Net(max_epochs=2, patience=50, eval_size=0.25, batch_size=bs, verbose=0, device=0, seed=1)
+    net.fit(cs)
+    durs = [r['dur'] for r in net.train_history_]
+    print('batch %d, compact set (gather-fused): %d samples, epoch times %s s -> %.0f samples/s (second epoch, training + hold-out pass)'
+          % (bs, n, ['%.2f' % d for d in durs], n / durs[-1]), flush=True)

@@ -157,18 +157,32 @@ class Handle:
         _check(self.lib.scs_forward_host(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), int(n), _ptr(probs),
                                          _ptr(labels)), 'scs_forward_host')
 
+    def _check_volume(self, vol, dims, centers, n, probs, labels):
+        nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
+        if min(int(d) for d in dims) < 1:
+            raise ValueError('volume dimensions must be positive, got %r' % (tuple(dims),))
+        _need(vol, nvox, 'volume')
+        _need(centers, 3 * n, 'centre list')
+        _need(probs, 15 * n, 'probs')
+        _need(labels, n, 'labels out')
+        return nvox
+
     def forward_volume(self, vol, dims, centers, atlas4d, n, probs=None, labels=None, stream=0):
+        _need(atlas4d, 15 * self._check_volume(vol, dims, centers, n, probs, labels), 'atlas volume')
         _check(self.lib.scs_forward_volume(self.h, _ptr(vol), int(dims[0]), int(dims[1]), int(dims[2]), _ptr(centers),
                                            _ptr(atlas4d), int(n), _ptr(probs), _ptr(labels), stream or None),
                'scs_forward_volume')
 
     def forward_volume_rows(self, vol, dims, centers, atlas_rows, n, probs=None, labels=None, stream=0):
+        self._check_volume(vol, dims, centers, n, probs, labels)
+        _need(atlas_rows, 15 * n, 'atlas rows')
         _check(self.lib.scs_forward_volume_rows(self.h, _ptr(vol), int(dims[0]), int(dims[1]), int(dims[2]),
                                                 _ptr(centers), _ptr(atlas_rows), int(n), _ptr(probs), _ptr(labels),
                                                 stream or None), 'scs_forward_volume_rows')
 
     def forward_profiled(self, ax, co, sa, atlas, n, probs=None, labels=None, stream=0):
         """-> (stage_ms float32[8], launches) measured with HIP events on `stream`."""
+        self._check_inputs(ax, co, sa, atlas, n, probs=probs, labels=labels)
         ms = np.zeros(8, np.float32)
         k = ctypes.c_int(0)
         _check(self.lib.scs_forward_profiled(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), int(n), _ptr(probs),
@@ -177,6 +191,9 @@ class Handle:
         return ms, int(k.value)
 
     def dilate_mask(self, mask_dev, scratch_dev, dims, iterations, stream=0):
+        nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
+        _need(mask_dev, nvox, 'mask')
+        _need(scratch_dev, nvox, 'dilation scratch')
         _check(self.lib.scs_dilate_mask(self.h, _ptr(mask_dev), _ptr(scratch_dev), int(dims[0]), int(dims[1]), int(dims[2]),
                                         int(iterations), stream or None), 'scs_dilate_mask')
 
@@ -212,6 +229,8 @@ class Handle:
         return float(loss.value) if want_loss else None
 
     def gather_labels(self, label_vols, descs, samples, n, y_out, stream=0):
+        _need(samples, 4 * n, 'sample rows')
+        _need(y_out, n, 'labels out')
         _check(self.lib.scs_gather_labels(self.h, _ptr(label_vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(n), _ptr(y_out),
                                           stream or None),
                'scs_gather_labels')

@@ -112,3 +112,34 @@ def test_plain_c_training_host_matches_the_python_binding(tmp_path):
     assert np.array_equal(params, params_c)
     assert np.isfinite(params_c).all() and np.isfinite(losses_c).all() and (losses_c > 0).all()
     assert not np.array_equal(params_c, np.fromfile(weights_file, dtype=np.float32))          # the steps did move the parameters
+
+
+def test_the_binding_refuses_short_buffers_before_any_launch(handle):
+    """The kernels trust the sizes they are given; the ctypes binding checks every buffer against the call's geometry, so a
+    short one is a ValueError and not a GPU memory fault."""
+    import torch
+    dev = 'cuda:0'
+    n = 8
+    x = torch.zeros((n, 1, 32, 32), device=dev)
+    at = torch.zeros((n, 15), device=dev)
+    probs = torch.zeros((n, 15), device=dev)
+    with pytest.raises(ValueError):
+        handle.forward(x, x, x[:4], at, n, probs)
+    with pytest.raises(ValueError):
+        handle.forward(x, x, x, at, n, probs[:4])
+    vol = torch.zeros((16, 16, 16), device=dev)
+    centers = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError):
+        handle.forward_volume(vol, (16, 16, 32), centers, torch.zeros((16, 16, 16, 15), device=dev), n, probs)
+    with pytest.raises(ValueError):
+        handle.forward_volume(vol, (16, 16, 16), centers, torch.zeros((16, 16, 8, 15), device=dev), n, probs)
+    with pytest.raises(ValueError):
+        handle.forward_volume_rows(vol, (16, 16, 16), centers[:4], at, n, probs)
+    mask = torch.zeros((16, 16, 16), dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        handle.dilate_mask(mask, mask[:8], (16, 16, 16), 2)
+    y = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        handle.train_step(x, x, x, at, y[:4], n)
+    with pytest.raises(ValueError):
+        handle.gather_labels(mask, torch.zeros((1, 3), dtype=torch.int64, device=dev), centers, n, y)     # 3 ints per row: short

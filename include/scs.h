@@ -130,7 +130,7 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count);
  * alpha = 0.1.  Dropout keep-masks come from `masks_dev` when non-NULL (uint8 0/1, laid out
  * [3][n][540] tower masks in (c,h,w) order, then [n][540] f1_drop, then [n][540] f2_drop), else from a
  * counter-based generator keyed by dropout_seed.  *loss_host receives the batch mean loss (the call
- * synchronises the stream to return it) unless NULL. */
+ * synchronises the stream to return it) unless NULL.  1 <= n <= 65536 (the step's workspace is ~0.75 MB per sample). */
 int scs_train_step(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,
                    const float* atlas_dev, const uint8_t* y_dev, int64_t n, uint64_t dropout_seed,
                    const uint8_t* masks_dev, float* loss_host, void* stream);

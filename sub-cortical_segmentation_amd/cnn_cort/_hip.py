@@ -92,14 +92,37 @@ def _ptr(x):
     return x.data_ptr()
 
 
-def _need(x, count, what):
-    """A buffer handed to the library must hold at least `count` elements: the kernels trust their sizes, and a short buffer
-    is a GPU memory fault (which can take the whole node down), not an exception."""
+_ITEM = {'f32': 4, 'i32': 4, 'u8': 1}
+
+
+def _dtype_name(x):
+    return str(x.dtype).replace('torch.', '')
+
+
+def _need(x, count, what, dtype='f32'):
+    """A buffer handed to the library must be C-contiguous, of the element type the kernels read, and hold at least `count`
+    elements: the kernels trust their sizes, and a short buffer (or a float64 view that happens to have enough elements) is
+    a GPU memory fault (which can take the whole node down), not an exception."""
     if x is None:
         return
+    names = {'f32': ('float32',), 'i32': ('int32',), 'u8': ('uint8', 'bool')}[dtype]
+    if _dtype_name(x) not in names:
+        raise ValueError('%s must be %s, got %s' % (what, names[0], _dtype_name(x)))
+    contiguous = x.flags['C_CONTIGUOUS'] if isinstance(x, np.ndarray) else x.is_contiguous()
+    if not contiguous:
+        raise ValueError('%s must be C-contiguous' % what)
     have = x.size if isinstance(x, np.ndarray) else x.numel()
     if have < count:
         raise ValueError('%s holds %d elements, the call needs %d' % (what, have, count))
+
+
+def _table(x, cols, what, dtype):
+    """A 2-D table [rows, cols] of `dtype` (sample rows, volume descriptors): returns rows.  The row count the kernels clamp
+    against is taken from the shape, so the shape has to be the real one."""
+    if x is None or len(x.shape) != 2 or int(x.shape[1]) != cols:
+        raise ValueError('%s must be a 2-D [N, %d] array, got shape %r' % (what, cols, None if x is None else tuple(x.shape)))
+    _need(x, int(x.shape[0]) * cols, what, dtype)
+    return int(x.shape[0])
 
 
 class Handle:
@@ -143,9 +166,9 @@ class Handle:
         for name, x in (('axial view', ax), ('coronal view', co), ('sagittal view', sa)):
             _need(x, 1024 * n, name)
         _need(atlas, 15 * n, 'atlas rows')
-        _need(y, n, 'labels')
+        _need(y, n, 'labels', 'u8')
         _need(probs, 15 * n, 'probs')
-        _need(labels, n, 'labels out')
+        _need(labels, n, 'labels out', 'i32')
 
     def forward(self, ax, co, sa, atlas, n, probs=None, labels=None, stream=0):
         self._check_inputs(ax, co, sa, atlas, n, probs=probs, labels=labels)
@@ -162,9 +185,9 @@ class Handle:
         if min(int(d) for d in dims) < 1:
             raise ValueError('volume dimensions must be positive, got %r' % (tuple(dims),))
         _need(vol, nvox, 'volume')
-        _need(centers, 3 * n, 'centre list')
+        _need(centers, 3 * n, 'centre list', 'i32')
         _need(probs, 15 * n, 'probs')
-        _need(labels, n, 'labels out')
+        _need(labels, n, 'labels out', 'i32')
         return nvox
 
     def forward_volume(self, vol, dims, centers, atlas4d, n, probs=None, labels=None, stream=0):
@@ -192,8 +215,8 @@ class Handle:
 
     def dilate_mask(self, mask_dev, scratch_dev, dims, iterations, stream=0):
         nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
-        _need(mask_dev, nvox, 'mask')
-        _need(scratch_dev, nvox, 'dilation scratch')
+        _need(mask_dev, nvox, 'mask', 'u8')
+        _need(scratch_dev, nvox, 'dilation scratch', 'u8')
         _check(self.lib.scs_dilate_mask(self.h, _ptr(mask_dev), _ptr(scratch_dev), int(dims[0]), int(dims[1]), int(dims[2]),
                                         int(iterations), stream or None), 'scs_dilate_mask')
 
@@ -203,9 +226,39 @@ class Handle:
         return out
 
     # ---- training
+    @staticmethod
+    def _desc_count(descs):
+        """Number of scs_volume records (24 bytes each: int64 offset, int32 x, y, z, reserved) in a descriptor table given as
+        int64 [V, 3] or int32 [V, 6]."""
+        name = _dtype_name(descs)
+        if name == 'int64':
+            cols = 3
+        elif name == 'int32':
+            cols = 6
+        else:
+            raise ValueError('volume descriptors must be int64 [V,3] or int32 [V,6] (scs_volume records), got %s' % name)
+        if len(descs.shape) != 2 or int(descs.shape[1]) != cols or int(descs.shape[0]) < 1:
+            raise ValueError('volume descriptors must have shape [V,%d], got %r' % (cols, tuple(descs.shape)))
+        contiguous = descs.flags['C_CONTIGUOUS'] if isinstance(descs, np.ndarray) else descs.is_contiguous()
+        if not contiguous:
+            raise ValueError('volume descriptors must be C-contiguous')
+        return int(descs.shape[0])
+
+    def _check_tables(self, samples, descs, atlas_rows, y, index, n):
+        """Shapes and types of the compact training-set tables: the device clamps row and volume numbers against the counts
+        passed here, so they must be the real counts (a flat int32 view would report 4x the rows)."""
+        n_samples = _table(samples, 4, 'sample rows', 'i32')
+        n_vols = self._desc_count(descs)
+        _need(atlas_rows, 15 * n_samples, 'atlas rows')
+        _need(y, n_samples, 'labels', 'u8')
+        _need(index, n, 'batch index', 'i32')
+        if index is None and n > n_samples:
+            raise ValueError('more samples asked for (%d) than the table holds (%d)' % (n, n_samples))
+        return n_samples, n_vols
+
     def train_step(self, ax, co, sa, atlas, y, n, seed=0, masks=None, want_loss=True, stream=0):
         self._check_inputs(ax, co, sa, atlas, n, y=y)
-        _need(masks, 5 * 540 * n, 'dropout masks')
+        _need(masks, 5 * 540 * n, 'dropout masks', 'u8')
         loss = ctypes.c_float(0.0)
         _check(self.lib.scs_train_step(self.h, _ptr(ax), _ptr(co), _ptr(sa), _ptr(atlas), _ptr(y), int(n),
                                        ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
@@ -216,31 +269,30 @@ class Handle:
     def train_step_volume(self, vols, descs, samples, atlas_rows, y, index, n, seed=0, masks=None, want_loss=True, stream=0, flips=None):
         """Gather-fused step: patches are cut inside the kernels from `vols` (concatenated volumes on the device) around
         the voxels of `samples[index]` (include/scs.h: scs_train_step_volume)."""
-        _need(index, n, 'batch index')
-        _need(flips, n, 'flip flags')
-        _need(atlas_rows, 15 * samples.shape[0], 'atlas rows')
-        _need(y, samples.shape[0], 'labels')
-        _need(masks, 5 * 540 * n, 'dropout masks')
+        n_samples, n_vols = self._check_tables(samples, descs, atlas_rows, y, index, n)
+        _need(flips, n, 'flip flags', 'u8')
+        _need(masks, 5 * 540 * n, 'dropout masks', 'u8')
         loss = ctypes.c_float(0.0)
-        _check(self.lib.scs_train_step_volume(self.h, _ptr(vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(samples.shape[0]),
+        _check(self.lib.scs_train_step_volume(self.h, _ptr(vols), _ptr(descs), n_vols, _ptr(samples), n_samples,
                                               _ptr(atlas_rows), _ptr(y), _ptr(index), _ptr(flips), int(n), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), _ptr(masks),
                                               ctypes.addressof(loss) if want_loss else None, stream or None),
                'scs_train_step_volume')
         return float(loss.value) if want_loss else None
 
     def gather_labels(self, label_vols, descs, samples, n, y_out, stream=0):
-        _need(samples, 4 * n, 'sample rows')
-        _need(y_out, n, 'labels out')
-        _check(self.lib.scs_gather_labels(self.h, _ptr(label_vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(n), _ptr(y_out),
+        if _table(samples, 4, 'sample rows', 'i32') < n:
+            raise ValueError('sample table holds fewer than %d rows' % n)
+        n_vols = self._desc_count(descs)
+        _need(label_vols, 1, 'label volumes', 'u8')
+        _need(y_out, n, 'labels out', 'u8')
+        _check(self.lib.scs_gather_labels(self.h, _ptr(label_vols), _ptr(descs), n_vols, _ptr(samples), int(n), _ptr(y_out),
                                           stream or None),
                'scs_gather_labels')
 
     def eval_batch_volume(self, vols, descs, samples, atlas_rows, y, index, n, stream=0):
-        _need(index, n, 'batch index')
-        _need(atlas_rows, 15 * samples.shape[0], 'atlas rows')
-        _need(y, samples.shape[0], 'labels')
+        n_samples, n_vols = self._check_tables(samples, descs, atlas_rows, y, index, n)
         ls, nc = ctypes.c_double(0.0), ctypes.c_int64(0)
-        _check(self.lib.scs_eval_batch_volume(self.h, _ptr(vols), _ptr(descs), int(descs.shape[0]), _ptr(samples), int(samples.shape[0]),
+        _check(self.lib.scs_eval_batch_volume(self.h, _ptr(vols), _ptr(descs), n_vols, _ptr(samples), n_samples,
                                               _ptr(atlas_rows), _ptr(y), _ptr(index), int(n), ctypes.byref(ls), ctypes.byref(nc), stream or None), 'scs_eval_batch_volume')
         return float(ls.value), int(nc.value)
 

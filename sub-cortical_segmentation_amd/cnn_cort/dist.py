@@ -45,16 +45,18 @@ def init_from_env(backend=None):
     td = _td()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not td.is_initialized():
+    if (world > 1 or os.environ.get('SCS_DIST_FORCE_INIT')) and not td.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = os.environ.get('SCS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             # one GPU per rank; LOCAL_RANK wraps around only in single-GPU rehearsals (gloo backend)
-            if backend == 'nccl' and world > torch.cuda.device_count():
-                raise RuntimeError('backend nccl (RCCL) needs one GPU per rank: %d ranks, %d visible device(s)'
-                                   % (world, torch.cuda.device_count()))
+            # (ranks of THIS node: a 2-node x 8-GPU job has WORLD_SIZE 16 and LOCAL_WORLD_SIZE 8)
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+            if backend == 'nccl' and (local_world > torch.cuda.device_count() or local >= torch.cuda.device_count()):
+                raise RuntimeError('backend nccl (RCCL) needs one GPU per rank: %d ranks on this node, %d visible device(s)'
+                                   % (local_world, torch.cuda.device_count()))
             local = local % max(1, torch.cuda.device_count())
             torch.cuda.set_device(local)
         td.init_process_group(backend=backend, rank=int(os.environ.get('RANK', '0')), world_size=world)
@@ -132,7 +134,7 @@ def allreduce_flat(t, n_active):
 def allreduce_grads(handle, active, stream=0, n_active=None):
     """All-reduce the gradient arena of a libscs handle across ranks (RCCL); returns grad_scale for Adam.
     `active` False = this rank had no batch this step: its arena is zeroed first."""
-    if world_size() == 1:
+    if not is_dist():                         # a process group of ONE rank still runs the collective (RCCL rehearsal on one GPU)
         return 1.0
     import torch
     ptr, n = handle.grad_arena()
@@ -151,7 +153,7 @@ def allreduce_grads(handle, active, stream=0, n_active=None):
 def sync_params(handle):
     """Average the parameter arena across ranks (reconciles the per-rank BN running statistics; the trainable
     entries are already identical)."""
-    if world_size() == 1:
+    if not is_dist():
         return
     ptr, n = handle.param_arena()
     p = wrap_device_floats(ptr, n, handle.device)

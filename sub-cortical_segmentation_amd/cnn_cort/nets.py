@@ -498,10 +498,11 @@ class Net:
             d_desc = torch.from_numpy(desc).to(dev)
             d_samples = torch.from_numpy(X.samples).to(dev)
             d_atlas = torch.from_numpy(X.atlas).to(dev)
-            d_labvols = torch.from_numpy(np.concatenate([v.ravel() for v in X.labels])).to(dev)
-            d_y = torch.empty((X.samples.shape[0],), dtype=torch.uint8, device=dev)
-            h.gather_labels(d_labvols, d_desc, d_samples, X.samples.shape[0], d_y, stream)     # centre label, 15 -> 0, on the device
-            del d_labvols
+            # the labels the caller passed (and that were range-checked and split above) are the labels trained on: X.y, not a
+            # second reading of the label volumes (a set built with relabelled / merged classes must train on ITS labels)
+            if X.y.size and int(X.y.max()) > 14:
+                raise ValueError('labels must lie in 0..14')
+            d_y = torch.from_numpy(X.y).to(dev)
             d_tr = torch.from_numpy(X.index[tr_idx].astype(np.int32)).to(dev)
             d_va = torch.from_numpy(X.index[va_idx].astype(np.int32)).to(dev)
 
@@ -682,8 +683,16 @@ class Net:
         from . import dist
         if self.history_file and dist.rank() == 0:
             base = self.history_file[:-4] if self.history_file.endswith('.pkl') else self.history_file
+            rows = [{k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in r.items()} for r in history]
             with open(base + '.json', 'w') as f:
-                json.dump([{k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v in r.items()} for r in history], f, indent=0)
+                json.dump(rows, f, indent=0)
+            if self.history_file.endswith('.pkl'):
+                # what SaveTrainingHistory leaves (nets.py:156): a protocol-2 pickle of the list of epoch dicts, plain python
+                # values, readable by the reference's python 2
+                import pickle
+                with open(self.history_file + '.tmp', 'wb') as f:
+                    pickle.dump(rows, f, protocol=2)
+                os.replace(self.history_file + '.tmp', self.history_file)
 
 
 def build_model(weights_path, options):

@@ -12,7 +12,9 @@ float32) but stores it in a pickle-free container:
 
 ``load_params`` additionally reads the reference's own ``.pkl`` through an allow-listed unpickler
 (the pickle references only OrderedDict / numpy reconstruct helpers - pure data), so a user of the
-reference can point ``net.load_params_from`` at the weights file they already have.
+reference can point ``net.load_params_from`` at the weights file they already have; ``save_params`` on a
+``.pkl`` path additionally writes that pickle (python-2 cPickle protocol 2, numpy 1.x spelling), so the
+reference can read weights trained here.
 
 Array order inside a layer follows Lasagne's ``get_params()``:
   Conv2DLayer (bias stripped by batch_norm(), nets.py:171)  -> [W (Cout,Cin,3,3)]
@@ -113,6 +115,142 @@ def read_reference_pickle(path):
         return _DataOnlyUnpickler(f, encoding='latin1').load()
 
 
+class _Py2PickleWriter:
+    """Emits the exact opcode stream python-2 cPickle (protocol 2, what nolearn's ``save_params_to`` uses:
+    ``pickle.dump(params, f, -1)``) produces for ``OrderedDict{str: [float32 ndarray, ...]}`` under numpy 1.x, so that the
+    reference's own environment (python 2.7 + numpy 1.13, requirements.txt) can read files written here:
+    ``numpy.core.multiarray._reconstruct`` (not numpy 2's ``numpy._core``), array bytes as a py2 ``str`` (BINSTRING), and
+    cPickle's memo discipline (objects with a second reference are memoised: key strings, lists, the ndarray class, the
+    shared '<f4' dtype, every array; temporaries - shape tuples, the raw byte strings - are not).  Given the arrays of
+    nets/miccai2012_v1/miccai2012_v1.pkl it reproduces that file byte for byte (tests/test_params.py)."""
+
+    def __init__(self):
+        self.out = []
+        self.memo_next = 1
+        self.memo = {}                  # tag -> memo index of objects written before
+
+    def _put(self, tag=None):
+        i = self.memo_next
+        self.memo_next += 1
+        self.out.append(b'q' + bytes([i]) if i < 256 else b'r' + i.to_bytes(4, 'little'))
+        if tag is not None:
+            self.memo[tag] = i
+
+    def _get(self, tag):
+        i = self.memo[tag]
+        self.out.append(b'h' + bytes([i]) if i < 256 else b'j' + i.to_bytes(4, 'little'))
+
+    def _int(self, v):
+        if 0 <= v < 256:
+            self.out.append(b'K' + bytes([v]))
+        elif 0 <= v < 65536:
+            self.out.append(b'M' + v.to_bytes(2, 'little'))
+        else:
+            self.out.append(b'J' + int(v).to_bytes(4, 'little', signed=True))
+
+    def _str(self, b, memoize):
+        b = b if isinstance(b, bytes) else b.encode('latin1')
+        self.out.append((b'U' + bytes([len(b)]) if len(b) < 256 else b'T' + len(b).to_bytes(4, 'little')) + b)
+        if memoize:
+            self._put()
+
+    def _global(self, tag, module, name):
+        if tag in self.memo:
+            self._get(tag)
+        else:
+            self.out.append(b'c' + module.encode() + b'\n' + name.encode() + b'\n')
+            self._put(tag)
+
+    def _tuple(self, ints):
+        if len(ints) > 3:
+            self.out.append(b'(')
+        for v in ints:
+            self._int(int(v))
+        self.out.append({0: b')', 1: b'\x85', 2: b'\x86', 3: b'\x87'}.get(len(ints), b't'))
+
+    def _array(self, a):
+        a = np.ascontiguousarray(a, dtype='<f4')
+        self._global('reconstruct', 'numpy.core.multiarray', '_reconstruct')
+        self._global('ndarray', 'numpy', 'ndarray')
+        self._tuple((0,))
+        self._str('b', False)
+        self.out.append(b'\x87R')                      # (ndarray, (0,), 'b') -> _reconstruct(...)
+        self._put()
+        self.out.append(b'(')
+        self._int(1)                                   # ndarray.__setstate__ version
+        self._tuple(a.shape)
+        if 'f4' in self.memo:
+            self._get('f4')
+        else:
+            self._global('dtype', 'numpy', 'dtype')
+            self._str('f4', False)
+            self._int(0)
+            self._int(1)
+            self.out.append(b'\x87R')                  # dtype('f4', 0, 1)
+            self._put('f4')
+            self.out.append(b'(')
+            self._int(3)
+            self._str('<', False)
+            self.out.append(b'NNN')
+            self._int(-1)
+            self._int(-1)
+            self._int(0)
+            self.out.append(b'tb')                     # dtype.__setstate__((3, '<', None, None, None, -1, -1, 0))
+        self.out.append(b'\x89')                       # is_fortran = False
+        self._str(a.tobytes(), False)
+        self.out.append(b'tb')
+
+    def _list_items(self, n, emit):
+        """cPickle's batch_list for n < 1000 items: nothing / item APPEND / MARK items APPENDS."""
+        if n == 1:
+            emit(0)
+            self.out.append(b'a')
+        elif n > 1:
+            self.out.append(b'(')
+            for i in range(n):
+                emit(i)
+            self.out.append(b'e')
+
+    def dump(self, params):
+        items = list(params.items())
+        assert len(items) < 1000
+        self.out.append(b'\x80\x02')
+        self._global('OrderedDict', 'collections', 'OrderedDict')
+        self.out.append(b']')
+        self._put()
+
+        def pair(i):
+            name, arrs = items[i]
+            self.out.append(b']')
+            self._put()
+
+            def kv(j):
+                if j == 0:
+                    self._str(name, True)
+                else:
+                    self.out.append(b']')
+                    self._put()
+                    self._list_items(len(arrs), lambda k: self._array(arrs[k]))
+            self._list_items(2, kv)
+        self._list_items(len(items), pair)
+        self.out.append(b'\x85R')                      # OrderedDict([[k, v], ...])
+        self._put()
+        self.out.append(b'.')
+        return b''.join(self.out)
+
+
+def write_reference_pickle(path, params):
+    """Write `params` as the pickle nolearn's ``save_params_to`` writes under the reference's python 2 / numpy 1.x
+    (nets.py:155 SaveWeights, :251 load_params_from): the reference can load weights trained here."""
+    check_params(params)
+    ordered = OrderedDict((name, list(params[name])) for name, _ in LAYER_SPEC)
+    data = _Py2PickleWriter().dump(ordered)
+    with open(path + '.tmp', 'wb') as f:
+        f.write(data)
+    os.replace(path + '.tmp', path)
+    return path
+
+
 def _paths(path):
     base = path[:-4] if path.endswith(('.f32', '.pkl')) else (path[:-5] if path.endswith('.json') else path)
     return base + '.f32', base + '.json'
@@ -138,6 +276,8 @@ def save_params(path, params):
     with open(man_path + '.tmp', 'w') as f:
         json.dump({'format': 'scs-params-v1', 'dtype': '<f4', 'total': off, 'layers': manifest}, f, indent=0)
     os.replace(man_path + '.tmp', man_path)
+    if path.endswith('.pkl'):
+        write_reference_pickle(path, params)          # what the reference's load_params_from reads (nets.py:251)
     return blob_path
 
 

@@ -176,6 +176,11 @@ constexpr size_t fin_counter_words(size_t wgs_per_tower) { return (1 + (wgs_per_
 // Cross-workgroup hand-off of the partial sums without any fence on the producers: the sums are stored write-through
 // (`sc1`: they never sit dirty in an XCD's L2), every storing wave drains its stores, and one lane per workgroup takes a
 // ticket; the workgroup whose ticket completes the count invalidates its L1 once and reads the sums with `sc1` loads.
+// This hand-off is valid only where vector stores are counted by vmcnt and `sc1` stores write through - the gfx942 / gfx950
+// family (MI355X_MICROARCH.md, "Valid forms").  On a target that counts stores in vscnt the ticket could overtake the sums.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "conv_mfma.h: the in-kernel batch-norm finalize (FIN configurations) relies on gfx942/gfx950 memory-counter semantics"
+#endif
 __device__ __forceinline__ void st_sc1(float2* p, float2 v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

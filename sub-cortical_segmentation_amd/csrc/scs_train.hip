@@ -82,6 +82,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* l1p[kTowers]{};                     // [20][12]: flipped conv1 taps (9), sc, sh, pad
     float* l1m[kTowers]{};                     // [20][2]: mean, inv_std of conv1's batch statistics
     double* mom = nullptr;                     // [3][100] R (9x9), S (column 9), count
+    bool tickets_dirty = false;                // a step failed between launches: the tickets are zeroed before the next one
     unsigned int* fin_counter = nullptr;       // arrival tickets of the in-kernel finalize steps (inside `base`; zero between launches)
     float* wg_part = nullptr;                  // [4 layers][3][kWgPartFloats] partial weight gradients
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
@@ -119,7 +120,12 @@ void train_free(scs_ctx* h) {
     h->tws = nullptr;
 }
 
-static int moment_units(int n) { const int ppb = (n + 255) / 256; return (n + ppb - 1) / ppb; }   // <= 256 groups of patches
+// Patches per input-moment unit: one per workgroup up to batch 256, never more than kMomentPpb - a unit's raw second moments
+// are ONE fp32 MFMA accumulator (900 products per patch); the units are combined in double (bn1_final_kernel).
+constexpr int kMomentPpb = 4;
+constexpr int64_t kMaxTrainBatch = 65536;    // largest n the training entry points take (workspace: ~0.75 MB per sample)
+static int moment_ppb(int n) { return std::min(kMomentPpb, (n + 255) / 256); }
+static int moment_units(int n) { const int ppb = moment_ppb(n); return (n + ppb - 1) / ppb; }
 
 static int train_ensure(scs_ctx* h, int n) {
     if (!h->tws) {
@@ -187,7 +193,7 @@ static int train_ensure(scs_ctx* h, int n) {
                  o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
                  o_sp = take((size_t)kTowers * c * 8 * 64 * 2),     // up to 8 bands x 64 channels x 2 sums
-                 o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * 256 * 128),
+                 o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * std::max<size_t>(256, (c + kMomentPpb - 1) / kMomentPpb) * 128),
                  o_fc = take(kTowers * fin_counter_words(c));                 // one workgroup per patch in the FIN configurations
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
@@ -825,7 +831,11 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // has been zero since the arena was allocated
 
     // ---- prep: operand packs (unfolded), transposed dense weights, atlas columns + batch labels, dropout masks
-    const int units1 = moment_units(n), ppb = (n + units1 - 1) / units1;
+    const int units1 = moment_units(n), ppb = moment_ppb(n);
+    if (w->tickets_dirty) {                     // a launch of the previous step failed in mid-flight: re-arm the arrival tickets
+        SCS_HIP(hipMemsetAsync(w->fin_counter, 0, kTowers * fin_counter_words((size_t)w->cap) * sizeof(unsigned int), st));
+        w->tickets_dirty = false;
+    }
     const uint8_t* masks = masks_dev ? masks_dev : w->masks;
     const uint8_t* mask5 = masks;                                  // [3][n][540]
     const uint8_t* mask1 = masks + (size_t)3 * n * kFlat;          // f1_drop [n][540]
@@ -1028,7 +1038,11 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     fa.z0 = 0;
     run(ST_WGFINAL2, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((20 * 20 * 9 + 63) / 64, kTowers, 1), dim3(256), 0, sd, fa); });
     join();                                   // every gradient is in the arena before the caller's stream goes on
-    SCS_HIP(hipGetLastError());
+    if (hipError_t le = hipGetLastError(); le != hipSuccess) {
+        w->tickets_dirty = true;
+        set_error("a launch of the training step failed: %s", hipGetErrorString(le));
+        return SCS_ERR_HIP;
+    }
     h->packed_dirty = true;          // BN running statistics moved
     if (!h->last_train_event) SCS_HIP(hipEventCreateWithFlags(&h->last_train_event, hipEventDisableTiming));
     SCS_HIP(hipEventRecord(h->last_train_event, st));
@@ -1070,7 +1084,7 @@ const char* scs_train_stage_name(int stage) { return (stage >= 0 && stage < ST_C
 int scs_train_step(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, const uint8_t* y,
                    int64_t n64, uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
-    SCS_ARG(n64 > 0 && n64 <= (1 << 20), "n out of range");
+    SCS_ARG(n64 > 0 && n64 <= kMaxTrainBatch, "n out of range (1..65536)");
     SCS_ARG(ax && co && sa && atlas && y, "null input pointer");
     X0Src x0{};
     x0.views[0] = ax; x0.views[1] = co; x0.views[2] = sa;
@@ -1080,7 +1094,7 @@ int scs_train_step(scs_handle h, const float* ax, const float* co, const float* 
 int scs_train_step_profiled(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas, const uint8_t* y,
                             int64_t n64, uint64_t dropout_seed, float* stage_ms, void* stream) {
     SCS_ARG(h != nullptr && stage_ms != nullptr, "null handle or output");
-    SCS_ARG(n64 > 0 && n64 <= (1 << 20), "n out of range");
+    SCS_ARG(n64 > 0 && n64 <= kMaxTrainBatch, "n out of range (1..65536)");
     SCS_ARG(ax && co && sa && atlas && y, "null input pointer");
     X0Src x0{};
     x0.views[0] = ax; x0.views[1] = co; x0.views[2] = sa;
@@ -1091,7 +1105,7 @@ int scs_train_step_volume(scs_handle h, const float* vols, const scs_volume* des
                           int64_t n_samples, const float* atlas_rows, const uint8_t* y, const int32_t* index, const uint8_t* flips,
                           int64_t n64, uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
-    SCS_ARG(n64 > 0 && n64 <= (1 << 20), "n out of range");
+    SCS_ARG(n64 > 0 && n64 <= kMaxTrainBatch, "n out of range (1..65536)");
     SCS_ARG(vols && descs && samples && atlas_rows && y, "null input pointer");
     SCS_ARG(n_vols > 0 && n_samples > 0 && n_samples <= 0x7fffffff, "empty volume / sample table");
     SCS_ARG(index || n64 <= n_samples, "more samples asked for than the table holds");

@@ -16,6 +16,11 @@ Ranks process independent batches (weak scaling), the forward
 path has no collective, the training path exactly one (the gradient arena).  Timing = K steps between
 barrier + synchronize brackets, max over ranks; rank 0 prints ONE JSON line.
 
+The default (forward) run also measures the training step once its own timed region is over - `train_step`: batch 256
+(BASELINE configs[2]) and 128 (the reference's effective batch), 200 steps each of scs_train_step + all-reduce +
+scs_adam_apply, with the dominant training kernel's roofline - so that the driver's one line carries both halves of
+BASELINE.json's metric ("fwd & train step").  The headline keys stay the forward measurement.
+
 roofline: the dominant kernel (forward: fused conv1+conv2+pool1, 50.6 % of the net's MACs; train: the longest of the
 conv forward / data-gradient / weight-gradient kernels) is timed live with HIP events on the stream it is launched on
 (scs_forward_profiled / scs_train_step_profiled); achieved = algorithmic FLOP per launch / mean launch duration against
@@ -153,6 +158,181 @@ def cpu_baseline_train(weights, budget_s=None, batch=256):
                       % (done // batch, batch, dt)}
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources: ties a committed PMC measurement to the code it was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(PKG, 'csrc', '*.h')) + glob.glob(os.path.join(PKG, 'csrc', '*.hip'))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(key):
+    """HBM bytes per launch of kernel `key` from the committed rocprofv3 --pmc passes (profiles/traffic.json, written by
+    tools/pmc_traffic.py) - reported only when that file was measured on the kernel sources of THIS tree; otherwise null plus
+    a note saying which sources it belongs to (a constant that silently outlives the kernel it describes is worse than none)."""
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        t = json.load(open(tfile))
+    except Exception:
+        return None, 'profiles/traffic.json missing'
+    here = csrc_sha16()
+    if t.get('_csrc_sha16') != here:
+        return None, 'profiles/traffic.json was measured on kernel sources %s (commit %s); this tree has %s' % (
+            t.get('_csrc_sha16'), t.get('_source_commit'), here)
+    return t.get(key), 'rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, commit %s (tools/pmc_traffic.py)' % t.get('_source_commit')
+
+
+TRAIN_CONV_MACS = {'conv1+conv2 fwd': 3 * (162000 + 2822400), 'conv3 fwd': 3 * 1036800, 'conv4 fwd': 3 * 1440000, 'conv5 fwd': 3 * 194400,
+                   'conv5 dgrad': 3 * 194400, 'conv4 dgrad': 3 * 1440000, 'conv3 dgrad': 3 * 1036800,
+                   'conv2 dgrad + layer-1 sums': 3 * (2822400 + 162000), 'conv5 wgrad': 3 * 194400, 'conv4 wgrad': 3 * 1440000,
+                   'conv3 wgrad': 3 * 1036800, 'conv2 wgrad': 3 * 2822400}
+
+
+def train_inputs(torch, B, rank, dev):
+    ax, co, sa, at = synth_on_device(torch, B, 1000 * rank, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4 + rank)
+    y = torch.randint(0, 15, (B,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
+    return ax, co, sa, at, y
+
+
+def train_stage_profile(h, inputs, B, st, reps=5):
+    """Every launch of one training step timed with HIP events on the stream it is issued on (scs_train_step_profiled; the
+    weight-gradient kernels run on the library's side stream), averaged over a few steps -> (roofline of the dominant conv
+    kernel, per-stage table, launches per step, sum of launch times)."""
+    ax, co, sa, at, y = inputs
+    acc = {}
+    for r in range(reps):
+        for k, v in h.train_step_profiled(ax, co, sa, at, y, B, seed=1000 + r, stream=st).items():
+            acc[k] = acc.get(k, 0.0) + v / reps
+    convs = {k: v for k, v in TRAIN_CONV_MACS.items() if acc.get(k, 0.0) > 0}
+    dom = max(convs, key=lambda k: acc[k])
+    dur = acc[dom] * 1e-3
+    achieved = 2.0 * convs[dom] * B / dur / 1e12
+    traffic, note = measured_traffic('train: ' + dom) if B == 256 else (None, 'measured at batch 256 only')
+    roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_source': note, 'launch_ms': acc[dom], 'patches_per_launch': B}
+    stages = {k: {'ms': v, 'tflops': (2.0 * TRAIN_CONV_MACS[k] * B / (v * 1e-3) / 1e12) if k in TRAIN_CONV_MACS and v > 0 else None}
+              for k, v in acc.items() if v > 0}
+    return roofline, stages, len(stages), float(sum(acc.values()))
+
+
+def measure_train(torch, dist, h, B, steps, warmup, rank, world, dev, st, profile):
+    """`steps` training steps (scs_train_step + gradient all-reduce over RCCL when world > 1 + scs_adam_apply) of batch B per
+    GPU between barrier + synchronize brackets, max over ranks."""
+    inputs = train_inputs(torch, B, rank, dev)
+    ax, co, sa, at, y = inputs
+    ctr = [0]
+
+    def step():
+        ctr[0] += 1
+        h.train_step(ax, co, sa, at, y, B, seed=5 + ctr[0], want_loss=False, stream=st)
+        scale = dist.allreduce_grads(h, True, st, n_active=world)
+        h.adam_apply(grad_scale=scale, stream=st)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = dist.max_scalar(time.perf_counter() - t0)
+    value = world * B * steps / dt
+    out = {'per_gpu_batch': B, 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'value': value, 'unit': 'patches/s',
+           'net_tflops': value * TRAIN_FLOP / 1e12, 'net_frac_of_f32_peak': value * TRAIN_FLOP / 1e12 / (PEAK_F32_TFLOPS * world)}
+    if profile and rank == 0:
+        out['roofline'], out['stages'], out['launches_per_step'], out['sum_of_launch_ms'] = train_stage_profile(h, inputs, B, st)
+    return out, step
+
+
+def make_cohort(root, n_subjects, seed, shape=(256, 256, 192)):
+    """S synthetic subject folders of BASELINE configs[4] size on local disk: int16 T1, float32 15-channel prior (755 MB
+    inflated), registered sub-cortical mask whose 10-voxel dilation gives a ~330 000-voxel ROI.  One subject is synthesised,
+    the others are file copies of it (the work per subject does not depend on the voxel values)."""
+    import shutil
+    from cnn_cort import nifti, synth
+    first = os.path.join(root, 'subj000')
+    os.makedirs(os.path.join(first, 'tmp'), exist_ok=True)
+    t1 = synth.smooth_volume(shape, seed=seed, as_int=True)
+    core = synth.ellipsoid_mask(shape, radii=(0.3, 0.27, 0.33))
+    nifti.save(t1, os.path.join(first, 'T1.nii.gz'))
+    nifti.save(synth.toy_atlas(shape, seed=seed + 1).astype(np.float32), os.path.join(first, 'tmp', 'MNI_sub_probabilities.nii.gz'))
+    nifti.save(core.astype(np.uint8), os.path.join(first, 'tmp', 'MNI_subcortical_mask.nii.gz'))
+    scans = [os.path.join(first, 'T1.nii.gz')]
+    for i in range(1, n_subjects):
+        sub = os.path.join(root, 'subj%03d' % i)
+        shutil.copytree(first, sub)
+        scans.append(os.path.join(sub, 'T1.nii.gz'))
+    return scans
+
+
+def cohort_mode(args, torch, dist, rank, world, local, weights):
+    """BASELINE configs[4] end to end: base.test_cohort over S synthetic 256x256x192 subjects per rank, files on local disk,
+    out_probabilities and post_process on (the reference's defaults) - the loop of train_model.py:74-78 with test_scan
+    (base.py:401-458) inside.  value = subjects/hour over all ranks; the line also states what the host has to deliver for it:
+    CPU-seconds per subject (process CPU time, all threads), GPU-seconds per subject, reader threads, usable CPUs, and how
+    many such ranks one host share of that size could feed."""
+    import shutil
+    import tempfile
+    from cnn_cort import base
+    from cnn_cort.nets import build_model
+    S = max(1, args.subjects)
+    cpus = usable_cpus()
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    readers = args.readers or max(1, min(6, cpus // max(1, local_world) - 1))
+    root = tempfile.mkdtemp(prefix='scs_cohort_r%d_' % rank, dir=os.environ.get('SCS_BENCH_TMP'))
+    try:
+        t_make = time.perf_counter()
+        scans = make_cohort(root, S + 1, seed=rank)                    # one extra subject for the warm-up
+        t_make = time.perf_counter() - t_make
+        opts = {'experiment': 'miccai2012_v1', 'net_verbose': 0, 'train_split': 0.25, 'max_epochs': 1, 'patience': 20,
+                'patch_size': [32, 32], 'load_weights': 'True', 'batch_size': 128, 'device': local, 'crop': 'True',
+                'test_batch_size': 100000, 'out_probabilities': 'True', 'post_process': 'True', 'debug': 'False'}
+        net = build_model(os.path.join(PKG, 'nets'), opts)
+        base.test_scan(net, scans[0], opts)                            # warm-up: library, workspace, page cache of the code paths
+        n_roi = int(getattr(net, 'last_scan_voxels', 0))
+        if hasattr(net, 'gpu_seconds'):
+            net.gpu_seconds = 0.0
+        torch.cuda.synchronize()
+        dist.barrier()
+        c0, t0 = time.process_time(), time.perf_counter()
+        res = base.test_cohort(net, scans[1:], opts, shard=False, readers=readers)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = dist.max_scalar(time.perf_counter() - t0)
+        cpu_s = dist.sum_scalar(time.process_time() - c0) / (world * S)
+        gpu_s = dist.sum_scalar(float(getattr(net, 'gpu_seconds', 0.0))) / (world * S)
+        assert len(res) == S
+        value = world * S / dt * 3600.0
+        per_rank_rate = S / dt                                         # subjects per second and rank
+        out = {'metric': 'subjects/hour (test_cohort end to end: read, ROI, gather-fused inference, probabilities + post-processed labels written)',
+               'value': value, 'unit': 'subjects/h', 'n_gpus': world, 'steps': S, 'warmup': 1, 'ms_per_step': 1e3 * dt / S,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'whole-cohort inference, one subject at a time per GPU, %d synthetic 256x256x192 subjects per rank, '
+                                      '~%d ROI voxels each, out_probabilities + post_process (BASELINE configs[4])' % (S, n_roi),
+                          'weights': 'miccai2012_v1 (shipped)', 'parallelism': 'subjects sharded over ranks, no collective'},
+               'host': {'cpu_seconds_per_subject': cpu_s, 'gpu_seconds_per_subject': gpu_s, 'wall_seconds_per_subject_per_rank': dt / S,
+                        'usable_cpus': cpus, 'reader_threads_per_rank': readers,
+                        'cores_busy_per_rank': per_rank_rate * cpu_s,
+                        'ranks_one_host_share_can_feed': (cpus / (per_rank_rate * cpu_s)) if cpu_s > 0 else None,
+                        'synth_seconds': t_make},
+               'gpu_stage_patches_per_s': (n_roi / gpu_s) if gpu_s > 0 else None}
+        if rank == 0 and world == 1 and not args.no_cpu:
+            cb = cpu_baseline_volume(weights)
+            per_subject = (n_roi or 400000) / cb['value']
+            out['cpu_baseline'] = {'value': 3600.0 / per_subject, 'unit': 'subjects/h', 'cores': cb['cores'], 'kind': 'port',
+                                   'sample': cb['sample'] + ' - GPU stage of one subject only; the file stages are the same code on both sides'}
+        if rank == 0:
+            print(json.dumps(out, default=float))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` with no torchrun environment: start N ranks as CHILD processes (one per GPU,
     torch.distributed.run, rendezvous on 127.0.0.1) and exit with their code.  Called before anything in this process
@@ -175,10 +355,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--mode', choices=['forward', 'train', 'volume'], default='forward')
+    ap.add_argument('--mode', choices=['forward', 'train', 'volume', 'cohort'], default='forward')
     ap.add_argument('--batch', type=int, default=0)
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-train-block', action='store_true', help='forward mode: skip the train_step block')
+    ap.add_argument('--train-steps', type=int, default=200, help='timed steps per batch size of the train_step block')
+    ap.add_argument('--subjects', type=int, default=6, help='cohort mode: synthetic subjects per rank')
+    ap.add_argument('--readers', type=int, default=0, help='cohort mode: reader threads per rank (0 = usable CPUs / ranks on this host, at most 6)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher rehearsal without a GPU: ranks rendezvous (gloo), run the barrier / max-over-ranks '
                          'timing brackets around an empty step and rank 0 prints a line marked "dry_run": true, value null')
@@ -198,13 +382,14 @@ def main():
     if args.dry_run:
         rank, world, _ = dist.init_from_env(backend='gloo')
         assert world == args.gpus
+        ranks_seen = int(round(dist.sum_scalar(1.0)))
         dist.barrier()
         t0 = time.perf_counter()
         dist.barrier()
         dt = dist.max_scalar(time.perf_counter() - t0)
         if rank == 0:
             print(json.dumps({'metric': 'tri-view 32x32 patches/s (%s)' % args.mode, 'value': None, 'unit': 'patches/s',
-                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
+                              'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
                               'dry_run': True, 'bracket_s': dt}))
         return
 
@@ -216,79 +401,81 @@ def main():
         raise SystemExit('bench.py: --gpus %d but only %d HIP device(s) are visible (set SCS_DIST_BACKEND=gloo for a '
                          'shared-GPU rehearsal)' % (args.gpus, torch.cuda.device_count()))
     rank, world, local = dist.init_from_env()
-    assert world == args.gpus, (world, args.gpus)
+    # every rank checks the communicator it actually got, and rank 0 reports how many ranks answered a collective
+    if world != args.gpus or dist.world_size() != args.gpus:
+        raise SystemExit('bench.py: rank %d sees a process group of %d rank(s), --gpus is %d' % (rank, dist.world_size(), args.gpus))
+    ranks_seen = int(round(dist.sum_scalar(1.0)))
+    if ranks_seen != args.gpus:
+        raise SystemExit('bench.py: a sum over the ranks counted %d, --gpus is %d' % (ranks_seen, args.gpus))
     torch.cuda.set_device(local)
     dev = 'cuda:%d' % local
     weights = P.load_params(os.path.join(PKG, 'nets', 'miccai2012_v1', 'miccai2012_v1'))
+    if args.mode == 'cohort':
+        return cohort_mode(args, torch, dist, rank, world, local, weights)
     h = _hip.Handle(local)
     h.set_params(P.params_to_flat(weights))
     if args.chunk:
         h.set_chunk(args.chunk)
     chunk = h.set_chunk(0)
     st = torch.cuda.current_stream().cuda_stream
+    backend = torch.distributed.get_backend() if dist.is_dist() else None
 
-    if args.mode == 'forward':
-        B = args.batch or 100000
-        ax, co, sa, at = synth_on_device(torch, B, 1000 * rank, dev)
-        probs = torch.empty((B, 15), device=dev)
-        labels = torch.empty((B,), dtype=torch.int32, device=dev)
-
-        def step():
-            h.forward(ax, co, sa, at, B, probs, labels, st)
-        flop_per_patch = FWD_FLOP
-        workload = 'forward-only inference, synthetic 32x32x3-view float32 patches, batch %d per GPU (BASELINE configs[1])' % B
-    elif args.mode == 'volume':
-        # BASELINE configs[4]: one subject per GPU, gather-fused inference over a ~400 000-voxel ROI of a 256x256x192
-        # volume (synthetic, z-scored noise), labels + probabilities from one pass
-        dims = (256, 256, 192)
-        g = torch.Generator(device=dev)
-        g.manual_seed(7 + rank)
-        vol = torch.randn(dims, generator=g, device=dev, dtype=torch.float32)
-        e = torch.rand(dims + (15,), generator=g, device=dev, dtype=torch.float32)
-        atlas4d = (e / e.sum(-1, keepdim=True)).contiguous()
-        zz, yy, xx = torch.meshgrid(*[torch.arange(s, device=dev) for s in dims], indexing='ij')
-        roi = (((zz - 128) / 60.0) ** 2 + ((yy - 128) / 52.0) ** 2 + ((xx - 96) / 31.0) ** 2) <= 1.0
-        centers = torch.nonzero(roi).to(torch.int32).contiguous()          # C order, like np.nonzero (base.py:310-331)
-        B = int(centers.shape[0])
-        probs = torch.empty((B, 15), device=dev)
-        labels = torch.empty((B,), dtype=torch.int32, device=dev)
-
-        def step():
-            h.forward_volume(vol, dims, centers, atlas4d, B, probs, labels, st)
-        flop_per_patch = FWD_FLOP
-        workload = 'gather-fused whole-subject inference (scs_forward_volume), 256x256x192 volume, %d ROI voxels per GPU (BASELINE configs[4])' % B
-    else:
+    train_out = None
+    if args.mode == 'train':
         B = args.batch or 256
-        ax, co, sa, at = synth_on_device(torch, B, 1000 * rank, dev)
-        g = torch.Generator(device=dev)
-        g.manual_seed(4 + rank)
-        y = torch.randint(0, 15, (B,), generator=g, device=dev, dtype=torch.int32).to(torch.uint8)
-        ctr = [0]
-
-        def step():
-            ctr[0] += 1
-            h.train_step(ax, co, sa, at, y, B, seed=5 + ctr[0], want_loss=False, stream=st)
-            scale = dist.allreduce_grads(h, True, st, n_active=world)
-            h.adam_apply(grad_scale=scale, stream=st)
+        train_out, _ = measure_train(torch, dist, h, B, args.steps, args.warmup, rank, world, dev, st, profile=True)
+        value, dt_ms = train_out['value'], train_out['ms_per_step']
         flop_per_patch = TRAIN_FLOP
         workload = 'training step (fwd+bwd+Adam), synthetic batch %d per GPU, 15 classes (BASELINE configs[2]/[3])' % B
+    else:
+        if args.mode == 'forward':
+            B = args.batch or 100000
+            ax, co, sa, at = synth_on_device(torch, B, 1000 * rank, dev)
+            probs = torch.empty((B, 15), device=dev)
+            labels = torch.empty((B,), dtype=torch.int32, device=dev)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = dist.max_scalar(time.perf_counter() - t0)
-    value = world * B * args.steps / dt
+            def step():
+                h.forward(ax, co, sa, at, B, probs, labels, st)
+            workload = 'forward-only inference, synthetic 32x32x3-view float32 patches, batch %d per GPU (BASELINE configs[1])' % B
+        else:
+            # BASELINE configs[4], GPU stage only: one subject per GPU, gather-fused inference over a ~400 000-voxel ROI of a
+            # 256x256x192 volume (synthetic, z-scored noise), labels + probabilities from one pass (--mode cohort times the
+            # whole of test_scan, files included)
+            dims = (256, 256, 192)
+            g = torch.Generator(device=dev)
+            g.manual_seed(7 + rank)
+            vol = torch.randn(dims, generator=g, device=dev, dtype=torch.float32)
+            e = torch.rand(dims + (15,), generator=g, device=dev, dtype=torch.float32)
+            atlas4d = (e / e.sum(-1, keepdim=True)).contiguous()
+            zz, yy, xx = torch.meshgrid(*[torch.arange(s, device=dev) for s in dims], indexing='ij')
+            roi = (((zz - 128) / 60.0) ** 2 + ((yy - 128) / 52.0) ** 2 + ((xx - 96) / 31.0) ** 2) <= 1.0
+            centers = torch.nonzero(roi).to(torch.int32).contiguous()          # C order, like np.nonzero (base.py:310-331)
+            B = int(centers.shape[0])
+            probs = torch.empty((B, 15), device=dev)
+            labels = torch.empty((B,), dtype=torch.int32, device=dev)
+
+            def step():
+                h.forward_volume(vol, dims, centers, atlas4d, B, probs, labels, st)
+            workload = 'gather-fused whole-subject inference (scs_forward_volume), 256x256x192 volume, %d ROI voxels per GPU (BASELINE configs[4], GPU stage)' % B
+        flop_per_patch = FWD_FLOP
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = dist.max_scalar(time.perf_counter() - t0)
+        value = world * B * args.steps / dt
+        dt_ms = 1e3 * dt / args.steps
 
     out = {
         'metric': 'tri-view 32x32 patches/s (%s)' % {'forward': 'forward', 'train': 'train step', 'volume': 'forward, gather-fused'}[args.mode],
-        'value': value, 'unit': 'patches/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'value': value, 'unit': 'patches/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'dist_backend': backend,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': workload, 'weights': 'miccai2012_v1 (shipped)', 'per_gpu_batch': B, 'chunk': chunk,
                    'parallelism': 'independent patch shards, no data-path collective' if args.mode != 'train'
@@ -308,48 +495,30 @@ def main():
         ms = ms.astype(np.float64)
         dur = float(ms[dom]) / launches * 1e-3
         achieved = flop_launch / dur / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')           # filled from rocprofv3 --pmc passes
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(STAGE_NAMES[dom])
-            except Exception:
-                traffic = None
+        traffic, note = measured_traffic(STAGE_NAMES[dom]) if B == 100000 else (None, 'measured at the default batch only')
         out['roofline'] = {'bound': 'mfma', 'kernel': STAGE_NAMES[dom], 'achieved': achieved, 'peak': PEAK_F32_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic,
+                           'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_source': note,
                            'launch_ms': dur * 1e3, 'patches_per_launch': per_launch_patches}
         out['stages'] = {STAGE_NAMES[i]: {'ms_per_step': float(ms[i]),
                                           'tflops': float(2.0 * STAGE_MACS[i] * B / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else None}
                          for i in range(8)}
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
-    if rank == 0 and args.mode == 'train':
-        # dominant training kernel: every launch of one step timed with HIP events on the stream it is issued on
-        # (scs_train_step_profiled; the weight-gradient kernels run on the library's side stream), averaged over a few steps
-        reps = 5
-        acc = {}
-        for r in range(reps):
-            for k, v in h.train_step_profiled(ax, co, sa, at, y, B, seed=1000 + r, stream=st).items():
-                acc[k] = acc.get(k, 0.0) + v / reps
-        conv_macs = {'conv1+conv2 fwd': 3 * (162000 + 2822400), 'conv3 fwd': 3 * 1036800, 'conv4 fwd': 3 * 1440000, 'conv5 fwd': 3 * 194400,
-                     'conv5 dgrad': 3 * 194400, 'conv4 dgrad': 3 * 1440000, 'conv3 dgrad': 3 * 1036800,
-                     'conv2 dgrad + layer-1 sums': 3 * (2822400 + 162000), 'conv5 wgrad': 3 * 194400, 'conv4 wgrad': 3 * 1440000,
-                     'conv3 wgrad': 3 * 1036800, 'conv2 wgrad': 3 * 2822400}
-        dom = max(conv_macs, key=lambda k: acc.get(k, 0.0))
-        dur = acc[dom] * 1e-3
-        achieved = 2.0 * conv_macs[dom] * B / dur / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get('train: ' + dom)
-            except Exception:
-                traffic = None
-        out['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'launch_ms': acc[dom], 'patches_per_launch': B}
-        out['stages'] = {k: {'ms': v, 'tflops': (2.0 * conv_macs[k] * B / (v * 1e-3) / 1e12) if k in conv_macs and v > 0 else None}
-                         for k, v in acc.items()}
-        out['launches_per_step'] = len([k for k, v in acc.items() if v > 0])
-        out['sum_of_launch_ms'] = float(sum(acc.values()))
+    if args.mode == 'train' and rank == 0:
+        for k in ('roofline', 'stages', 'launches_per_step', 'sum_of_launch_ms'):
+            out[k] = train_out[k]
+    if args.mode == 'forward' and not args.no_train_block:
+        # the other half of BASELINE.json's metric, in the same driver-run line: the training step at batch 256 (configs[2])
+        # and 128 (nolearn's effective batch in the reference), every rank takes part (the step has a collective when N > 1)
+        del ax, co, sa, at, probs, labels
+        blk = {}
+        for tb in (256, 128):
+            r, _ = measure_train(torch, dist, h, tb, args.train_steps, 20, rank, world, dev, st, profile=True)
+            if rank == 0:
+                r['frac_of_f32_peak'] = r['net_frac_of_f32_peak']
+                blk['batch%d' % tb] = r
+        if rank == 0:
+            out['train_step'] = dict(blk, metric='tri-view 32x32 patches/s (train step: scs_train_step + all-reduce + scs_adam_apply)',
+                                     flop_per_patch=TRAIN_FLOP, dtype='f32', data='synthetic')
     if rank == 0 and world == 1 and not args.no_cpu:
         out['cpu_baseline'] = {'train': cpu_baseline_train, 'volume': cpu_baseline_volume, 'forward': cpu_baseline}[args.mode](weights)
     if rank == 0:

@@ -132,6 +132,8 @@ class Net:
         self._dirty = True           # host params newer than device
         self._dev_newer = False      # device params newer than host (after training steps)
         self._step = 0
+        self.gpu_seconds = 0.0       # device time of predict_volume calls (HIP events; bench.py --mode cohort reads it)
+        self.last_scan_voxels = 0
 
     # ------------------------------------------------------------------ device plumbing
     def _torch(self):
@@ -339,6 +341,8 @@ class Net:
         h = self._ensure_handle()
         dev = 'cuda:%d' % self._dev()
         stream = torch.cuda.current_stream(self._dev()).cuda_stream
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         d_vol = torch.from_numpy(volume).to(dev)
         d_atl = torch.from_numpy(atlas_rows if atlas_rows is not None else atlas4d).to(dev)
         d_cen = torch.from_numpy(centers).to(dev)
@@ -354,7 +358,12 @@ class Net:
                 h.forward_volume(d_vol, volume.shape, d_cen[lo:hi], d_atl, hi - lo,
                                  d_pr[lo:hi] if want_probs else None, d_lab[lo:hi], stream)
         labels = d_lab.cpu().numpy().astype(np.int64)
-        return labels, (d_pr.cpu().numpy() if want_probs else None)
+        probs = d_pr.cpu().numpy() if want_probs else None
+        ev1.record()
+        ev1.synchronize()
+        self.gpu_seconds += ev0.elapsed_time(ev1) * 1e-3
+        self.last_scan_voxels = n
+        return labels, probs
 
     def dilate_mask(self, mask, iterations=10):
         """scipy.ndimage.binary_dilation(mask, iterations=iterations) (default 6-neighbour structure, border 0) on the GPU:

@@ -26,7 +26,7 @@ def run_bench(args):
 
 @pytest.mark.parametrize('mode', ['forward', 'train'])
 def test_bench_line(mode):
-    out = run_bench(['--mode', mode, '--steps', '3', '--warmup', '1'] + (['--batch', '8192'] if mode == 'forward' else []))
+    out = run_bench(['--mode', mode, '--steps', '3', '--warmup', '1'] + (['--batch', '8192', '--train-steps', '20'] if mode == 'forward' else []))
     assert KEYS <= set(out), KEYS - set(out)
     assert out['n_gpus'] == 1 and out['steps'] == 3 and out['warmup'] == 1 and out['unit'] == 'patches/s'
     assert out['dtype'] == 'f32' and out['data'] == 'synthetic' and out['vs_baseline'] is None and out['scaling'] == 'weak'
@@ -38,3 +38,13 @@ def test_bench_line(mode):
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and cb['unit'] == 'patches/s' and cb['sample']
     if mode == 'train':
         assert out['launches_per_step'] <= 30 and 'conv2 dgrad + layer-1 sums' in out['stages']
+    else:
+        # the default (forward) line also carries the training step: BASELINE.json's metric is "fwd & train step"
+        ts = out['train_step']
+        assert out['ranks_seen'] == 1
+        for key, bsz in (('batch256', 256), ('batch128', 128)):
+            blk = ts[key]
+            assert blk['per_gpu_batch'] == bsz and blk['steps'] == 20 and blk['unit'] == 'patches/s'
+            assert abs(blk['ms_per_step'] * blk['value'] / 1e3 - bsz) < 1.0
+            assert 0.02 < blk['frac_of_f32_peak'] < 1.0 and blk['launches_per_step'] <= 30
+            assert blk['roofline']['bound'] == 'mfma' and blk['roofline']['launch_ms'] > 0 and blk['stages']

@@ -178,7 +178,10 @@ int scs_train_step_profiled(scs_handle h, const float* ax_dev, const float* co_d
 
 /* Test hook: copy an intermediate of the LAST training step to the host.  which: 0 d(fc_2 pre-activation) [n][272],
  * 1 d(FC1 pre-activation) [n][540], 2 d(d1 pre-activations) [n][540], 3 f1_drop(feat) [n][540], 4 relu(FC1) [n][540],
- * 5 fc_2 input [n][556], 6 d logits [n][16].  count = floats to copy. */
+ * 5 fc_2 input [n][556], 6 d logits [n][16], 7 relu(fc_2) [n][272], 8 relu(d1) of the three towers [n][540];
+ * 100 + 10 t + i: raw conv output of block i (2..5) of tower t, [n][Cout_i][Ho][Ho]; 200 + 10 t + i: the (scale, shift) pairs
+ * the step applied as that block's batch norm (i = 1..5), float2 [Cout_i].  With these a test can read off every ReLU gate and
+ * max-pool routing decision the float32 step took.  count = floats to copy. */
 int scs_get_train_buffer(scs_handle h, int which, float* host_out, size_t count);
 
 /* Device pointers to the parameter and gradient arenas (SCS_N_PARAMS floats each) - the gradient arena is

@@ -182,14 +182,45 @@ def _pool_bwd(x, y, g):
     return (x == up(y)) * up(g)
 
 
-def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None):
+def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None, gates=None):
     """One training forward/backward in float64 (deterministic=False semantics).
 
     masks: dict with 0/1 arrays 'axial_l1drop','coronal_l1drop','saggital_l1drop' [N,60,3,3],
            'f1_drop' [N,540], 'f2_drop' [N,540]   (Bernoulli(0.5) keep masks; x*mask/(1-p)).
+    gates: optional forced decisions of the BACKWARD pass, for comparing with a float32 implementation whose pre-activations
+           within rounding of zero (or of a tied pooling window) fall on the other side: {'relu': {name: bool array shaped like
+           the layer's pre-activation}, 'pool': {name: bool array shaped like the pooling INPUT, True where the window's
+           gradient goes}}; names '<tower>_conv<i>', '<tower>_d1', 'FC1', 'fc_2'.  The forward pass is not touched (a
+           pre-activation of +-1e-7 contributes nothing either way).  With `debug`, debug['forced'] lists per name how many
+           decisions differ from the oracle's own and the largest |pre-activation| (relative to the layer's largest) among them.
     Returns loss, grads {layer: [arrays]} (zeros for BN mean/inv_std), bn_batch {layer: (mean, inv_std)},
     probs [N,15].
     """
+    forced = {}
+
+    def act_bwd(name, pre, r, alpha, g):
+        """Backward of prelu(relu(pre)): -> (d pre, d alpha).  Forced gate: PReLU on a ReLU output is the identity wherever the
+        gate is open, whatever value the oracle's own forward pass holds there (its r may be 0 where the float32 step saw
+        +1e-8: the PReLU derivative AT zero, 0.5 (1 + alpha), must not enter)."""
+        fg = (gates or {}).get('relu', {}).get(name)
+        gp, da = _prelu_bwd(r, alpha, g)
+        if fg is None:
+            return _relu_bwd(pre, gp), da
+        fg = np.asarray(fg, bool).reshape(pre.shape)
+        diff = fg != (pre > 0)
+        forced['relu:' + name] = (int(diff.sum()), float(np.abs(pre[diff]).max() / max(np.abs(pre).max(), 1e-300)) if diff.any() else 0.0)
+        return g * fg, da
+
+    def pool_bwd(name, x, yv, g):
+        fg = (gates or {}).get('pool', {}).get(name)
+        up = lambda t: t.repeat(2, axis=2).repeat(2, axis=3)
+        if fg is None:
+            return _pool_bwd(x, yv, g)
+        fg = np.asarray(fg, bool).reshape(x.shape)
+        diff = (fg != (x == up(yv))) & (up(yv) > 0)          # (windows without a positive value: the ReLU gate closes them anyway)
+        forced['pool:' + name] = (int(diff.sum()), float(np.abs(x - up(yv))[diff].max() / max(np.abs(x).max(), 1e-300)) if diff.any() else 0.0)
+        return up(g) * fg
+
     P = _p64(params)
     N = ax.shape[0]
     grads = {k: [np.zeros_like(a) for a in v] for k, v in P.items()}
@@ -250,9 +281,8 @@ def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None):
     dz /= N
     grads['out_layer'] = [h2.T @ dz, dz.sum(0)]
     g = dz @ W3.T
-    g, da = _prelu_bwd(r2, P['prelu_f2'][0], g)
+    g, da = act_bwd('fc_2', pre2, r2, P['prelu_f2'][0], g)
     grads['prelu_f2'] = [da]
-    g = _relu_bwd(pre2, g)
     grads['fc_2'] = [cat2.T @ g, g.sum(0)]
     if debug is not None:
         debug.update(dpre2=g.copy(), cat2=cat2, r1=r1, cat_d=cat_d,
@@ -260,9 +290,8 @@ def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None):
                                      min(float(np.abs(cache[t]['pre']).min()) for t in TOWERS)))
     g = (g @ W2.T)[:, :540]                                  # the atlas input takes no gradient
     g = g / 0.5 * m2
-    g, da = _prelu_bwd(r1, P['prelu_f1'][0], g)
+    g, da = act_bwd('FC1', pre1, r1, P['prelu_f1'][0], g)
     grads['prelu_f1'] = [da]
-    g = _relu_bwd(pre1, g)
     grads['FC1'] = [cat_d.T @ g, g.sum(0)]
     if debug is not None:
         debug.update(dpre1=g.copy())
@@ -270,9 +299,8 @@ def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None):
     for ti, t in enumerate(TOWERS):
         ch = cache[t]
         gt = g[:, 180 * ti:180 * (ti + 1)]
-        gt, da = _prelu_bwd(ch['r'], P['%s_prelu_d1' % t][0], gt)
+        gt, da = act_bwd('%s_d1' % t, ch['pre'], ch['r'], P['%s_prelu_d1' % t][0], gt)
         grads['%s_prelu_d1' % t] = [da]
-        gt = _relu_bwd(ch['pre'], gt)
         W, b = P['%s_d1' % t]
         grads['%s_d1' % t] = [ch['hd'].reshape(N, -1).T @ gt, gt.sum(0)]
         gh = (gt @ W.T).reshape(ch['hd'].shape)
@@ -280,10 +308,9 @@ def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None):
         for i in range(5, 0, -1):
             rec = ch['convs'][i - 1]
             if i in (2, 4):
-                gh = _pool_bwd(rec['p'], rec['pooled'], gh)
-            gh, da = _prelu_bwd(rec['r'], rec['alpha'], gh)
+                gh = pool_bwd('%s_conv%d' % (t, i), rec['p'], rec['pooled'], gh)
+            gh, da = act_bwd('%s_conv%d' % (t, i), rec['yb'], rec['r'], rec['alpha'], gh)
             grads['%s_ch_prelu%d' % (t, i)] = [da]
-            gh = _relu_bwd(rec['yb'], gh)
             dgamma = (gh * rec['xhat']).sum(axis=(0, 2, 3))
             dbeta = gh.sum(axis=(0, 2, 3))
             M = gh.shape[0] * gh.shape[2] * gh.shape[3]
@@ -294,6 +321,8 @@ def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None):
             grads[name] = [dbeta, dgamma, np.zeros_like(dbeta), np.zeros_like(dbeta)]
             gh, dW = _conv_bwd(rec['x'], rec['W'], dzc)
             grads['%s_ch_conv%d' % (t, i)] = [dW]
+    if debug is not None:
+        debug['forced'] = forced
     return loss, grads, bn_batch, probs
 
 

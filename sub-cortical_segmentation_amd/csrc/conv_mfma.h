@@ -52,20 +52,26 @@ enum ConvSrc { SRC_NCHW = 0, SRC_CONV1 = 1, SRC_VOLUME = 2, SRC_NCHW_PAD2 = 3, S
                SRC_DZ_POOL_PAD2 = 7, SRC_X0 = 8 };
 
 // FIN_ = 1 (EPI_RAW_STATS / EPI_RAW_BNB*): the workgroup of a tower that finishes last also finalizes the batch-norm sums
-// (what a separate tiny launch would do: in the stream that launch costs ~9 us, the tail 5-6 us - two-level arrival tickets,
-// see arrive_last).
-// NSPLIT_ = 1 (one or two M tiles per workgroup - the conv5 block): the waves split the output channels instead of the
-// tiles, B operands come straight from global memory; no weight buffer in LDS.
+// (what a separate tiny launch would do: in the stream that launch costs ~9 us - two-level tree of tickets and partial
+// reductions, see take_ticket / bn_grp_* / bn_top_*).
+// NSPLIT_ = KS > 0 (the 3x3 / 5x5 planes of the conv5 block: a handful of M tiles per workgroup, whose matrix work is tiny next
+// to the latency of staging and weight streaming): GEMM-style K split.  The NT16 * KS waves of a workgroup are (channel pair
+// p, K part ks): wave (p, ks) owns the 16-wide block p and the 4-wide block p of ALL M tiles of the workgroup's G patches, over
+// the input-channel chunks [ks * NC4 / KS, (ks + 1) * NC4 / KS).  Its B operands come straight from global memory (every
+// workgroup reads the same packed weights: L2), ALL of them requested at kernel start - one round trip that hides behind the
+// staging - and each is used for every tile, so a weight element is fetched once per G patches instead of once per patch.
+// No weight buffer in LDS, no barrier inside the loop; the KS partial sums are added through LDS in a fixed order.
 // Derived: SHARED (4q + 1 tiles on 4 waves: the odd tile's channel blocks are dealt to the waves); tile ownership rotates
 // with the workgroup index (see the kernel).
 template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_, int NB_ = 1, int WPS_ = 1, int STAMP_ = 0, int NW_ = 4, int FIN_ = 0,
           int NSPLIT_ = 0>
 struct ConvCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_, FIN = FIN_;
-    static_assert(!FIN_ || (NW_ == 4 && (EPI_ == EPI_RAW_STATS || EPI_ == EPI_RAW_BNB || EPI_ == EPI_RAW_BNB_POOL)), "in-kernel finalize: 256-thread statistics kernels");
-    static_assert(!FIN_ || NB_ == 1, "in-kernel finalize: the ticket words are sized for one workgroup per patch");
+    static_assert(!FIN_ || (NW_ >= 4 && (EPI_ == EPI_RAW_STATS || EPI_ == EPI_RAW_BNB || EPI_ == EPI_RAW_BNB_POOL)), "in-kernel finalize: statistics kernels of at least 256 threads");
+    static_assert(!FIN_ || (NB_ == 1 && G_ == 1), "in-kernel finalize: one statistics unit per workgroup");
     static constexpr int NW = NW_, NTH = 64 * NW_;          // waves / threads per workgroup
-    static constexpr bool NSPLIT = NSPLIT_ != 0;            // one or two M tiles: the waves split the output channels (see the kernel)
+    static constexpr bool NSPLIT = NSPLIT_ != 0;            // K split over waves of (channel pair, K part) (see above)
+    static constexpr int KS = NSPLIT_ > 0 ? NSPLIT_ : 1;
     static constexpr bool PAD2 = (SRC_ == SRC_NCHW_PAD2 || SRC_ == SRC_DZ_PAD2 || SRC_ == SRC_DZ_POOL_PAD2);
     static constexpr bool FUSED1 = (SRC_ == SRC_CONV1 || SRC_ == SRC_VOLUME || SRC_ == SRC_X0);
     // PAD2: the global input is (HIN_-4)^2 and is zero-padded by 2 on every side in LDS (dgrad)
@@ -111,7 +117,10 @@ struct ConvCfg {
     // fetched at kernel start); the waves' partial sums reuse the space behind the restaged outputs
     static constexpr int L1_X_FLOATS = (HOB + 2) * 32 + 8, L1_TAB_FLOATS = 240, L1_RED_FLOATS = NW_ * 20 * 16;
     static constexpr int L1_PRE_FLOATS = EPI_ == EPI_L1 ? L1_X_FLOATS + L1_TAB_FLOATS : 0;
-    static constexpr int EPI_FLOATS = OUT_FLOATS + (EPI_ == EPI_L1 ? L1_RED_FLOATS : 0);
+    // NSPLIT: the waves' partial tiles [KS][TILES * 16 rows][COUT] sit behind the restaged outputs
+    static constexpr int OUT_FLOATS_AL = (OUT_FLOATS + 3) / 4 * 4;
+    static constexpr int KRED_FLOATS = NSPLIT_ ? KS * TILES * 16 * COUT_ : 0;
+    static constexpr int EPI_FLOATS = (NSPLIT_ ? OUT_FLOATS_AL + KRED_FLOATS : OUT_FLOATS) + (EPI_ == EPI_L1 ? L1_RED_FLOATS : 0);
     static constexpr int WBUF_FLOATS = NSPLIT_ ? 0 : 2 * WCHUNK;   // double-buffered weight chunks (NSPLIT: operands come straight from global memory)
     static constexpr int MAIN_FLOATS = IN_FLOATS_AL + WBUF_FLOATS + XS_FLOATS;
     static_assert(EPI_ != EPI_L1 || EPI_FLOATS <= MAIN_FLOATS, "EPI_L1 scratch must not reach the prefetched input rows");
@@ -128,9 +137,10 @@ struct ConvCfg {
     static_assert(SRC_ != SRC_DZ_POOL_PAD2 || (HINB % 2 == 0 && HIN_ % 2 == 0 && PLANE_ % 2 == 0 && (NB_ == 1 || HOB % 2 == 0)),
                   "pooled d z staging walks 2x2 windows");
     static_assert(EPI_ != EPI_L1 || (COUT_ == 20 && HO == 30 && G_ == 1 && NW_ == 4), "EPI_L1 is the conv2 data gradient");
-    static_assert(!NSPLIT_ || (NW_ == 4 && RAW && !FUSED1 && EPI_ != EPI_L1 && NT16 == NT4 &&
-                               ((TILES == 1 && NT16 <= 4) || (TILES == 2 && NT16 == 2))),
-                  "NSPLIT: raw training kernels with one M tile (a wave per 16 + 4 channel block pair) or two (tile x pair)");
+    static_assert(!NSPLIT_ || (NW_ == NT16 * KS && RAW && !FUSED1 && EPI_ != EPI_L1 && NT16 == NT4 && NT16 >= 1 && NB_ == 1 &&
+                               NC4 % KS == 0 && TILES <= 8),
+                  "NSPLIT: raw training kernels, Cout = pairs of a 16-wide and a 4-wide block, NT16 * KS waves, KS divides the chunks");
+    static_assert(!FIN_ || LDS_BYTES >= (size_t)NTH * 3 * 8 + 16, "finalize scratch");
 };
 
 // the 32x32 input patches of a training batch: given as three [n][32][32] arrays, or cut on the fly from z-scored
@@ -159,6 +169,7 @@ __device__ __forceinline__ int4 x0_sample(const X0Src& s, int g) {
 // what the last workgroup of a tower needs to turn the partial sums into batch-norm coefficients (FIN configurations)
 struct FinArgs {
     unsigned int* counter;        // arrival tickets, zero between launches: fin_counter_words(workgroups per tower) words per tower
+    double* grp;                  // group records: [tower][fin_groups(workgroups per tower)][kFinRec][2]
     double count;                 // values per channel over the batch
     float* bn[kTowers];           // forward: this layer's (beta, gamma, mean, inv_std) in the parameter arena; backward: the
                                   // layer below's (d beta, d gamma, -, -) slot in the gradient arena
@@ -166,18 +177,25 @@ struct FinArgs {
     float* coef[kTowers];         // forward: float4 [COUT] (sc, sh, mean, inv_std) out; backward: float4 [COUT] (sc, sh, ca, cb) out
 };
 
-// Arrival tickets are a two-level tree: groups of kFinGroup workgroups share a counter (each on its own 128-byte line), the
-// workgroup that completes a group takes a ticket on the tower's top counter.  Same-address device-scope atomics retire one
-// at a time (~50 ns each on MI355X, tools/gridbar.hip): a flat counter makes the last of 256 simultaneously finishing
-// workgroups wait ~13 us for its ticket, the tree ~1.5 us.
+// The in-kernel finalize is a two-level tree over the workgroups of a tower, in arrival tickets AND in arithmetic: groups of
+// kFinGroup workgroups share a ticket counter (each on its own 128-byte line); the workgroup that completes a group reduces
+// that group's partial sums to one record per channel, then takes a ticket on the tower's top counter; the workgroup that
+// completes the top counter combines the group records.  Same-address device-scope atomics retire one at a time (~50 ns
+// each on MI355X, tools/gridbar.hip): a flat counter makes the last of 256 simultaneously finishing workgroups wait ~13 us
+// for its ticket, the tree ~1.5 us; and the last workgroup reads units / kFinGroup records instead of every unit, so the tail
+// of the kernel does not grow with the batch.  Which workgroup arrives last changes nothing in the arithmetic: groups are
+// fixed by the workgroup index and every sum runs in index order (deterministic).
 constexpr int kFinGroup = 16, kFinLine = 32;
 constexpr size_t fin_counter_words(size_t wgs_per_tower) { return (1 + (wgs_per_tower + kFinGroup - 1) / kFinGroup) * kFinLine; }
+constexpr size_t fin_groups(size_t wgs_per_tower) { return (wgs_per_tower + kFinGroup - 1) / kFinGroup; }
+constexpr int kFinRec = 64;                                   // group records per group: [64 channels] x (double, double)
 
-// Cross-workgroup hand-off of the partial sums without any fence on the producers: the sums are stored write-through
-// (`sc1`: they never sit dirty in an XCD's L2), every storing wave drains its stores, and one lane per workgroup takes a
-// ticket; the workgroup whose ticket completes the count invalidates its L1 once and reads the sums with `sc1` loads.
+// Cross-workgroup hand-off of the partial sums without any fence: the sums are stored write-through (`sc1`: they never sit
+// dirty in an XCD's L2), every storing wave drains its stores (vmcnt(0)) in front of the workgroup barrier behind which ONE
+// lane takes the ticket, and every load of handed-off data is an `sc1` load to registers (served by L2 / memory, never by a
+// CU's L1) issued after the ticket that completed the count has returned (MI355X_MICROARCH.md, "Valid forms").
 // This hand-off is valid only where vector stores are counted by vmcnt and `sc1` stores write through - the gfx942 / gfx950
-// family (MI355X_MICROARCH.md, "Valid forms").  On a target that counts stores in vscnt the ticket could overtake the sums.
+// family.  On a target that counts stores in vscnt the ticket could overtake the sums.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
 #error "conv_mfma.h: the in-kernel batch-norm finalize (FIN configurations) relies on gfx942/gfx950 memory-counter semantics"
 #endif
@@ -187,59 +205,83 @@ __device__ __forceinline__ void st_sc1(float2* p, float2 v) {
 __device__ __forceinline__ float2 ld_sc1(const float2* p) {
     return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__device__ __forceinline__ bool arrive_last(unsigned int* counter /* this tower's words */, unsigned int nwg, unsigned int wg, volatile int* s_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial sums have left
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+    return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// One ticket on `c` behind this workgroup's drained stores; true in every thread when it completed `full` arrivals (the
+// counter is re-armed for the next launch).
+__device__ __forceinline__ bool take_ticket(unsigned int* c, unsigned int full, volatile int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int g = wg / kFinGroup, groups = (nwg + kFinGroup - 1) / kFinGroup;
-        const unsigned int gsize = min((unsigned int)kFinGroup, nwg - g * kFinGroup);
-        unsigned int* gc = counter + (size_t)kFinLine * (1 + g);
-        bool last = false;
-        if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
-            __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               // re-armed for the next launch
-            if (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
-                __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                last = true;
-            }
-        }
+        const bool last = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == full - 1;
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_flag = last ? 1 : 0;
     }
     __syncthreads();
     return *s_flag != 0;
 }
 
-// Finalize by the last workgroup (256 threads).  Thread (j, c) = (tid / CH, tid % CH) walks units j, j + J, ... of channel
-// c (J = 256 / CH): a wave's loads cover whole rows of the [units][CH] table, and kFinBatch of them are in flight at once.
-constexpr int kFinBatch = 20;
+constexpr int kFinBatch = 8;
 
-// Forward (same arithmetic as scs_train.hip: bn_fwd_final_kernel): units of (mean, M2) over count / units values each ->
-// batch mean / biased variance by the parallel-variance formula in double, fixed order.
+// ---- forward statistics.  A unit is (mean, M2 = sum of squared deviations) of `per_unit` values.
+// group step: units [u0, u0 + k) of channel c -> (mean_g, M2_g) by the parallel-variance formula in double, about the first
+// unit's mean (exact differences)
 template <int CH>
-__device__ __forceinline__ void bn_fin_forward(const float2* __restrict__ part /*[units][CH]*/, int units, double count, float* bn,
-                                               float2* __restrict__ ss, float4* __restrict__ low4, double* s_acc /*[256][3]*/) {
-    constexpr int J = 256 / CH;
+__device__ __forceinline__ void bn_grp_forward(const float2* __restrict__ part /*[units][CH]*/, int u0, int k, double per_unit,
+                                               double* __restrict__ rec /*[kFinRec][2]*/) {
+    const int c = threadIdx.x;
+    if (c < CH) {
+        float2 v[kFinGroup];
+#pragma unroll
+        for (int i = 0; i < kFinGroup; ++i) v[i] = ld_sc1(part + (size_t)(u0 + min(i, k - 1)) * CH + c);
+        const double m0 = (double)v[0].x;
+        double s = 0, s2 = 0, q = 0;
+#pragma unroll
+        for (int i = 0; i < kFinGroup; ++i)
+            if (i < k) { const double d = (double)v[i].x - m0; s += d; s2 += d * d; q += (double)v[i].y; }
+        const double dm = s / k;
+        st_sc1(rec + 2 * c, m0 + dm);
+        st_sc1(rec + 2 * c + 1, q + per_unit * fmax(s2 - s * dm, 0.0));
+    }
+}
+// top step: group records (group g holds min(kFinGroup, units - g kFinGroup) units) -> batch mean / biased variance -> scale /
+// shift for the next conv's staging, (sc, sh, mean, inv_std) for the backward pass, running averages (alpha 0.1)
+template <int CH, int NTH>
+__device__ __forceinline__ void bn_top_forward(const double* __restrict__ rec /*[groups][kFinRec][2]*/, int groups, int units, double per_unit,
+                                               float* bn, float2* __restrict__ ss, float4* __restrict__ low4, double* s_acc /*[NTH][3]*/) {
+    constexpr int J = NTH / CH;
     const int tid = threadIdx.x, j = tid / CH, c = tid - j * CH;
     double s = 0, s2 = 0, q = 0, m0 = 0;
     if (j < J) {
-        m0 = (double)ld_sc1(part + c).x;
-        for (int u0 = j; u0 < units; u0 += kFinBatch * J) {
-            float2 v[kFinBatch];
+        m0 = ld_sc1(rec + 2 * c);
+        for (int g0 = j; g0 < groups; g0 += kFinBatch * J) {
+            double mg[kFinBatch], qg[kFinBatch];
 #pragma unroll
-            for (int k = 0; k < kFinBatch; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * J, units - 1) * CH + c);
+            for (int i = 0; i < kFinBatch; ++i) {
+                const double* r = rec + ((size_t)min(g0 + i * J, groups - 1) * kFinRec + c) * 2;
+                mg[i] = ld_sc1(r); qg[i] = ld_sc1(r + 1);
+            }
 #pragma unroll
-            for (int k = 0; k < kFinBatch; ++k)
-                if (u0 + k * J < units) { const double d = (double)v[k].x - m0; s += d; s2 += d * d; q += v[k].y; }
+            for (int i = 0; i < kFinBatch; ++i) {
+                const int g = g0 + i * J;
+                if (g < groups) {
+                    const double ng = per_unit * min(kFinGroup, units - g * kFinGroup), d = mg[i] - m0;
+                    s += ng * d; s2 += ng * d * d; q += qg[i];
+                }
+            }
         }
     }
     s_acc[tid * 3] = s; s_acc[tid * 3 + 1] = s2; s_acc[tid * 3 + 2] = q;
     __syncthreads();
     if (tid < CH) {
         s = s2 = q = 0;
-        for (int k = 0; k < J; ++k) { s += s_acc[(tid + k * CH) * 3]; s2 += s_acc[(tid + k * CH) * 3 + 1]; q += s_acc[(tid + k * CH) * 3 + 2]; }
-        const double dm = s / units, mean = m0 + dm;
-        const double var = (q + (count / units) * fmax(s2 - s * dm, 0.0)) / count;
+        for (int i = 0; i < J; ++i) { s += s_acc[(tid + i * CH) * 3]; s2 += s_acc[(tid + i * CH) * 3 + 1]; q += s_acc[(tid + i * CH) * 3 + 2]; }
+        const double count = per_unit * units, dm = s / count, mean = m0 + dm;
+        const double var = (q + fmax(s2 - s * dm, 0.0)) / count;
         const double inv = 1.0 / sqrt(var + (double)kBnEps);
         const float sc = bn[CH + c] * (float)inv, sh = bn[c] - (float)mean * sc;
         ss[c] = make_float2(sc, sh);
@@ -249,30 +291,48 @@ __device__ __forceinline__ void bn_fin_forward(const float2* __restrict__ part /
     }
 }
 
-// Backward finalize (bn_bwd_final_kernel): (d beta, d gamma) partial sums -> gradients + the coefficients of
-// d z = [y > 0] sc dUp + ca z + cb,  ca = -sc inv mg,  cb = sc (inv mean mg - mb),  mb = d beta / M,  mg = d gamma / M.
+// ---- backward: units are (d beta, d gamma) partial sums
 template <int CH>
-__device__ __forceinline__ void bn_fin_backward(const float2* __restrict__ part /*[units][CH]*/, int units, double count,
-                                                const float4* __restrict__ low4, float* __restrict__ gbn, float4* __restrict__ cf4,
-                                                double* s_acc /*[256][3]*/) {
-    constexpr int J = 256 / CH;
+__device__ __forceinline__ void bn_grp_backward(const float2* __restrict__ part, int u0, int k, double* __restrict__ rec) {
+    const int c = threadIdx.x;
+    if (c < CH) {
+        float2 v[kFinGroup];
+#pragma unroll
+        for (int i = 0; i < kFinGroup; ++i) v[i] = ld_sc1(part + (size_t)(u0 + min(i, k - 1)) * CH + c);
+        double sb = 0, sg = 0;
+#pragma unroll
+        for (int i = 0; i < kFinGroup; ++i)
+            if (i < k) { sb += (double)v[i].x; sg += (double)v[i].y; }
+        st_sc1(rec + 2 * c, sb);
+        st_sc1(rec + 2 * c + 1, sg);
+    }
+}
+// (d beta, d gamma) -> gradients + the coefficients of d z = [y > 0] sc dUp + ca z + cb,
+// ca = -sc inv mg,  cb = sc (inv mean mg - mb),  mb = d beta / M,  mg = d gamma / M.
+template <int CH, int NTH>
+__device__ __forceinline__ void bn_top_backward(const double* __restrict__ rec, int groups, double count, const float4* __restrict__ low4,
+                                                float* __restrict__ gbn, float4* __restrict__ cf4, double* s_acc /*[NTH][3]*/) {
+    constexpr int J = NTH / CH;
     const int tid = threadIdx.x, j = tid / CH, c = tid - j * CH;
     double sb = 0, sg = 0;
     if (j < J) {
-        for (int u0 = j; u0 < units; u0 += kFinBatch * J) {
-            float2 v[kFinBatch];
+        for (int g0 = j; g0 < groups; g0 += kFinBatch * J) {
+            double bg[kFinBatch], gg[kFinBatch];
 #pragma unroll
-            for (int k = 0; k < kFinBatch; ++k) v[k] = ld_sc1(part + (size_t)min(u0 + k * J, units - 1) * CH + c);
+            for (int i = 0; i < kFinBatch; ++i) {
+                const double* r = rec + ((size_t)min(g0 + i * J, groups - 1) * kFinRec + c) * 2;
+                bg[i] = ld_sc1(r); gg[i] = ld_sc1(r + 1);
+            }
 #pragma unroll
-            for (int k = 0; k < kFinBatch; ++k)
-                if (u0 + k * J < units) { sb += v[k].x; sg += v[k].y; }
+            for (int i = 0; i < kFinBatch; ++i)
+                if (g0 + i * J < groups) { sb += bg[i]; sg += gg[i]; }
         }
     }
     s_acc[tid * 3] = sb; s_acc[tid * 3 + 1] = sg;
     __syncthreads();
     if (tid < CH) {
         sb = sg = 0;
-        for (int k = 0; k < J; ++k) { sb += s_acc[(tid + k * CH) * 3]; sg += s_acc[(tid + k * CH) * 3 + 1]; }
+        for (int i = 0; i < J; ++i) { sb += s_acc[(tid + i * CH) * 3]; sg += s_acc[(tid + i * CH) * 3 + 1]; }
         gbn[c] = (float)sb; gbn[CH + c] = (float)sg;                                // mean / inv_std entries stay 0
         const float4 lo = low4[c];                                                  // sc, sh, mean, inv
         const double mb = sb / count, mg = sg / count, sc = lo.x, inv = lo.w, mean = lo.z;
@@ -540,6 +600,20 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         wr0 = reinterpret_cast<const float4*>(wsrc)[wi0];
         if constexpr (C::WPT > 1) wr1 = reinterpret_cast<const float4*>(wsrc)[wi1];
         if constexpr (C::WPT > 2) wr2 = reinterpret_cast<const float4*>(wsrc)[wi2];
+    }
+    // NSPLIT: wave (pr, ks) = (channel pair, K part); every B operand of its k-steps (chunks ks * CPW .. + CPW, 9 taps each)
+    // is requested now and lands under the staging below
+    constexpr int KS_CPW = C::NC4 / C::KS, KS_SPW = C::NSPLIT ? KS_CPW * 9 : 1;
+    const int ks_pr = C::NSPLIT ? wave % C::NT16 : 0, ks_part = C::NSPLIT ? wave / C::NT16 : 0;
+    float ks_b16[KS_SPW], ks_b4[KS_SPW];
+    if constexpr (C::NSPLIT) {
+        const float* __restrict__ wb = wsrc + (size_t)ks_part * KS_CPW * C::WCHUNK + kq * C::NS16 + lr + ks_pr * 16;                       // W[k = 4s + kq][cout = 16 p + lr]
+        const float* __restrict__ wl = wsrc + (size_t)ks_part * KS_CPW * C::WCHUNK + 36 * C::NS16 + kq * C::L4 + (lane & 3) + ks_pr * 4;   // W[k = 4s + kq][cout = 16 NT16 + 4 p + (lane & 3)]
+#pragma unroll
+        for (int i = 0; i < KS_SPW; ++i) {
+            ks_b16[i] = wb[(i / 9) * C::WCHUNK + (i % 9) * 4 * C::NS16];
+            ks_b4[i] = wl[(i / 9) * C::WCHUNK + (i % 9) * 4 * C::L4];
+        }
     }
 
     // per-lane epilogue bias, fetched now so its latency hides under the staging
@@ -847,81 +921,65 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
     }
 
     if constexpr (C::NSPLIT) {
-        // One or two M tiles per workgroup (the 3x3 / 5x5 outputs of the conv5 block): with tiles dealt to waves, one or two
-        // waves would do all the matrix work behind a barrier per weight chunk.  Instead wave w owns the channel pair
-        // (16-block p, 4-block p) of tile t: one tile -> (t, p) = (0, w), two tiles -> (w & 1, w >> 1).  Its B operands come
-        // straight from global memory (they are shared by every workgroup and sit in L2), four chunks ahead in registers:
-        // no weight buffer in LDS, no barrier inside the loop.
-        constexpr bool TWO = C::TILES == 2;
-#ifndef SCS_NS_DEPTH
-#define SCS_NS_DEPTH 4
-#endif
-        constexpr int DEPTH = SCS_NS_DEPTH;
-        const int tj = TWO ? (wave & 1) : 0, pr = TWO ? (wave >> 1) : wave;
-        const bool active = pr < C::NT16;
-        int abase_n;
-        {
-            const int m = min(tj * 16 + lr, C::MTOT - 1);
+        // GEMM-style K split (see ConvCfg): this wave multiplies ALL M tiles of the workgroup with its channel pair over its
+        // share of the input-channel chunks; A operands from the staged planes, B operands already in registers.
+        int abase_n[C::TILES];
+#pragma unroll
+        for (int j = 0; j < C::TILES; ++j) {
+            const int m = min(j * 16 + lr, C::MTOT - 1);
             const int g = m / C::PIXB, r = m - g * C::PIXB, y = r / C::HO, x = r - y * C::HO;
-            abase_n = (g * C::CIN + kq) * C::PLANE + y * C::WIN + x;
+            abase_n[j] = (g * C::CIN + kq) * C::PLANE + y * C::WIN + x;
         }
-        const int prc = min(pr, C::NT16 - 1);
-        const float* __restrict__ wb = wsrc + kq * C::NS16 + lr + prc * 16;                          // W[k = 4s + kq][cout = 16 p + lr]
-        const float* __restrict__ wl = wsrc + 36 * C::NS16 + kq * C::L4 + (lane & 3) + prc * 4;      // W[k = 4s + kq][cout = 16 NT16 + 4 p + (lane & 3)]
-        f32x4 accn = {0.f, 0.f, 0.f, 0.f}, acc4n = {0.f, 0.f, 0.f, 0.f};
+        f32x4 accn[C::TILES], acc4n[C::TILES];
+#pragma unroll
+        for (int j = 0; j < C::TILES; ++j) { accn[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc4n[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         __syncthreads();                                     // the staged planes are visible
         if constexpr (C::STAMP) { if (tid == 0) stp[2] = __builtin_amdgcn_s_memtime(); }
-        if (active) {
-            float bq[DEPTH][9], lq[DEPTH][9];
+        {
+            const float* __restrict__ sa = s_in + ks_part * KS_CPW * 4 * C::PLANE;
 #pragma unroll
-            for (int c = 0; c < DEPTH - 1; ++c)
+            for (int i = 0; i < KS_SPW; ++i) {
+                const int off = (i / 9) * 4 * C::PLANE + ((i % 9) / 3) * C::WIN + (i % 9) % 3;
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int cc = min(c, C::NC4 - 1);
-                    bq[c][tap] = wb[cc * C::WCHUNK + tap * 4 * C::NS16];
-                    lq[c][tap] = wl[cc * C::WCHUNK + tap * 4 * C::L4];
-                }
-            // the A operands of a chunk (9 LDS reads) are requested one chunk ahead as well: a wave has nothing else to
-            // hide an LDS round trip per MFMA behind
-            float aq[2][9];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) aq[0][tap] = s_in[abase_n + (tap / 3) * C::WIN + (tap % 3)];
-#pragma unroll
-            for (int c4 = 0; c4 < C::NC4; ++c4) {
-                if (c4 + DEPTH - 1 < C::NC4) {
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        bq[(c4 + DEPTH - 1) % DEPTH][tap] = wb[(c4 + DEPTH - 1) * C::WCHUNK + tap * 4 * C::NS16];
-                        lq[(c4 + DEPTH - 1) % DEPTH][tap] = wl[(c4 + DEPTH - 1) * C::WCHUNK + tap * 4 * C::L4];
-                    }
-                }
-                if (c4 + 1 < C::NC4) {
-                    const float* __restrict__ sa = s_in + (c4 + 1) * 4 * C::PLANE + abase_n;
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) aq[(c4 + 1) & 1][tap] = sa[(tap / 3) * C::WIN + (tap % 3)];
-                }
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const float av = aq[c4 & 1][tap];
-                    accn = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[c4 % DEPTH][tap], accn, 0, 0, 0);
-                    acc4n = __builtin_amdgcn_mfma_f32_4x4x1f32(lq[c4 % DEPTH][tap], av, acc4n, 0, 0, 0);
+                for (int j = 0; j < C::TILES; ++j) {
+                    const float av = sa[abase_n[j] + off];
+                    accn[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ks_b16[i], accn[j], 0, 0, 0);
+                    acc4n[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(ks_b4[i], av, acc4n[j], 0, 0, 0);
                 }
             }
         }
         if constexpr (C::STAMP) { if (tid == 0) stp[3] = __builtin_amdgcn_s_memtime(); }
         __syncthreads();                                     // every wave has read its planes: the LDS becomes the output stage
-        float* s_o = smem;
-        const float val4 = ksub_reduce(acc4n, kq, (lane ^ 32) << 2);                                // this lane: cout 16 NT16 + 4 p + kq
-        if (active) {
+        // partial tiles -> s_red[ks][row m][cout] (the 4-wide blocks' k-subgroup partials are combined across the lanes first)
+        constexpr int MROWS = C::TILES * 16;
+        float* s_red = smem + C::OUT_FLOATS_AL;
+        {
+            float* rw = s_red + (size_t)ks_part * MROWS * C::COUT;
+            const int xor32_addr = (lane ^ 32) << 2;
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int m = tj * 16 + kq * 4 + r4;
-                if (m < C::MTOT) { const int g = m / C::PIXB, r = m - g * C::PIXB; s_o[(g * C::COUT + pr * 16 + lr) * C::OSTR + r] = accn[r4]; }
+            for (int j = 0; j < C::TILES; ++j) {
+                const float val4 = ksub_reduce(acc4n[j], kq, xor32_addr);                               // row j * 16 + (lane & 15), cout 16 NT16 + 4 p + kq
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) rw[(j * 16 + kq * 4 + r4) * C::COUT + ks_pr * 16 + lr] = accn[j][r4];
+                rw[(j * 16 + (lane & 15)) * C::COUT + C::NT16 * 16 + ks_pr * 4 + kq] = val4;
             }
-            const int m = tj * 16 + (lane & 15);
-            if (m < C::MTOT) { const int g = m / C::PIXB, r = m - g * C::PIXB; s_o[(g * C::COUT + C::NT16 * 16 + pr * 4 + kq) * C::OSTR + r] = val4; }
         }
         if constexpr (C::STAMP) { if (tid == 0) stp[6] = __builtin_amdgcn_s_memtime(); }
+        __syncthreads();
+        // sum of the K parts in part order -> the restaged outputs [g][cout][OSTR]
+        {
+            float* s_o = smem;
+            constexpr int TOT = C::G * C::COUT * C::PIXB;
+#pragma unroll 2
+            for (int e = tid; e < TOT; e += C::NTH) {
+                const int co = e % C::COUT, m = e / C::COUT;                   // consecutive lanes: consecutive channels of one row
+                const int g = m / C::PIXB, r = m - g * C::PIXB;
+                float v = s_red[m * C::COUT + co];
+#pragma unroll
+                for (int q = 1; q < C::KS; ++q) v += s_red[(q * MROWS + m) * C::COUT + co];
+                s_o[(g * C::COUT + co) * C::OSTR + r] = v;
+            }
+        }
         __syncthreads();
         if constexpr (C::STAMP) { if (tid == 0) stp[7] = __builtin_amdgcn_s_memtime(); }
     } else {
@@ -1226,18 +1284,31 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             }
         }
         if constexpr (C::FIN) {
-            static_assert(C::LDS_BYTES >= 256 * 3 * 8 + 16, "finalize scratch");
             __syncthreads();                                               // s_o has been read: the LDS is free
-            double* s_acc = reinterpret_cast<double*>(smem);
-            if (arrive_last(a.fin.counter + tower * fin_counter_words(gridDim.x), gridDim.x, blockIdx.x, reinterpret_cast<volatile int*>(smem + 256 * 6))) {
+            double* s_acc = reinterpret_cast<double*>(smem);               // [NTH][3]
+            volatile int* s_flag = reinterpret_cast<volatile int*>(smem + C::NTH * 6);
+            const unsigned int nwg = gridDim.x, grp = blockIdx.x / kFinGroup, groups = (nwg + kFinGroup - 1) / kFinGroup;
+            unsigned int* cnt = a.fin.counter + tower * fin_counter_words(nwg);
+            if (take_ticket(cnt + (size_t)kFinLine * (1 + grp), min((unsigned int)kFinGroup, nwg - grp * kFinGroup), s_flag)) {
+                // this workgroup completed its group: the group's units (G per workgroup) -> one record per channel
                 const float2* part = reinterpret_cast<const float2*>(sp);
-                const int units = a.n * C::NB;
-                if constexpr (C::EPI == EPI_RAW_STATS)
-                    bn_fin_forward<C::COUT>(part, units, a.fin.count, pick3(a.fin.bn, tower), reinterpret_cast<float2*>(pick3(a.fin.ss, tower)),
-                                            reinterpret_cast<float4*>(pick3(a.fin.coef, tower)), s_acc);
-                else
-                    bn_fin_backward<C::COUT>(part, units, a.fin.count, reinterpret_cast<const float4*>(pick3(a.bnlow, tower)),
-                                             pick3(a.fin.bn, tower), reinterpret_cast<float4*>(pick3(a.fin.coef, tower)), s_acc);
+                const int units = a.n * C::NB, upw = C::G * C::NB;         // units per workgroup
+                const int u0 = (int)grp * kFinGroup * upw;
+                double* grec = a.fin.grp + ((size_t)tower * groups + grp) * kFinRec * 2;
+                const double per_unit = a.fin.count / units;
+                // (a group of kFinGroup workgroups holds kFinGroup * upw units: reduced in slices of kFinGroup units when upw > 1)
+                static_assert(C::G * C::NB == 1, "in-kernel finalize: one unit per workgroup");
+                if constexpr (C::EPI == EPI_RAW_STATS) bn_grp_forward<C::COUT>(part, u0, min(kFinGroup, units - u0), per_unit, grec);
+                else bn_grp_backward<C::COUT>(part, u0, min(kFinGroup, units - u0), grec);
+                if (take_ticket(cnt, groups, s_flag)) {
+                    const double* rec = a.fin.grp + (size_t)tower * groups * kFinRec * 2;
+                    if constexpr (C::EPI == EPI_RAW_STATS)
+                        bn_top_forward<C::COUT, C::NTH>(rec, (int)groups, units, per_unit, pick3(a.fin.bn, tower), reinterpret_cast<float2*>(pick3(a.fin.ss, tower)),
+                                                        reinterpret_cast<float4*>(pick3(a.fin.coef, tower)), s_acc);
+                    else
+                        bn_top_backward<C::COUT, C::NTH>(rec, (int)groups, a.fin.count, reinterpret_cast<const float4*>(pick3(a.bnlow, tower)),
+                                                         pick3(a.fin.bn, tower), reinterpret_cast<float4*>(pick3(a.fin.coef, tower)), s_acc);
+                }
             }
         }
     }

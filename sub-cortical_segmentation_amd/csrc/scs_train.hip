@@ -83,6 +83,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* l1m[kTowers]{};                     // [20][2]: mean, inv_std of conv1's batch statistics
     double* mom = nullptr;                     // [3][100] R (9x9), S (column 9), count
     bool tickets_dirty = false;                // a step failed between launches: the tickets are zeroed before the next one
+    double* fin_grp = nullptr;                 // group records of the in-kernel finalize steps (inside `base`)
     unsigned int* fin_counter = nullptr;       // arrival tickets of the in-kernel finalize steps (inside `base`; zero between launches)
     float* wg_part = nullptr;                  // [4 layers][3][kWgPartFloats] partial weight gradients
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
@@ -194,7 +195,8 @@ static int train_ensure(scs_ctx* h, int n) {
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
                  o_sp = take((size_t)kTowers * c * 8 * 64 * 2),     // up to 8 bands x 64 channels x 2 sums
                  o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * std::max<size_t>(256, (c + kMomentPpb - 1) / kMomentPpb) * 128),
-                 o_fc = take(kTowers * fin_counter_words(c));                 // one workgroup per patch in the FIN configurations
+                 o_fc = take(kTowers * fin_counter_words(c)),                 // one workgroup per patch in the FIN configurations
+                 o_fg = take(kTowers * fin_groups(c) * kFinRec * 2 * 2);      // group records (doubles)
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
     for (int t = 0; t < kTowers; ++t) {
@@ -209,6 +211,7 @@ static int train_ensure(scs_ctx* h, int n) {
     w->dcat = w->base + o_dcat; w->dfeat = w->base + o_dfeat; w->loss_rows = w->base + o_lr; w->loss_dev = w->base + o_ld;
     w->stat_part = w->base + o_sp; w->l1_part = w->base + o_l1; w->mom_part = w->base + o_mp;
     w->fin_counter = reinterpret_cast<unsigned int*>(w->base + o_fc);
+    w->fin_grp = reinterpret_cast<double*>(w->base + o_fg);
     SCS_HIP(hipMalloc(&w->masks, c * kFlat * 5 + c));
     w->yb = w->masks + c * kFlat * 5;
     w->cap = (int)c;
@@ -358,7 +361,9 @@ __device__ __forceinline__ void moments_body(const X0Src& x0, float* __restrict_
 }
 
 // First launch of a step: rows [0, kPrepJobs) of the grid are the prep jobs, rows kPrepJobs + t the input moments of tower t
-// (nothing in either half depends on the other; one launch instead of two on the step's critical path).
+// (nothing in either half depends on the other; one launch instead of two on the step's critical path.  The prep jobs on the
+// side stream beside the moments was tried: the fork / join events cost more than the 8 us the jobs take - 0.628 against 0.616
+// ms per step, profiles/r03_notes.txt).
 __global__ __launch_bounds__(256) void prep_moments_kernel(PrepArgs a, X0Src x0, float* __restrict__ mom_part, int n, int ppb, int units) {
     const int job = blockIdx.y;
     if (job < kPrepJobs) { if ((int)blockIdx.x < kPrepBlocks) prep_body(a, job); }
@@ -790,6 +795,8 @@ static int set_train_attrs(TrainWs* w, int device) {
     if (w->attr_device == device) return SCS_OK;
     SCS_HIP(conv_set_attr<TF12>()); SCS_HIP(conv_set_attr<TF3>()); SCS_HIP(conv_set_attr<TF4>()); SCS_HIP(conv_set_attr<TF5>());
     SCS_HIP(conv_set_attr<DG5>()); SCS_HIP(conv_set_attr<DG4>()); SCS_HIP(conv_set_attr<DG3>()); SCS_HIP(conv_set_attr<DG2>());
+    SCS_HIP(conv_set_attr<TF3N>()); SCS_HIP(conv_set_attr<TF4N>()); SCS_HIP(conv_set_attr<DG5N>()); SCS_HIP(conv_set_attr<DG4N>());
+    SCS_HIP(conv_set_attr<DG3N>());
     SCS_HIP(wgrad_set_attr<WG2>()); SCS_HIP(wgrad_set_attr<WG3>()); SCS_HIP(wgrad_set_attr<WG4>()); SCS_HIP(wgrad_set_attr<WG5>());
     w->attr_device = device;
     return SCS_OK;
@@ -810,6 +817,10 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     constexpr HeadOff H = head_off();
     constexpr TowerOff T0 = tower_off(0);
     static const bool one_stream = getenv("SCS_TRAIN_ONE_STREAM") != nullptr;      // tuning runs: no side stream
+    // batch-norm finalize inside the producing conv kernel up to kFinMaxBatch, as a launch of its own beyond (train_cfg.h);
+    // SCS_FIN_MAX_BATCH overrides the bound (tests run both forms at one batch size)
+    const char* fin_env = getenv("SCS_FIN_MAX_BATCH");
+    const bool fin_in_kernel = n <= (fin_env ? atoi(fin_env) : kFinMaxBatch);
     hipStream_t sd = one_stream ? st : w->side;
 
     w->prof = stage_ms != nullptr;
@@ -881,15 +892,15 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         a.x0 = x0;
         const int C = kCout[i], Hh = kHout[i];
         const double count = (double)n * Hh * Hh;
-        a.fin.counter = w->fin_counter; a.fin.count = count;
+        a.fin.counter = w->fin_counter; a.fin.grp = w->fin_grp; a.fin.count = count;
         for (int t = 0; t < kTowers; ++t) {
             a.fin.bn[t] = P + T0.bn[i] + t * kTowerFloats;
             a.fin.ss[t] = reinterpret_cast<float*>(w->ss[t][i]); a.fin.coef[t] = reinterpret_cast<float*>(w->low4[t][i]);
         }
-        constexpr bool kFwdFin[kConvs] = {false, TF12::FIN != 0, TF3::FIN != 0, TF4::FIN != 0, TF5::FIN != 0};
+        const bool kFwdFin[kConvs] = {false, TF12::FIN != 0, TF3::FIN != 0 && fin_in_kernel, TF4::FIN != 0 && fin_in_kernel, TF5::FIN != 0};
         if (i == 1) run(ST_CONV12, st, [&] { conv_launch<TF12>(a, st); });
-        else if (i == 2) run(ST_CONV3, st, [&] { conv_launch<TF3>(a, st); });
-        else if (i == 3) run(ST_CONV4, st, [&] { conv_launch<TF4>(a, st); });
+        else if (i == 2) run(ST_CONV3, st, [&] { if (fin_in_kernel) conv_launch<TF3>(a, st); else conv_launch<TF3N>(a, st); });
+        else if (i == 3) run(ST_CONV4, st, [&] { if (fin_in_kernel) conv_launch<TF4>(a, st); else conv_launch<TF4N>(a, st); });
         else run(ST_CONV5, st, [&] { conv_launch<TF5>(a, st); });
         const int units = n * kStatBands[i];
         if (kFwdFin[i]) {
@@ -966,7 +977,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     WgFinalArgs fa{};
     fa.grads = G; fa.tower_stride = kTowerFloats;
     constexpr int kDgBands[kConvs] = {0, DG2::NB, DG3::NB, DG4::NB, DG5::NB};
-    constexpr bool kDgFin[kConvs + 1] = {false, DG2::FIN != 0, DG3::FIN != 0, DG4::FIN != 0, DG5::FIN != 0, false};
+    const bool kDgFin[kConvs + 1] = {false, DG2::FIN != 0, DG3::FIN != 0 && fin_in_kernel, DG4::FIN != 0 && fin_in_kernel,
+                                     DG5::FIN != 0 && fin_in_kernel, false};
     for (int i = kConvs - 1; i >= 1; --i) {
         const int C = kCout[i], Hh = kHout[i];
         const double count = (double)n * Hh * Hh;
@@ -995,15 +1007,15 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         a.stats = (i >= 2) ? w->stat_part : w->l1_part;
         a.x0 = x0;
         if (i >= 2) {                                                   // finalize of the layer below, done by the kernel's last workgroup
-            a.fin.counter = w->fin_counter; a.fin.count = (double)n * kHout[i - 1] * kHout[i - 1];
+            a.fin.counter = w->fin_counter; a.fin.grp = w->fin_grp; a.fin.count = (double)n * kHout[i - 1] * kHout[i - 1];
             for (int t = 0; t < kTowers; ++t) {
                 a.fin.bn[t] = G + T0.bn[i - 1] + t * kTowerFloats;
                 a.fin.coef[t] = reinterpret_cast<float*>(w->cf4[t][i - 1]);
             }
         }
-        if (i == 4) run(ST_DG5, st, [&] { conv_launch<DG5>(a, st); });
-        else if (i == 3) run(ST_DG4, st, [&] { conv_launch<DG4>(a, st); });
-        else if (i == 2) run(ST_DG3, st, [&] { conv_launch<DG3>(a, st); });
+        if (i == 4) run(ST_DG5, st, [&] { if (fin_in_kernel) conv_launch<DG5>(a, st); else conv_launch<DG5N>(a, st); });
+        else if (i == 3) run(ST_DG4, st, [&] { if (fin_in_kernel) conv_launch<DG4>(a, st); else conv_launch<DG4N>(a, st); });
+        else if (i == 2) run(ST_DG3, st, [&] { if (fin_in_kernel) conv_launch<DG3>(a, st); else conv_launch<DG3N>(a, st); });
         else run(ST_DG2, st, [&] { conv_launch<DG2>(a, st); });
         // weight gradient of this layer on the side stream (it reads the d z the kernel above stored)
         fork();
@@ -1134,18 +1146,45 @@ int scs_get_train_buffer(scs_handle h, int which, float* host_out, size_t count)
     if (!h->tws || !h->tws->base) { set_error("no training step has run"); return SCS_ERR_STATE; }
     TrainWs* w = h->tws;
     const float* src = nullptr;
-    size_t ld = 0;
-    switch (which) {
-        case 0: src = w->dR2; ld = kFC2ld; break;     // [n][272]
-        case 1: src = w->dcat; ld = kFC1; break;      // [n][540]
-        case 2: src = w->dfeat; ld = kFlat; break;    // [n][540]
-        case 3: src = w->featd; ld = kFlat; break;    // [n][540]
-        case 4: src = w->R1; ld = kFC1; break;        // [n][540]
-        case 5: src = w->cat2; ld = kFC1ld; break;    // [n][556]
-        case 6: src = w->dlog; ld = 16; break;        // [n][16]
-        default: SCS_ARG(false, "unknown buffer id");
+    size_t ld = 0, rows = (size_t)w->cap;
+    if (which >= 100 && which < 300) {
+        // 100 + 10 t + i: raw output of conv block i (2..5) of tower t, [n][Cout_i][Ho][Ho];
+        // 200 + 10 t + i: that block's batch-norm (scale, shift) pairs as applied in the step, float2 [Cout_i] (i = 1..5; block 1:
+        //                 the folded conv1 table)
+        const int t = (which % 100) / 10, i = which % 10;
+        SCS_ARG(t >= 0 && t < kTowers, "unknown tower");
+        if (which < 200) {
+            SCS_ARG(i >= 2 && i <= kConvs, "raw outputs exist for conv blocks 2..5");
+            src = w->Z[t][i - 1]; ld = (size_t)kCout[i - 1] * kHout[i - 1] * kHout[i - 1];
+        } else {
+            SCS_ARG(i >= 1 && i <= kConvs, "unknown conv block");
+            SCS_ARG(count == 2 * (size_t)kCout[i - 1], "count must be 2 * Cout");
+            SCS_HIP(hipSetDevice(h->device));
+            SCS_HIP(hipDeviceSynchronize());
+            if (i == 1) {                                    // l1p: [20][12] rows of (9 taps, sc, sh, pad)
+                float tab[240];
+                SCS_HIP(hipMemcpy(tab, w->l1p[t], sizeof(tab), hipMemcpyDeviceToHost));
+                for (int c = 0; c < 20; ++c) { host_out[2 * c] = tab[c * 12 + 9]; host_out[2 * c + 1] = tab[c * 12 + 10]; }
+            } else {
+                SCS_HIP(hipMemcpy(host_out, w->ss[t][i - 1], count * sizeof(float), hipMemcpyDeviceToHost));
+            }
+            return SCS_OK;
+        }
+    } else {
+        switch (which) {
+            case 0: src = w->dR2; ld = kFC2ld; break;     // [n][272]
+            case 1: src = w->dcat; ld = kFC1; break;      // [n][540]
+            case 2: src = w->dfeat; ld = kFlat; break;    // [n][540]
+            case 3: src = w->featd; ld = kFlat; break;    // [n][540]
+            case 4: src = w->R1; ld = kFC1; break;        // [n][540]
+            case 5: src = w->cat2; ld = kFC1ld; break;    // [n][556]
+            case 6: src = w->dlog; ld = 16; break;        // [n][16]
+            case 7: src = w->R2; ld = kFC2ld; break;      // [n][272]
+            case 8: src = w->feat; ld = kFlat; break;     // [n][540]
+            default: SCS_ARG(false, "unknown buffer id");
+        }
     }
-    SCS_ARG(count <= (size_t)w->cap * ld, "count exceeds the buffer");
+    SCS_ARG(count <= rows * ld, "count exceeds the buffer");
     SCS_HIP(hipSetDevice(h->device));
     SCS_HIP(hipDeviceSynchronize());
     SCS_HIP(hipMemcpy(host_out, src, count * sizeof(float), hipMemcpyDeviceToHost));

@@ -11,14 +11,25 @@ namespace scs {
 using TF12 = ConvCfg<20, 20, 30, 1, EPI_RAW_STATS, SRC_X0, 180, 7, 4>;          // conv1 (recomputed) + conv2
 using TF3 = ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 208, 1, 4, 0, 4, 1>;   // BN2 + ReLU + pool1 while staging; finalizes BN3
 using TF4 = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4, 0, 4, 1>;        // BN3 + ReLU while staging; finalizes BN4
-using TF5 = ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 0, 4, 0, 1>;   // BN4 + ReLU + pool2 while staging; one M tile:
-                                                                                 // the waves split the output channels (NSPLIT)
+using TF5 = ConvCfg<40, 60, 5, 4, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 0, 6, 0, 2>;   // BN4 + ReLU + pool2 while staging; 4 patches (3 M
+                                                                                 // tiles) per workgroup, 6 waves = 3 channel pairs x 2 K parts (K split)
 // data gradients: input = dZ_i (computed while staging) zero-padded by 2, Cin' = Cout_i, Cout' = Cin_i; the epilogue
 // leaves the BN-backward partial sums of the block below and (last template argument) finalizes them in its last workgroup
-using DG5 = ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1, 1>;  // below: conv4 block (pooled)
+using DG5 = ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1>;     // below: conv4 block (pooled)
 using DG4 = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3, 0, 4, 1>;   // below: conv3 block
 using DG3 = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3, 0, 4, 1>;   // below: conv2 block (pooled)
 using DG2 = ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 256, 5, 4>;        // below: conv1 block (recomputed)
+
+// The same tilings without the in-kernel finalize.  The finalize costs every workgroup a drained write-through store and a
+// returning ticket (~1.5 us during which it holds its CU slot): with ONE generation of workgroups (batch 256: 768 patch-towers on
+// 256 CUs x 3) that is a 5 us tail against the ~9 us of a separate finalize launch, but it grows with the generations (+20 us per
+// kernel at batch 2048, profiles/r03_tbench_fin.txt), so beyond kFinMaxBatch the step uses these and launches the finalize.
+using TF3N = ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 208, 1, 4, 0, 4, 0>;
+using TF4N = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4, 0, 4, 0>;
+using DG5N = ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 0>;
+using DG4N = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3, 0, 4, 0>;
+using DG3N = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3, 0, 4, 0>;
+constexpr int kFinMaxBatch = 512;
 
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 // <CIN, COUT, HIN, row bands, workgroups per CU, X source, d z source, patches per staging round>.  d z is read from memory

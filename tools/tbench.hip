@@ -12,6 +12,87 @@
 #include "train_cfg.h"
 
 namespace scs { void set_error(const char*, ...) {} }
+namespace scs {
+// ---- experiment kept out of the product headers (profiles/r03_tbench_c5.txt): not faster than the per-patch kernel
+// Weight gradient of a conv layer with SMALL planes (conv5: 5x5 -> 3x3) as a split-K GEMM with an on-the-fly im2col operand:
+//   D[j = (c, tap)][o] = sum_{k = (n, pixel)}  X[n][c][pixel + tap] * dz[n][o][pixel]
+// The address of X[k; j] separates into a k part and a j part (n * CIN * HIN^2 + py * HIN + px  +  c * HIN^2 + dy * HIN + dx), so
+// every lane fetches its own MFMA operands straight from global memory (the latency form of gemm_mfma.h: dense_wgrad_kernel):
+// no LDS staging, no per-patch loop - per patch the planes hold 9 output pixels, and staging them patch by patch left the
+// matrix cores idle behind one global round trip per patch.  Workgroup = one 16-row tile of (c, tap) x all output channels
+// (four 16-column tiles, columns >= COUT are zero) x one K slice; the four waves split the slice's k-steps, their partial
+// tiles are added through LDS in wave order; the slices' partials go to wgrad_final_kernel like those of the other layers.
+template <int CIN_, int COUT_, int HIN_>
+struct WgSmallCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2, PIX = HO * HO, J = CIN_ * 9, MT = (J + 15) / 16;
+    static constexpr int NT = (COUT_ + 15) / 16, NB = 1;
+    static constexpr int CH = 20;                       // k-steps in flight per wave and round
+    static_assert(NT <= 4, "one workgroup covers all output channels");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void wgrad_small_kernel(WgArgs a) {
+    __shared__ f32x4 s_r[4 * C::NT * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int mt = blockIdx.x, slice = blockIdx.y, tower = blockIdx.z;
+    const int ktot = a.n * C::PIX;                                   // reduction length: (patch, output pixel) pairs
+    const int steps = (ktot + 3) / 4, per_slice = (steps + a.slices - 1) / a.slices;
+    const int sl_beg = min(steps, slice * per_slice), sl_end = min(steps, sl_beg + per_slice);
+    const int per = (sl_end - sl_beg + 3) / 4;
+    const int s_beg = min(sl_end, sl_beg + wave * per), s_end = min(sl_end, s_beg + per);
+    const int j = min(mt * 16 + lr, C::J - 1), c = j / 9, tap = j - c * 9;
+    const float* __restrict__ xcol = pick3(a.X, tower) + c * C::HIN * C::HIN + (tap / 3) * C::HIN + tap % 3;
+    const float* __restrict__ zcol = pick3(a.dZ, tower) + lr * C::PIX;
+    bool col_ok[C::NT];
+#pragma unroll
+    for (int q = 0; q < C::NT; ++q) col_ok[q] = q * 16 + lr < C::COUT;
+    f32x4 acc[C::NT];
+#pragma unroll
+    for (int q = 0; q < C::NT; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = s_beg; s0 < s_end; s0 += C::CH) {
+        float av[C::CH], bv[C::CH][C::NT];
+#pragma unroll
+        for (int i = 0; i < C::CH; ++i) {
+            const int k = 4 * (s0 + i) + kq;
+            const bool on = (s0 + i) < s_end && k < ktot;
+            const int kk = on ? k : 0, nn = kk / C::PIX, p = kk - nn * C::PIX, py = p / C::HO, px = p - py * C::HO;
+            av[i] = on ? xcol[(size_t)nn * C::CIN * C::HIN * C::HIN + py * C::HIN + px] : 0.f;
+#pragma unroll
+            for (int q = 0; q < C::NT; ++q) bv[i][q] = (on && col_ok[q]) ? zcol[(size_t)nn * C::COUT * C::PIX + q * 16 * C::PIX + p] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < C::CH; ++i)
+#pragma unroll
+            for (int q = 0; q < C::NT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][q], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < C::NT; ++q) s_r[(wave * C::NT + q) * 64 + lane] = acc[q];
+    __syncthreads();
+    if (wave < C::NT) {
+        const int q = wave;
+        f32x4 v = s_r[q * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const f32x4 u = s_r[(w * C::NT + q) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        const int o = q * 16 + lr;
+        float* __restrict__ out = a.part + ((size_t)tower * a.slices + slice) * C::COUT * C::J;      // [tower][slice][j][o]
+        if (o < C::COUT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = mt * 16 + kq * 4 + r;
+                if (jj < C::J) out[jj * C::COUT + o] = v[r];
+            }
+        }
+    }
+}
+
+template <class C>
+inline void wgrad_small_launch(const WgArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_small_kernel<C>, dim3(C::MT, a.slices, kTowers), dim3(256), 0, st, a);
+}
+
+}  // namespace scs
 using namespace scs;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -24,7 +105,7 @@ static float* dev_random(size_t n, unsigned seed, float lo = -1.f, float hi = 1.
     return d;
 }
 
-struct Pool { float* in[3]; float* in2[3]; float* in3[3]; float* out[3]; float* out2[3]; float* coef[3]; float* fin[3]; unsigned int* counter; float* stats; float* part; size_t per; };
+struct Pool { double* grp; float* in[3]; float* in2[3]; float* in3[3]; float* out[3]; float* out2[3]; float* coef[3]; float* fin[3]; unsigned int* counter; float* stats; float* part; size_t per; };
 static Pool g_pool;
 static void make_pool(int n) {
     g_pool.per = (size_t)n * 20 * 1024;
@@ -34,6 +115,7 @@ static void make_pool(int n) {
         g_pool.coef[t] = dev_random(4096, 31 + t, 0.2f, 1.2f);
         g_pool.fin[t] = dev_random(4096, 41 + t, 0.2f, 1.2f);      // finalize outputs of the FIN configurations
     }
+    CK(hipMalloc(&g_pool.grp, 3 * fin_groups(n) * kFinRec * 2 * 8));
     CK(hipMalloc(&g_pool.counter, 3 * fin_counter_words(n) * 4)); CK(hipMemset(g_pool.counter, 0, 3 * fin_counter_words(n) * 4));
     CK(hipMalloc(&g_pool.stats, (size_t)3 * n * 32 * 256 * 4));      // up to 32 bands x 256 floats per patch and tower
     CK(hipMalloc(&g_pool.part, (size_t)3 * 1024 * 60 * 40 * 9 * 4));     // up to 1024 partials of the largest layer per tower
@@ -68,7 +150,7 @@ static ConvArgs conv_args(int n) {
         a.x0.views[t] = g_pool.in2[t];
         a.fin.bn[t] = g_pool.fin[t]; a.fin.ss[t] = g_pool.fin[t] + 1024; a.fin.coef[t] = g_pool.fin[t] + 2048;
     }
-    a.fin.counter = g_pool.counter; a.fin.count = (double)n * C::PIX;
+    a.fin.counter = g_pool.counter; a.fin.grp = g_pool.grp; a.fin.count = (double)n * C::PIX;
     a.stats = g_pool.stats;
     return a;
 }
@@ -101,6 +183,14 @@ static void stamps(const char* name, int n) {
         epi_bar += (double)(h[w * 8 + 7] - h[w * 8 + 6]);
         tmin = std::min(tmin, h[w * 8]); tmax = std::max(tmax, h[w * 8 + 4]);
     }
+    // device-side span per XCD (s_memtime is an XCD-local clock; workgroups b and b + 8 share an XCD): first start -> last end
+    double span = 0, wg_max = 0;
+    for (int x = 0; x < 8; ++x) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (size_t w = x; w < nwg; w += 8) { lo = std::min(lo, h[w * 8]); hi = std::max(hi, h[w * 8 + 4]); wg_max = std::max(wg_max, (double)(h[w * 8 + 4] - h[w * 8])); }
+        if (hi > lo) span = std::max(span, (double)(hi - lo));
+    }
+    printf("%-28s device span (max over XCDs) %.0f cycles, slowest workgroup %.0f cycles\n", name, span, wg_max);
     printf("%-28s per-WG ticks (100 MHz): stage %.0f | w0+barrier %.0f | main loop %.0f | epilogue %.0f (acc->LDS %.0f, barrier %.0f, rest %.0f) | total %.0f ; kernel span %.0f ; WGs %zu\n",
            name, d[0] / nwg, d[1] / nwg, d[2] / nwg, d[3] / nwg, epi_lds / nwg, epi_bar / nwg, (d[3] - epi_lds - epi_bar) / nwg,
            (d[0] + d[1] + d[2] + d[3]) / nwg, (double)(tmax - tmin), nwg);
@@ -119,6 +209,15 @@ static void run_wg(const char* name, int n, int slices, int rounds, double macs_
     if ((size_t)slices * C::NB > 1024) { printf("%s: too many partials for the tbench pool\n", name); return; }
     char buf[128]; snprintf(buf, sizeof buf, "%s slices %d [LDS %zu]", name, slices, (size_t)C::LDS_BYTES);
     time_it(buf, rounds, 2.0 * macs_per_patch_tower * 3.0 * n, [&] { wgrad_launch<C>(a, nullptr); });
+}
+
+template <class C>
+static void run_wg_small(const char* name, int n, int slices, int rounds, double macs_per_patch_tower) {
+    WgArgs a{};
+    for (int t = 0; t < kTowers; ++t) { a.X[t] = g_pool.in[t]; a.dZ[t] = g_pool.in2[t]; }
+    a.part = g_pool.part; a.n = n; a.slices = slices;
+    char buf[128]; snprintf(buf, sizeof buf, "%s K slices %d", name, slices);
+    time_it(buf, rounds, 2.0 * macs_per_patch_tower * 3.0 * n, [&] { wgrad_small_launch<C>(a, nullptr); });
 }
 
 // a latency-bound stand-in for the tiny finalize launches between the conv kernels: `blocks` workgroups, each a chain of
@@ -213,6 +312,36 @@ int main(int argc, char** argv) {
         run_conv<DG4>("DG4 + d z stored", n, rounds, c4, true);
         run_conv<DG5>("DG5 + d z stored", n, rounds, c5, true);
     }
+    if (!strcmp(what, "c5")) {
+        // the conv5 block as K-split GEMM-style kernels: patches per workgroup x K parts (WPS 1: up to 256 registers, one
+        // workgroup of 6+ waves per CU; WPS 2: 168 registers, two per CU)
+        run_conv<TF5>("TF5 (shipped)", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 2, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 0, 6, 0, 2>>("TF5 G2 KS2 WPS1", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 3, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 0, 6, 0, 2>>("TF5 G3 KS2 WPS1", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 4, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 0, 6, 0, 2>>("TF5 G4 KS2 WPS1", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 4, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 2, 0, 6, 0, 2>>("TF5 G4 KS2 WPS2", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 7, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 0, 6, 0, 2>>("TF5 G7 KS2 WPS1", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 4, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 0, 15, 0, 5>>("TF5 G4 KS5 WPS1", n, rounds, c5);
+        run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4>>("TF5 one patch, tiles over waves (round 2 form)", n, rounds, c5);
+        run_conv<DG5>("DG5 (shipped)", n, rounds, c5, true);
+        run_conv<ConvCfg<60, 40, 7, 3, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 1, 0, 6, 0, 3>>("DG5 G3 KS3 WPS1 no FIN", n, rounds, c5, true);
+        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1>>("DG5 one patch, tiles over waves (FIN)", n, rounds, c5, true);
+        for (int sl : {4, 8, 16, 32}) run_wg_small<WgSmallCfg<40, 60, 5>>("WG5 split-K GEMM", n, sl, rounds, c5);
+        run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 1>>("WG5 per-patch staging (round 2 form)", n, 64, rounds, c5);
+        return 0;
+    }
+    if (!strcmp(what, "c5stamps")) {
+        stamps<ConvCfg<40, 60, 5, 4, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 1, 6, 0, 2>>("TF5 G4 KS2", n);
+        stamps<ConvCfg<40, 60, 5, 3, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 1, 6, 0, 2>>("TF5 G3 KS2", n);
+        stamps<ConvCfg<40, 60, 5, 4, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 1, 1, 15, 0, 5>>("TF5 G4 KS5", n);
+        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1>>("TF5 one patch, tiles over waves", n);
+        stamps<ConvCfg<60, 40, 7, 3, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 1, 1, 6, 0, 3>>("DG5 G3 KS3", n);
+        stamps<ConvCfg<60, 40, 7, 4, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 1, 1, 6, 0, 3>>("DG5 G4 KS3", n);
+        stamps<ConvCfg<60, 40, 7, 2, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 1, 1, 6, 0, 3>>("DG5 G2 KS3", n);
+        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1>>("DG5 one patch, tiles over waves", n);
+        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW, SRC_NCHW_PAD2, 49, 1, 4, 1>>("DG5 one patch, plain staging + epilogue", n);
+        return 0;
+    }
     if (!strcmp(what, "fin")) {
         // what the in-kernel finalize (last workgroup of a tower) adds to the statistics kernels
         run_conv<TF3>("TF3 (shipped, FIN)", n, rounds, c3);
@@ -246,11 +375,7 @@ int main(int argc, char** argv) {
         // conv5 block (one / two M tiles per patch): tiles dealt to waves + weight chunks through LDS, against the waves
         // splitting the output channels with operands straight from L2 (NSPLIT)
         run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4>>("TF5 tiles over waves", n, rounds, c5);
-        run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 0, 4, 0, 1>>("TF5 NSPLIT", n, rounds, c5);
-        run_conv<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 6, 0, 4, 0, 1>>("TF5 NSPLIT WPS6", n, rounds, c5);
         run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1>>("DG5 tiles over waves (FIN)", n, rounds, c5, true);
-        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1, 1>>("DG5 NSPLIT (FIN)", n, rounds, c5, true);
-        run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 6, 0, 4, 1, 1>>("DG5 NSPLIT WPS6 (FIN)", n, rounds, c5, true);
         return 0;
     }
     if (!strcmp(what, "wgs")) {
@@ -323,8 +448,6 @@ int main(int argc, char** argv) {
         stamps<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4, 1>>("TF4", n);
         stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1>>("TF5 tiles over waves", n);
         stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1>>("DG5 tiles over waves", n);
-        stamps<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 1, 4, 0, 1>>("DG5 (NSPLIT, as shipped)", n);
-        stamps<ConvCfg<40, 60, 5, 1, EPI_RAW_STATS, SRC_BN_POOL, 27, 1, 4, 1, 4, 0, 1>>("TF5 (NSPLIT, as shipped)", n);
     }
     if (all || !strcmp(what, "wg")) {
         run_wg<WG2>("WG2 (shipped)", n, 64, rounds, c2);

@@ -108,6 +108,42 @@ int scs_forward_volume_rows(scs_handle h, const float* vol_dev, int dim_x, int d
 int scs_dilate_mask(scs_handle h, uint8_t* mask_dev, uint8_t* scratch_dev, int dim_x, int dim_y, int dim_z, int iterations,
                     void* stream);
 
+/* ---- whole-volume preparation on the device (test_scan, base.py:401-458): the raw T1 and the registered mask go up as they
+ * lie in their files and everything the classifier needs from them is derived there. ------------------------------------ */
+
+/* Element types of a raw volume. */
+#define SCS_U8 0
+#define SCS_I16 1
+#define SCS_U16 2
+#define SCS_I32 3
+#define SCS_F32 4
+#define SCS_F64 5
+
+/* out[x][y][z] (float32, C order) = (v - mean) / std, mean and population std over the NON-ZERO voxels of the raw volume,
+ * evaluated in double and rounded once - the inference normalisation `(image - image[nz].mean()) / image[nz].std()` of
+ * load_patch_batch (base.py:357-358) followed by the float32 cast of the patches (base.py:380-386).
+ *   raw_dev        the voxels as stored (dtype: SCS_U8 .. SCS_F64), in the file's Fortran order (x fastest; fortran_order = 1)
+ *                  or in C order (z fastest; 0)
+ *   scratch_dev    3 * 1024 + 3 doubles: per-workgroup partial sums in a fixed order (the result is deterministic), then
+ *                  (mean, std, non-zero count), which the caller may read back
+ * Replaces: the whole-volume NumPy passes of base.py:357-358 (about 0.15 CPU-seconds per 256x256x192 subject). */
+int scs_zscore_volume(scs_handle h, const void* raw_dev, int dtype, int dim_x, int dim_y, int dim_z, int fortran_order,
+                      float* out_dev, double* scratch_dev, void* stream);
+
+/* The ROI of test_scan: mask != 0, dilated `iterations` times with the 6-neighbour cross (scs_dilate_mask), and the number of
+ * its voxels.  mask_dev (X*Y*Z bytes, C order) receives the dilated 0/1 mask; scratch_dev: X*Y*Z bytes; run_offsets_dev:
+ * ceil(X*Y*Z / 1024) + 1 int32 - start of every run of 1024 consecutive voxels in the voxel list, and the total.
+ * Synchronises the stream to return *total_host.
+ * Replaces: binary_dilation + np.nonzero of base.py:369-370, 310-331. */
+int scs_roi_prepare(scs_handle h, const void* mask_raw_dev, int dtype, int dim_x, int dim_y, int dim_z, int fortran_order,
+                    int iterations, uint8_t* mask_dev, uint8_t* scratch_dev, int32_t* run_offsets_dev, int64_t* total_host,
+                    void* stream);
+
+/* The voxel list itself: centers_dev int32 [n_centers][3] = (x, y, z) of the set voxels of mask_dev in C order - the order of
+ * np.nonzero, in which get_mask_voxels (base.py:310-331) lists them - n_centers = the total scs_roi_prepare returned. */
+int scs_roi_centers(scs_handle h, const uint8_t* mask_dev, int dim_x, int dim_y, int dim_z, const int32_t* run_offsets_dev,
+                    int32_t* centers_dev, int64_t n_centers, void* stream);
+
 /* Measurement hook (bench.py): scs_forward with HIP events recorded on `stream` around each stage of every
  * chunk; synchronises.  stage_ms[8] receives the summed elapsed milliseconds of
  *   0 conv1+conv2+pool1, 1 conv3, 2 conv4+pool2, 3 conv5, 4 d1 x3, 5 FC1 (+atlas concat), 6 fc_2, 7 out+softmax

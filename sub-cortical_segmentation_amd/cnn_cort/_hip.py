@@ -36,6 +36,9 @@ SIGNATURES = {
     'scs_forward_profiled': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _c.POINTER(_c.c_int)]),
     'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
     'scs_dilate_mask': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp]),
+    'scs_zscore_volume': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _vp]),
+    'scs_roi_prepare': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _vp, _c.POINTER(_c.c_int64), _vp]),
+    'scs_roi_centers': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp]),
     'scs_train_step': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
     'scs_train_step_volume': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _c.c_int64, _c.c_uint64, _vp, _vp, _vp]),
     'scs_gather_labels': (_c.c_int, [_vp, _vp, _vp, _c.c_int32, _vp, _c.c_int64, _vp, _vp]),
@@ -66,6 +69,10 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ScsError('HIP extension missing: %s (build it with __graft_entry__.build() or '
                        '`make -C sub-cortical_segmentation_amd/csrc`)' % LIB_PATH)
+    try:
+        import torch  # noqa: F401  - FIRST: torch brings its own HIP runtime; libscs.so then binds to that one.  Loaded the other
+    except ImportError:            # way round, /opt/rocm's runtime comes in ahead of torch's and the process has two (the second
+        pass                       # one finds "no ROCm-capable device")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         if os.environ.get('SCS_LIB_PATH') and not hasattr(lib, name):
@@ -123,6 +130,58 @@ def _table(x, cols, what, dtype):
         raise ValueError('%s must be a 2-D [N, %d] array, got shape %r' % (what, cols, None if x is None else tuple(x.shape)))
     _need(x, int(x.shape[0]) * cols, what, dtype)
     return int(x.shape[0])
+
+
+# ---- libscs_io.so: host-side file helpers (include/scs_io.h).  No HIP dependency: safe to load before torch has brought its own
+# HIP runtime into the process (libscs.so must NOT be: it would pull /opt/rocm's ahead of torch's and leave the process with two).
+IO_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), 'libscs_io.so')
+IO_SIGNATURES = {
+    'scs_io_last_error': (_c.c_char_p, []),
+    'scs_gz_gather': (_c.c_int, [_c.c_char_p, _vp, _c.c_int64, _c.c_int, _vp, _c.POINTER(_c.c_int64)]),
+    'scs_gz_read': (_c.c_int, [_c.c_char_p, _c.c_int64, _c.c_int64, _vp]),
+}
+_io_lib = None
+
+
+def load_io_library():
+    global _io_lib
+    if _io_lib is None:
+        if not os.path.exists(IO_LIB_PATH):
+            raise ScsError('host IO library missing: %s (build it with __graft_entry__.build())' % IO_LIB_PATH)
+        lib = ctypes.CDLL(IO_LIB_PATH)
+        for name, (res, args) in IO_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _io_lib = lib
+    return _io_lib
+
+
+def _io_error(lib, what, rc):
+    msg = lib.scs_io_last_error()
+    return IOError(msg.decode() if msg else '%s failed (%d)' % (what, rc))
+
+
+def gz_gather(path, byte_offsets, elem_bytes, total=False):
+    """Elements of a gzip file at ascending byte offsets of its inflated content (scs_gz_gather: host code of the library, no
+    GPU needed) -> uint8 array [n, elem_bytes] (and the inflated length when `total`)."""
+    lib = load_io_library()
+    off = np.ascontiguousarray(byte_offsets, dtype=np.int64)
+    out = np.empty((off.size, int(elem_bytes)), np.uint8)
+    n_out = ctypes.c_int64(0)
+    rc = lib.scs_gz_gather(os.fsencode(path), off.ctypes.data, off.size, int(elem_bytes), out.ctypes.data, ctypes.byref(n_out) if total else None)
+    if rc != 0:
+        raise _io_error(lib, 'scs_gz_gather', rc)
+    return (out, int(n_out.value)) if total else out
+
+
+def gz_read(path, offset, out):
+    """Bytes [offset, offset + out.nbytes) of the inflated content of a gzip file into the uint8 array `out` (scs_gz_read)."""
+    lib = load_io_library()
+    rc = lib.scs_gz_read(os.fsencode(path), int(offset), int(out.nbytes), out.ctypes.data)
+    if rc != 0:
+        raise _io_error(lib, 'scs_gz_read', rc)
+    return out
 
 
 class Handle:
@@ -219,6 +278,46 @@ class Handle:
         _need(scratch_dev, nvox, 'dilation scratch', 'u8')
         _check(self.lib.scs_dilate_mask(self.h, _ptr(mask_dev), _ptr(scratch_dev), int(dims[0]), int(dims[1]), int(dims[2]),
                                         int(iterations), stream or None), 'scs_dilate_mask')
+
+    # raw volumes as they lie in a NIfTI file: element type -> SCS_U8 .. SCS_F64 (include/scs.h)
+    RAW_DTYPES = {'uint8': 0, 'int16': 1, 'uint16': 2, 'int32': 3, 'float32': 4, 'float64': 5}
+    STAT_DOUBLES = 3 * 1024 + 3
+
+    def _raw(self, raw_dev, dims, what):
+        code = self.RAW_DTYPES.get(_dtype_name(raw_dev))
+        if code is None:
+            raise ValueError('%s: element type %s is not one of %s' % (what, _dtype_name(raw_dev), ', '.join(self.RAW_DTYPES)))
+        nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
+        if min(int(d) for d in dims) < 1 or raw_dev.numel() < nvox or not raw_dev.is_contiguous():
+            raise ValueError('%s must be a contiguous buffer of %d voxels' % (what, nvox))
+        return code, nvox
+
+    def zscore_volume(self, raw_dev, dims, fortran_order, out_dev, scratch_dev, stream=0):
+        code, nvox = self._raw(raw_dev, dims, 'raw volume')
+        _need(out_dev, nvox, 'normalised volume')
+        if _dtype_name(scratch_dev) != 'float64' or scratch_dev.numel() < self.STAT_DOUBLES:
+            raise ValueError('z-score scratch must hold %d float64' % self.STAT_DOUBLES)
+        _check(self.lib.scs_zscore_volume(self.h, _ptr(raw_dev), code, int(dims[0]), int(dims[1]), int(dims[2]), 1 if fortran_order else 0,
+                                          _ptr(out_dev), _ptr(scratch_dev), stream or None), 'scs_zscore_volume')
+
+    def roi_prepare(self, mask_raw_dev, dims, fortran_order, iterations, mask_dev, scratch_dev, run_offsets_dev, stream=0):
+        code, nvox = self._raw(mask_raw_dev, dims, 'raw mask')
+        _need(mask_dev, nvox, 'mask', 'u8')
+        _need(scratch_dev, nvox, 'dilation scratch', 'u8')
+        _need(run_offsets_dev, (nvox + 1023) // 1024 + 1, 'run offsets', 'i32')
+        total = ctypes.c_int64(0)
+        _check(self.lib.scs_roi_prepare(self.h, _ptr(mask_raw_dev), code, int(dims[0]), int(dims[1]), int(dims[2]), 1 if fortran_order else 0,
+                                        int(iterations), _ptr(mask_dev), _ptr(scratch_dev), _ptr(run_offsets_dev), ctypes.byref(total),
+                                        stream or None), 'scs_roi_prepare')
+        return int(total.value)
+
+    def roi_centers(self, mask_dev, dims, run_offsets_dev, centers_dev, n, stream=0):
+        nvox = int(dims[0]) * int(dims[1]) * int(dims[2])
+        _need(mask_dev, nvox, 'mask', 'u8')
+        _need(run_offsets_dev, (nvox + 1023) // 1024 + 1, 'run offsets', 'i32')
+        _need(centers_dev, 3 * n, 'centre list', 'i32')
+        _check(self.lib.scs_roi_centers(self.h, _ptr(mask_dev), int(dims[0]), int(dims[1]), int(dims[2]), _ptr(run_offsets_dev),
+                                        _ptr(centers_dev), int(n), stream or None), 'scs_roi_centers')
 
     def get_activation(self, which, count):
         out = np.empty(count, np.float32)

@@ -312,58 +312,141 @@ class Net:
         """int64 [N] = argmax(predict_proba) - base.py:425-428 (nolearn, use_label_encoder=False)."""
         return self._forward(X, False)[1]
 
+    def _wait(self, stream=None):
+        """Sleep (not spin) until the work queued on `stream` (default: the current one) is done: the event is polled between
+        short sleeps.  The runtime's own synchronisation - a .cpu() copy, hipEventSynchronize even with the blocking flag -
+        busy-waits on this platform: a subject's 0.12 s GPU stage was 0.12 CPU-seconds of spinning."""
+        torch = self._torch()
+        ev = torch.cuda.Event()
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self._dev()))
+        delay = 1e-4
+        while not ev.query():
+            time.sleep(delay)
+            delay = min(1e-3, delay * 1.5)
+
     def predict_volume(self, volume, centers, atlas4d=None, want_probs=False, batch=100000, atlas_rows=None):
         """Gather-fused inference for test_scan: `volume` float32 [X,Y,Z] already z-scored, `centers` int [N,3], and
         the priors either as `atlas4d` float32 [X,Y,Z,15] (gathered on the device, background rule applied there)
         or as `atlas_rows` float32 [N,15] already gathered by the caller with the rule applied (base.atlas_vectors_at).
+        `volume` and `centers` may be tensors already on the device (normalize_volume / roi_centers): nothing is uploaded then.
         Returns (labels int64 [N], probs float32 [N,15] or None).
         Replaces load_patch_batch + net.predict/predict_proba (base.py:380-397, 425-438)."""
         torch = self._torch()
-        volume = np.ascontiguousarray(volume, dtype=np.float32)
-        centers = np.ascontiguousarray(np.asarray(centers).reshape(-1, 3), dtype=np.int32)
-        if volume.ndim != 3:
-            raise ValueError('volume must be 3-D, got shape %r' % (volume.shape,))
+        dev = 'cuda:%d' % self._dev()
+        vol_on_dev = torch.is_tensor(volume)
+        if vol_on_dev:
+            if volume.dtype != torch.float32 or not volume.is_cuda or not volume.is_contiguous():
+                raise ValueError('a device volume must be a contiguous float32 tensor')
+        else:
+            volume = np.ascontiguousarray(volume, dtype=np.float32)
+        shape = tuple(int(d) for d in volume.shape)
+        if len(shape) != 3:
+            raise ValueError('volume must be 3-D, got shape %r' % (shape,))
+        cen_on_dev = torch.is_tensor(centers)
+        if cen_on_dev:
+            if centers.dtype != torch.int32 or not centers.is_cuda or not centers.is_contiguous() or centers.dim() != 2 or centers.shape[1] != 3:
+                raise ValueError('device centres must be a contiguous int32 [N,3] tensor')
+        else:
+            centers = np.ascontiguousarray(np.asarray(centers).reshape(-1, 3), dtype=np.int32)
         if (atlas4d is None) == (atlas_rows is None):
             raise ValueError('give exactly one of atlas4d and atlas_rows')
-        n = centers.shape[0]
+        n = int(centers.shape[0])
         if atlas_rows is not None:
             atlas_rows = np.ascontiguousarray(atlas_rows, dtype=np.float32)
             if atlas_rows.shape != (n, 15):
                 raise ValueError('atlas_rows must be [%d, 15], got %r' % (n, atlas_rows.shape))
         else:
             atlas4d = np.ascontiguousarray(atlas4d, dtype=np.float32)
-            if tuple(atlas4d.shape) != tuple(volume.shape) + (15,):
-                raise ValueError('atlas4d shape %r does not match volume shape %r + (15,)' % (atlas4d.shape, volume.shape))
-        if n and ((centers < 0).any() or (centers >= np.asarray(volume.shape, np.int32)).any()):
-            raise ValueError('patch centres outside the volume')
+            if tuple(atlas4d.shape) != shape + (15,):
+                raise ValueError('atlas4d shape %r does not match volume shape %r + (15,)' % (atlas4d.shape, shape))
+        if n and not cen_on_dev and ((centers < 0).any() or (centers >= np.asarray(shape, np.int32)).any()):
+            raise ValueError('patch centres outside the volume')          # (device lists come from roi_centers: inside by construction)
         if n == 0:
             return np.zeros((0,), np.int64), (np.zeros((0, 15), np.float32) if want_probs else None)
         h = self._ensure_handle()
-        dev = 'cuda:%d' % self._dev()
         stream = torch.cuda.current_stream(self._dev()).cuda_stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        d_vol = torch.from_numpy(volume).to(dev)
-        d_atl = torch.from_numpy(atlas_rows if atlas_rows is not None else atlas4d).to(dev)
-        d_cen = torch.from_numpy(centers).to(dev)
+        d_vol = volume if vol_on_dev else torch.from_numpy(volume).to(dev)
+        d_atl = torch.from_numpy(atlas_rows if atlas_rows is not None else atlas4d).to(dev, non_blocking=True)
+        d_cen = centers if cen_on_dev else torch.from_numpy(centers).to(dev)
         d_lab = torch.empty((n,), dtype=torch.int32, device=dev)
         d_pr = torch.empty((n, 15), dtype=torch.float32, device=dev) if want_probs else None
         batch = max(1, int(batch))
         for lo in range(0, n, batch):
             hi = min(n, lo + batch)
             if atlas_rows is not None:
-                h.forward_volume_rows(d_vol, volume.shape, d_cen[lo:hi], d_atl[lo:hi], hi - lo,
+                h.forward_volume_rows(d_vol, shape, d_cen[lo:hi], d_atl[lo:hi], hi - lo,
                                       d_pr[lo:hi] if want_probs else None, d_lab[lo:hi], stream)
             else:
-                h.forward_volume(d_vol, volume.shape, d_cen[lo:hi], d_atl, hi - lo,
+                h.forward_volume(d_vol, shape, d_cen[lo:hi], d_atl, hi - lo,
                                  d_pr[lo:hi] if want_probs else None, d_lab[lo:hi], stream)
+        ev1.record()
+        self._wait()
         labels = d_lab.cpu().numpy().astype(np.int64)
         probs = d_pr.cpu().numpy() if want_probs else None
-        ev1.record()
-        ev1.synchronize()
         self.gpu_seconds += ev0.elapsed_time(ev1) * 1e-3
         self.last_scan_voxels = n
         return labels, probs
+
+    def side_stream(self):
+        """Context manager that makes a stream of the calling THREAD's own the current one (test_cohort's reader threads prepare
+        the next subjects on the device while the main thread's stream runs the classifier)."""
+        import threading
+        torch = self._torch()
+        if not hasattr(self, '_tls'):
+            self._tls = threading.local()
+        if getattr(self._tls, 'stream', None) is None:
+            self._tls.stream = torch.cuda.Stream(device=self._dev())
+        return torch.cuda.stream(self._tls.stream)
+
+    @staticmethod
+    def _file_order(a):
+        """(buffer in memory order, dims (X, Y, Z), is-Fortran) of a 3-D array without copying it when it is contiguous either
+        way (nifti.load returns Fortran-ordered arrays, like nibabel)."""
+        a = np.asarray(a)
+        if a.ndim != 3:
+            raise ValueError('volume must be 3-D, got shape %r' % (a.shape,))
+        if a.dtype == np.bool_:
+            a = a.view(np.uint8)
+        if a.dtype.byteorder == '>' or a.dtype.name not in ('uint8', 'int16', 'uint16', 'int32', 'float32', 'float64'):
+            a = a.astype(np.float64 if a.dtype.kind == 'f' else np.int32 if a.dtype.kind in 'iu' and a.dtype.itemsize <= 4 else np.float64)
+        if a.flags['F_CONTIGUOUS'] and not a.flags['C_CONTIGUOUS']:
+            return a.T, a.shape, True                       # a.T is the C-contiguous view of the same bytes
+        return np.ascontiguousarray(a), a.shape, False
+
+    def normalize_volume(self, raw):
+        """(image - mean) / std over the non-zero voxels (population std, in double, one rounding to float32) of a raw T1
+        volume, ON the device: float32 tensor [X,Y,Z] (C order) ready for predict_volume.  The raw voxels go up as they lie in
+        the file.  Replaces the whole-volume NumPy passes of base.py:357-358."""
+        torch = self._torch()
+        buf, dims, fortran = self._file_order(raw)
+        h = self._ensure_handle()
+        dev = 'cuda:%d' % self._dev()
+        d_raw = torch.from_numpy(buf).to(dev)
+        out = torch.empty(tuple(int(d) for d in dims), dtype=torch.float32, device=dev)
+        scratch = torch.empty((h.STAT_DOUBLES,), dtype=torch.float64, device=dev)
+        h.zscore_volume(d_raw, dims, fortran, out, scratch, torch.cuda.current_stream(self._dev()).cuda_stream)
+        return out
+
+    def roi_centers(self, mask, iterations=10):
+        """The voxel list test_scan classifies (base.py:369-370): mask != 0, dilated `iterations` times (6-neighbour cross), its
+        voxels in C order - on the device.  Returns (centers int64 ndarray [N,3], the same as an int32 device tensor)."""
+        torch = self._torch()
+        buf, dims, fortran = self._file_order(mask)
+        h = self._ensure_handle()
+        dev = 'cuda:%d' % self._dev()
+        st = torch.cuda.current_stream(self._dev()).cuda_stream
+        nvox = int(np.prod(dims))
+        d_raw = torch.from_numpy(buf).to(dev)
+        d_mask = torch.empty((nvox,), dtype=torch.uint8, device=dev)
+        d_scr = torch.empty((nvox,), dtype=torch.uint8, device=dev)
+        d_off = torch.empty(((nvox + 1023) // 1024 + 1,), dtype=torch.int32, device=dev)
+        n = h.roi_prepare(d_raw, dims, fortran, iterations, d_mask, d_scr, d_off, st)
+        d_cen = torch.empty((n, 3), dtype=torch.int32, device=dev)
+        h.roi_centers(d_mask, dims, d_off, d_cen, n, st)
+        self._wait()
+        return d_cen.cpu().numpy().astype(np.int64), d_cen
 
     def dilate_mask(self, mask, iterations=10):
         """scipy.ndimage.binary_dilation(mask, iterations=iterations) (default 6-neighbour structure, border 0) on the GPU:
@@ -464,9 +547,18 @@ class Net:
         world x batch_size samples at the unchanged learning rate (the reference is single-device; scale batch_size down by
         the world size for history-comparable runs); the hold-out pass is sharded over the ranks."""
         from . import dist
-        from .base import CompactTrainingSet
+        from .base import CompactTrainingSet, compact_from_views
         torch = self._torch()
+        if isinstance(X, dict) and y is not None:
+            # the unchanged train_model.py sequence: the dict holds the lazy views generate_training_set returned -> the same
+            # set in its compact form (with the prior rows and labels of THIS call), patches cut on the GPU
+            lazy = compact_from_views(X, y)
+            if lazy is not None:
+                X = lazy
         compact = isinstance(X, CompactTrainingSet)
+        if not compact:
+            # anything array-like that is neither a NumPy array nor a torch tensor (a lone lazy view, a list) becomes the array
+            X = {k: (v if isinstance(v, np.ndarray) or torch.is_tensor(v) else np.asarray(v)) for k, v in X.items()}
         if compact:
             n = len(X)
             y_all = X.y[X.index]                       # labels in training order

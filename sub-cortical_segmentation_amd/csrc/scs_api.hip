@@ -10,6 +10,7 @@
 //   fc_2 -> [n][272]                                              nets.py:227
 //   out_layer + softmax + argmax                                  nets.py:231; base.py:425-438
 // Dropout layers are identity at inference, PReLU after ReLU is the identity for any alpha.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -202,6 +203,135 @@ __global__ __launch_bounds__(256) void dilate_step_kernel(const uint8_t* __restr
             out[at] = v ? 1 : 0;
         }
     }
+}
+
+
+// ----------------------------------------------------------------------------- whole-volume preparation (test_scan)
+// Element `lin` (C order of [X][Y][Z], z fastest) of a raw volume as it lies in a NIfTI file (Fortran order: x fastest) or in C
+// order; any of the scalar types a T1 / mask file holds.  dtype: 0 u8, 1 i16, 2 u16, 3 i32, 4 f32, 5 f64.
+template <class T> __device__ __forceinline__ double raw_at(const void* p, size_t i) { return (double)reinterpret_cast<const T*>(p)[i]; }
+__device__ __forceinline__ double raw_value(const void* raw, int dtype, size_t i) {
+    switch (dtype) {
+        case 0: return raw_at<uint8_t>(raw, i);
+        case 1: return raw_at<int16_t>(raw, i);
+        case 2: return raw_at<uint16_t>(raw, i);
+        case 3: return raw_at<int32_t>(raw, i);
+        case 4: return raw_at<float>(raw, i);
+        default: return raw_at<double>(raw, i);
+    }
+}
+__device__ __forceinline__ size_t file_index(long lin, int dx, int dy, int dz, int fortran) {
+    if (!fortran) return (size_t)lin;
+    const int z = (int)(lin % dz);
+    const long xy = lin / dz;
+    const int y = (int)(xy % dy), x = (int)(xy / dy);
+    return (size_t)x + (size_t)dx * ((size_t)y + (size_t)dy * z);
+}
+
+// count, sum and sum of squares of the non-zero voxels: per-block partials in a fixed order (deterministic), in double
+constexpr int kStatBlocks = 1024;
+__global__ __launch_bounds__(256) void zscore_stats_kernel(const void* __restrict__ raw, int dtype, long n, double* __restrict__ part /*[kStatBlocks][3]*/) {
+    __shared__ double s_red[4][3];
+    double cnt = 0, sm = 0, sq = 0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)kStatBlocks * 256L) {
+        const double v = raw_value(raw, dtype, (size_t)e);           // the statistics do not depend on the order
+        if (v != 0.0) { cnt += 1.0; sm += v; sq += v * v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o); sm += __shfl_down(sm, o); sq += __shfl_down(sq, o); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_red[wv][0] = cnt; s_red[wv][1] = sm; s_red[wv][2] = sq; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        part[blockIdx.x * 3 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+// mean and population standard deviation from the partials -> stat[0] = mean, stat[1] = std, stat[2] = count
+__global__ __launch_bounds__(256) void zscore_final_kernel(const double* __restrict__ part, double* __restrict__ stat) {
+    __shared__ double s_red[4][3];
+    double cnt = 0, sm = 0, sq = 0;
+    for (int b = threadIdx.x; b < kStatBlocks; b += 256) { cnt += part[b * 3]; sm += part[b * 3 + 1]; sq += part[b * 3 + 2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o); sm += __shfl_down(sm, o); sq += __shfl_down(sq, o); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { s_red[wv][0] = cnt; s_red[wv][1] = sm; s_red[wv][2] = sq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+        sm = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+        sq = (s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2]);
+        const double mean = cnt > 0 ? sm / cnt : 0.0;
+        const double var = cnt > 0 ? fmax(sq / cnt - mean * mean, 0.0) : 0.0;
+        stat[0] = mean; stat[1] = sqrt(var); stat[2] = cnt;
+    }
+}
+// out[x][y][z] = float((v - mean) / std), in double like the reference's inference path (base.py:358), then one rounding
+__global__ __launch_bounds__(256) void zscore_apply_kernel(const void* __restrict__ raw, int dtype, int dx, int dy, int dz, int fortran,
+                                                          const double* __restrict__ stat, float* __restrict__ out) {
+    const long n = (long)dx * dy * dz;
+    const double mean = stat[0], sd = stat[1];
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256L)
+        out[e] = (float)((raw_value(raw, dtype, file_index(e, dx, dy, dz, fortran)) - mean) / sd);
+}
+// mask != 0 as 0/1 bytes in C order
+__global__ __launch_bounds__(256) void binarize_kernel(const void* __restrict__ raw, int dtype, int dx, int dy, int dz, int fortran, uint8_t* __restrict__ out) {
+    const long n = (long)dx * dy * dz;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256L)
+        out[e] = raw_value(raw, dtype, file_index(e, dx, dy, dz, fortran)) != 0.0 ? 1 : 0;
+}
+// ROI voxel list in C order (np.nonzero order, base.py:310-331): set voxels per run of kRoiRun consecutive voxels ...
+constexpr int kRoiRun = 1024;
+__global__ __launch_bounds__(256) void roi_count_kernel(const uint8_t* __restrict__ m, long n, int32_t* __restrict__ counts) {
+    __shared__ int s_red[4];
+    const long base = blockIdx.x * (long)kRoiRun + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < n && m[base + k]) ++c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+// ... exclusive scan of the run counts by one workgroup (counts[i] <- offset of run i, counts[nb] <- total) ...
+__global__ __launch_bounds__(1024) void roi_scan_kernel(int32_t* __restrict__ counts, int nb) {
+    __shared__ long s_part[1024];
+    const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = min(nb, lo + per);
+    long sum = 0;
+    for (int i = lo; i < hi; ++i) sum += counts[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { long run = 0; for (int i = 0; i < 1024; ++i) { const long v = s_part[i]; s_part[i] = run; run += v; } counts[nb] = (int32_t)run; }
+    __syncthreads();
+    long run = s_part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = counts[i]; counts[i] = (int32_t)run; run += v; }
+}
+// ... and the (x, y, z) rows themselves, each run writing behind its offset
+__global__ __launch_bounds__(256) void roi_write_kernel(const uint8_t* __restrict__ m, long n, int dy, int dz, const int32_t* __restrict__ offsets,
+                                                       int32_t* __restrict__ centers, long cap) {
+    __shared__ int s_scan[256];
+    const long base = blockIdx.x * (long)kRoiRun + threadIdx.x * 4;
+    bool on[4];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { on[k] = base + k < n && m[base + k]; c += on[k] ? 1 : 0; }
+    s_scan[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                            // inclusive Hillis-Steele scan of the 256 thread counts
+        const int v = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    long at = (long)offsets[blockIdx.x] + s_scan[threadIdx.x] - c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (on[k]) {
+            const long lin = base + k;
+            const int z = (int)(lin % dz);
+            const long xy = lin / dz;
+            if (at < cap) { centers[at * 3] = (int)(xy / dy); centers[at * 3 + 1] = (int)(xy % dy); centers[at * 3 + 2] = z; }
+            ++at;
+        }
 }
 
 // ----------------------------------------------------------------------------- packed-weights arena
@@ -668,6 +798,64 @@ int scs_dilate_mask(scs_handle h, uint8_t* mask_dev, uint8_t* scratch_dev, int d
     }
     if (a != mask_dev)            // odd iteration count: the result sits in the scratch buffer
         SCS_HIP(hipMemcpyAsync(mask_dev, a, (size_t)dx * dy * dz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    SCS_HIP(hipGetLastError());
+    return SCS_OK;
+}
+
+
+static int dtype_ok(int dtype) { return dtype >= 0 && dtype <= 5; }
+
+int scs_zscore_volume(scs_handle h, const void* raw_dev, int dtype, int dx, int dy, int dz, int fortran_order, float* out_dev,
+                      double* scratch_dev, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(raw_dev && out_dev && scratch_dev, "null pointer");
+    SCS_ARG(dx > 0 && dy > 0 && dz > 0 && dtype_ok(dtype), "bad dims or dtype");
+    SCS_HIP(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long n = (long)dx * dy * dz;
+    hipLaunchKernelGGL(zscore_stats_kernel, dim3(kStatBlocks), dim3(256), 0, st, raw_dev, dtype, n, scratch_dev);
+    hipLaunchKernelGGL(zscore_final_kernel, dim3(1), dim3(256), 0, st, scratch_dev, scratch_dev + 3 * kStatBlocks);
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 65535L * 8);
+    hipLaunchKernelGGL(zscore_apply_kernel, dim3(blocks), dim3(256), 0, st, raw_dev, dtype, dx, dy, dz, fortran_order,
+                       scratch_dev + 3 * kStatBlocks, out_dev);
+    SCS_HIP(hipGetLastError());
+    return SCS_OK;
+}
+
+int scs_roi_prepare(scs_handle h, const void* mask_raw_dev, int dtype, int dx, int dy, int dz, int fortran_order, int iterations,
+                    uint8_t* mask_dev, uint8_t* scratch_dev, int32_t* run_offsets_dev, int64_t* total_host, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(mask_raw_dev && mask_dev && scratch_dev && run_offsets_dev && total_host, "null pointer");
+    SCS_ARG(dx > 0 && dy > 0 && dz > 0 && dtype_ok(dtype) && iterations >= 0, "bad dims, dtype or iteration count");
+    SCS_HIP(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long n = (long)dx * dy * dz;
+    SCS_ARG(n < (1L << 31), "volume too large for 32-bit voxel offsets");
+    const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 65535L * 8);
+    hipLaunchKernelGGL(binarize_kernel, dim3(blocks), dim3(256), 0, st, mask_raw_dev, dtype, dx, dy, dz, fortran_order, mask_dev);
+    int rc = scs_dilate_mask(h, mask_dev, scratch_dev, dx, dy, dz, iterations, stream);
+    if (rc != SCS_OK) return rc;
+    const int nb = (int)((n + kRoiRun - 1) / kRoiRun);
+    hipLaunchKernelGGL(roi_count_kernel, dim3(nb), dim3(256), 0, st, mask_dev, n, run_offsets_dev);
+    hipLaunchKernelGGL(roi_scan_kernel, dim3(1), dim3(1024), 0, st, run_offsets_dev, nb);
+    SCS_HIP(hipGetLastError());
+    int32_t total = 0;
+    SCS_HIP(hipMemcpyAsync(&total, run_offsets_dev + nb, sizeof(total), hipMemcpyDeviceToHost, st));
+    SCS_HIP(hipStreamSynchronize(st));
+    *total_host = total;
+    return SCS_OK;
+}
+
+int scs_roi_centers(scs_handle h, const uint8_t* mask_dev, int dx, int dy, int dz, const int32_t* run_offsets_dev, int32_t* centers_dev,
+                    int64_t n_centers, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(mask_dev && run_offsets_dev && (centers_dev || n_centers == 0), "null pointer");
+    SCS_ARG(dx > 0 && dy > 0 && dz > 0 && n_centers >= 0, "bad dims or count");
+    if (n_centers == 0) return SCS_OK;
+    SCS_HIP(hipSetDevice(h->device));
+    const long n = (long)dx * dy * dz;
+    const int nb = (int)((n + kRoiRun - 1) / kRoiRun);
+    hipLaunchKernelGGL(roi_write_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, mask_dev, n, dy, dz, run_offsets_dev, centers_dev, (long)n_centers);
     SCS_HIP(hipGetLastError());
     return SCS_OK;
 }

@@ -25,6 +25,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.scs_target_arch() == b'gfx950'
 
 
+def test_io_library_exports_every_declared_symbol_and_needs_no_hip_runtime():
+    """include/scs_io.h <-> libscs_io.so <-> the ctypes table; the library must not depend on a HIP runtime (it is loaded before
+    torch has brought its own)."""
+    import subprocess
+    from cnn_cort import _hip
+    src = re.sub(r'/\*.*?\*/', '', open(os.path.join(ROOT, 'include', 'scs_io.h')).read(), flags=re.S)
+    names = sorted(set(re.findall(r'\b(scs_[a-z_0-9]+)\s*\(', src)))
+    lib = _hip.load_io_library()
+    assert set(names) == set(_hip.IO_SIGNATURES) and all(hasattr(lib, n) for n in names)
+    needed = subprocess.run(['readelf', '-d', _hip.IO_LIB_PATH], capture_output=True, text=True).stdout
+    assert 'libamdhip64' not in needed and 'libscs.so' not in needed
+
+
 def test_errors_are_reported_not_fatal():
     from cnn_cort import _hip
     lib = _hip.load_library()

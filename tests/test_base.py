@@ -111,12 +111,15 @@ def test_nifti_streaming_rows_and_sparse(tmp_path, monkeypatch, dt, shape):
     sizes are shrunk so that a small file spans many of them and elements straddle the pieces)."""
     import gzip
     monkeypatch.setattr(nifti, '_MEMBER_BYTES', 1 << 12)
+    monkeypatch.setattr(nifti, '_GAP_ROWS', 1)                        # sparse writer: many data runs, zero runs of every length
+    monkeypatch.setattr(nifti, '_MAX_ROWS_BYTES', 5 * 17 * np.dtype(dt).itemsize)      # ... and runs split over several members
     monkeypatch.setattr(nifti, '_STREAM_BYTES', 4999)
     monkeypatch.setattr(nifti, '_FEED_BYTES', 777)
     rng = np.random.default_rng(5)
     a = (rng.random(shape) * 100).astype(dt)
-    vox = np.stack([rng.integers(0, shape[i], 200) for i in range(3)], 1)
-    vals = (rng.random((200,) + shape[3:]) * 50 + 1).astype(dt)
+    vox = np.stack([rng.integers(0, shape[i], 40) for i in range(3)], 1)
+    vox = np.concatenate([vox, vox[:3]])                              # duplicates: the later value wins
+    vals = (rng.random((43,) + shape[3:]) * 50 + 1).astype(dt)
     dense = np.zeros(shape, dt)
     dense[vox[:, 0], vox[:, 1], vox[:, 2]] = vals                     # later duplicates win
     for ext in ('.nii.gz', '.nii'):
@@ -131,6 +134,15 @@ def test_nifti_streaming_rows_and_sparse(tmp_path, monkeypatch, dt, shape):
         opener = gzip.open if ext.endswith('.gz') else open
         with opener(str(tmp_path / ('dense' + ext)), 'rb') as f1, opener(str(tmp_path / ('sparse' + ext)), 'rb') as f2:
             assert f1.read() == f2.read()
+    # a label map: one value almost everywhere (also a non-zero one: the post-processing quirk), through the fill-value writer
+    if len(shape) == 3:
+        for fillv in (0, 14):
+            lab = np.full(shape, fillv, dt)
+            lab[vox[:9, 0], vox[:9, 1], vox[:9, 2]] = np.arange(1, 10).astype(dt)
+            nifti.save(lab, str(tmp_path / 'lab_dense.nii.gz'))
+            nifti.save_mostly_constant(lab, str(tmp_path / 'lab_sparse.nii.gz'))
+            with gzip.open(str(tmp_path / 'lab_dense.nii.gz'), 'rb') as f1, gzip.open(str(tmp_path / 'lab_sparse.nii.gz'), 'rb') as f2:
+                assert f1.read() == f2.read()
     # a single-member stream as an external tool writes it, and a truncated one
     with gzip.open(str(tmp_path / 'a.nii.gz'), 'rb') as f:
         raw = f.read()
@@ -350,6 +362,9 @@ def test_post_processing_fast_path_equals_the_literal_procedure(seed):
     want = R.post_process_segmentation(seg, atlas)
     got = base.post_process_mask(seg, atlas)
     assert got.dtype == want.dtype and np.array_equal(got, want)
+    nz = np.nonzero(seg)                                         # with the box test_scan passes: where the labels can be non-zero
+    box = tuple(slice(int(i.min()), int(i.max()) + 1) for i in nz)
+    assert np.array_equal(base.post_process_mask(seg, atlas, box), want)
 
 
 def test_compact_training_set_is_the_materialised_one(tmp_path):
@@ -360,7 +375,9 @@ def test_compact_training_set_is_the_materialised_one(tmp_path):
     opts = {'train_folder': str(tmp_path / 'train'), 't1_name': 'T1.nii.gz', 'roi_name': 'gt_15_classes.nii.gz',
             'patch_size': [32, 32], 'debug': 'False', 'seed': 11}
     x_ax, x_co, x_sa, y_ax, x_atl, _ = base.load_data(opts)
+    x_ax, x_co, x_sa, y_ax = [[np.asarray(a) for a in l] for l in (x_ax, x_co, x_sa, y_ax)]     # real arrays: the materialising code
     ref = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts)
+    assert all(isinstance(a, np.ndarray) for a in ref)
     data = base.load_data_compact(opts)
     cs = base.generate_training_set_compact(data, opts)
     assert len(cs) == ref[0].shape[0] and cs.samples.shape == (len(cs), 4) and len(cs.volumes) == 2
@@ -393,3 +410,48 @@ def test_compact_training_set_refuses_inconsistent_geometry():
         CompactTrainingSet(vol, [np.zeros((8, 9, 10), np.uint8)], np.array([[1, 1, 2, 3], [0, 4, 5, 6]], np.int32), atlas, y, np.array([0], np.int32))
     with pytest.raises(ValueError):
         CompactTrainingSet(vol, [np.zeros((8, 9, 10), np.uint8)], samples, atlas, y, np.array([2], np.int32))
+
+
+def test_unchanged_call_sequence_stays_lazy_and_materialises_to_the_reference_arrays(tmp_path):
+    """train_model.py:36-60 unchanged: load_data returns LazyPatches (the reference's per-subject [n, 32, 32] arrays in shape, dtype,
+    len and indexing - equal to the literal get_patches lists the moment they are turned into arrays), generate_training_set
+    recognises them and returns lazy [N, 1, 32, 32] views of ONE CompactTrainingSet + real prior / label arrays, equal to what the
+    materialising code returns for real arrays under the same seed; real arrays in -> real arrays out."""
+    vol, atlas, mask = make_subject(str(tmp_path / 'train' / 's1'), shape=(40, 44, 36), with_labels=True)
+    make_subject(str(tmp_path / 'train' / 's2'), shape=(36, 40, 44), seed=5, with_labels=True)
+    opts = {'train_folder': str(tmp_path / 'train'), 't1_name': 'T1.nii.gz', 'roi_name': 'gt_15_classes.nii.gz',
+            'patch_size': [32, 32], 'debug': 'False', 'seed': 11}
+    x_ax, x_co, x_sa, y_ax, x_atl, names = base.load_data(opts)
+    assert all(isinstance(a, base.LazyPatches) for l in (x_ax, x_co, x_sa, y_ax) for a in l)
+    a0 = x_ax[0]
+    n0 = len(a0)
+    assert a0.shape == (n0, 32, 32) and a0.dtype == np.float32 and a0.ndim == 3 and y_ax[0].shape == (n0, 32, 32)
+    # the literal per-voxel procedure of the reference on the same voxels (oracle/patches_ref.py)
+    vn = R.zscore_training(vol)
+    lit = np.array(R.get_patches(vn, [tuple(c) for c in a0.centers], (32, 32), mode='axial')).astype(np.float32)   # (float64 under NumPy 2 promotion)
+    assert np.array_equal(np.asarray(a0), lit) and np.array_equal(a0[5], lit[5]) and np.array_equal(a0[3:9], lit[3:9])
+    assert np.array_equal(a0[np.array([7, 2])], lit[[7, 2]]) and np.array_equal(a0[:, 16, 16], lit[:, 16, 16])
+    assert np.array_equal(np.concatenate(x_co, axis=0).astype('float32')[:n0], np.asarray(x_co[0]))   # what generate_training_set does
+    lazy = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts)
+    assert all(isinstance(v, base.LazyTrainingView) for v in lazy[:3]) and lazy[0].compact is lazy[1].compact is lazy[2].compact
+    assert isinstance(lazy[3], np.ndarray) and lazy[3].dtype == np.float32 and isinstance(lazy[4], np.ndarray) and lazy[4].dtype == np.uint8
+    real_in = [[np.asarray(a) for a in l] for l in (x_ax, x_co, x_sa)]
+    ref = base.generate_training_set(real_in[0], real_in[1], real_in[2], x_atl, [np.asarray(a) for a in y_ax], opts)
+    assert all(isinstance(a, np.ndarray) for a in ref)
+    N = ref[0].shape[0]
+    for got, want in zip(lazy, ref):
+        assert tuple(got.shape) == want.shape and got.dtype == want.dtype and np.array_equal(np.asarray(got), want)
+    assert len(lazy[0]) == N and np.array_equal(lazy[1][10:20], ref[1][10:20]) and np.array_equal(lazy[2][4], ref[2][4])
+    # not randomised, and a mixed input (one real array) falls back to the materialising code
+    un = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts, randomize=False)
+    assert np.array_equal(np.asarray(un[0])[:n0, 0], lit)
+    mixed = base.generate_training_set([np.asarray(x_ax[0]), x_ax[1]], x_co, x_sa, x_atl, y_ax, opts)
+    assert isinstance(mixed[0], np.ndarray) and np.array_equal(mixed[0], ref[0])
+    # the set Net.fit trains on carries the prior rows and labels of the CALL (edited labels are honoured)
+    cs = base.compact_from_views({'in1': lazy[0], 'in2': lazy[1], 'in3': lazy[2], 'in4': lazy[3]}, lazy[4])
+    assert cs is not None and np.array_equal(cs.y[cs.index], lazy[4]) and np.array_equal(cs.atlas[cs.index], lazy[3])
+    y_edit = lazy[4].copy()
+    y_edit[y_edit == 3] = 4
+    cs2 = base.compact_from_views({'in1': lazy[0], 'in2': lazy[1], 'in3': lazy[2], 'in4': lazy[3]}, y_edit)
+    assert np.array_equal(cs2.y[cs2.index], y_edit)
+    assert base.compact_from_views({'in1': ref[0], 'in2': lazy[1], 'in3': lazy[2], 'in4': lazy[3]}, lazy[4]) is None

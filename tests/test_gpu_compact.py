@@ -16,6 +16,9 @@ from test_gpu_train import GRAD_RTOL, arena, dev, pack_masks, _random_masks
 pytestmark = pytest.mark.gpu
 
 
+_LAZY = {}
+
+
 @pytest.fixture(scope='module')
 def toy(tmp_path_factory):
     root = tmp_path_factory.mktemp('compact')
@@ -24,8 +27,10 @@ def toy(tmp_path_factory):
     opts = {'train_folder': str(root / 'train'), 't1_name': 'T1.nii.gz', 'roi_name': 'gt_15_classes.nii.gz',
             'patch_size': [32, 32], 'debug': 'False', 'seed': 11}
     x_ax, x_co, x_sa, y_ax, x_atl, _ = base.load_data(opts)
-    mat = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts)
+    lazy = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts)          # the unchanged call sequence: lazy views
+    mat = base.generate_training_set(*[[np.asarray(a) for a in l] for l in (x_ax, x_co, x_sa)], x_atl, [np.asarray(a) for a in y_ax], opts)
     cs = base.generate_training_set_compact(base.load_data_compact(opts), opts)
+    _LAZY['views'] = lazy
     return opts, mat, cs
 
 
@@ -117,15 +122,27 @@ def test_fit_compact_streamed_and_resident_agree(toy, weights):
     from cnn_cort.nets import Net, stratified_first_fold
     _, mat, cs = toy
     X = {'in1': mat[0], 'in2': mat[1], 'in3': mat[2], 'in4': mat[3]}
+    # the UNCHANGED call sequence of train_model.py:36-60: the dict of lazy views generate_training_set returned for load_data's
+    # lists - fit() must take the gather-fused path (no patch is cut on the host) and walk the same batches
+    lazy = _LAZY['views']
+    XL = {'in1': lazy[0], 'in2': lazy[1], 'in3': lazy[2], 'in4': lazy[3]}
     hist = {}
-    for mode in ('compact', 'resident', 'streamed'):
+    for mode in ('compact', 'resident', 'streamed', 'unchanged sequence'):
         net = Net(max_epochs=2, patience=20, eval_size=0.25, batch_size=48, verbose=0, device=0, seed=4,
                   fit_slice=96, fit_resident_bytes=(2 << 30) if mode == 'resident' else 0)
         net.load_params_from({k: [a.copy() for a in v] for k, v in weights.items()})
-        net.fit(cs if mode == 'compact' else X, None if mode == 'compact' else mat[4])
+        if mode == 'unchanged sequence':
+            real_get_patches = base.get_patches
+            base.get_patches = lambda *a, **k: (_ for _ in ()).throw(AssertionError('fit() cut patches on the host'))
+            try:
+                net.fit(XL, lazy[4])
+            finally:
+                base.get_patches = real_get_patches
+        else:
+            net.fit(cs if mode == 'compact' else X, None if mode == 'compact' else mat[4])
         hist[mode] = [(r['train_loss'], r['valid_loss'], r['valid_accuracy']) for r in net.train_history_]
         final = net.get_all_params_values()
-    assert hist['compact'] == hist['resident'] == hist['streamed'], hist
+    assert hist['compact'] == hist['resident'] == hist['streamed'] == hist['unchanged sequence'], hist
     # weighted mean over ragged batches: replay epoch 1 batch by batch with the same dropout seeds on a fresh handle
     tr, va = stratified_first_fold(mat[4], 4)
     assert len(tr) % 48 != 0

@@ -120,3 +120,109 @@ def test_gpu_dilation_equals_scipy(shape, iters):
     got = net.dilate_mask(mask.astype(np.float32) * 3.0, iters)          # any non-zero value counts as set (the mask file is float)
     want = ndimage.binary_dilation(mask, iterations=iters) if iters else mask
     assert got.dtype == bool and got.shape == mask.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('dtype,order', [(np.int16, 'F'), (np.float32, 'C'), (np.uint8, 'F'), (np.float64, 'F')])
+def test_device_zscore_equals_the_numpy_normalisation(dtype, order):
+    """Net.normalize_volume (scs_zscore_volume: raw voxels in file order -> float32 [X,Y,Z]) against the reference's
+    `(image - image[nz].mean()) / image[nz].std()` (base.py:357-358) followed by the float32 cast: equal to one float32 ulp (the
+    mean / std sums run in a different order), for the element types and memory orders a T1 file comes in."""
+    from cnn_cort import synth
+    from cnn_cort.nets import Net
+    shape = (37, 41, 29)
+    vol = synth.smooth_volume(shape, sigma=3.0, seed=5)
+    vol = (np.round(vol) if np.dtype(dtype).kind in 'iu' else vol * 1.37).astype(dtype)
+    if dtype == np.uint8:
+        vol = (synth.smooth_volume(shape, sigma=3.0, seed=5) / 4).astype(np.uint8)
+    vol = np.asfortranarray(vol) if order == 'F' else np.ascontiguousarray(vol)
+    net = Net(device=0)
+    got = net.normalize_volume(vol)
+    assert tuple(got.shape) == shape and got.is_contiguous()
+    want = R.zscore_inference(vol.astype(np.float64) if np.dtype(dtype).kind == 'f' else vol).astype(np.float32)
+    g = got.cpu().numpy()
+    assert np.abs(g - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert np.mean(g != want) < 1e-3                                   # all but a few roundings identical
+
+
+@pytest.mark.parametrize('shape,iters,order', [((23, 17, 31), 10, 'F'), ((40, 44, 36), 10, 'C'), ((9, 64, 5), 3, 'F'), ((33, 20, 18), 0, 'F')])
+def test_device_roi_voxel_list_equals_dilation_plus_nonzero(shape, iters, order):
+    """Net.roi_centers (scs_roi_prepare + scs_roi_centers) == get_mask_voxels(binary_dilation(mask, iterations)) row for row:
+    same voxels, same (C) order as np.nonzero (base.py:369-370, 310-331), from float and byte masks in either memory order."""
+    from scipy import ndimage
+    from cnn_cort.nets import Net
+    rng = np.random.RandomState(sum(shape) + iters)
+    mask = rng.rand(*shape) < 0.004
+    mask[0, 0, 0] = mask[-1, -1, -1] = True
+    raw = (mask.astype(np.float32) * 2.5) if order == 'F' else mask.astype(np.uint8)
+    raw = np.asfortranarray(raw) if order == 'F' else np.ascontiguousarray(raw)
+    net = Net(device=0)
+    centers, d_cen = net.roi_centers(raw, iters)
+    want = base.get_mask_voxels(ndimage.binary_dilation(mask, iterations=iters) if iters else mask)
+    assert centers.dtype == np.int64 and np.array_equal(centers, want)
+    assert np.array_equal(d_cen.cpu().numpy(), want.astype(np.int32))
+    empty, d_empty = net.roi_centers(np.zeros(shape, np.uint8), 2)
+    assert empty.shape == (0, 3) and d_empty.shape[0] == 0
+
+
+@pytest.mark.timeout(900)
+def test_full_size_subject_of_baseline_config_4(tmp_path, weights):
+    """BASELINE configs[4] at its stated size: one 256x256x192 int16 subject with a 15-channel prior and a registered mask whose
+    10-voxel dilation gives a ~3.3e5-voxel ROI, out_probabilities and post_process on, through test_scan (raw volumes to the
+    device, z-score + ROI voxel list there, gather-fused forward, files written).  Checked: the voxel list against scipy + NumPy;
+    the probabilities of 2 000 ROI voxels bit for bit against the PATCH path (literal strided-view get_patches from the same
+    normalised volume -> scs_forward_host); 16 of them against the float64 oracle on patches cut by the literal per-voxel
+    procedure from the NumPy-normalised volume (1e-4); labels = argmax; nothing written outside the ROI."""
+    import sys
+    from scipy import ndimage
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    scan = bench.make_cohort(str(tmp_path), 1, seed=3)[0]
+    sub = os.path.dirname(scan)
+    opts = options(str(tmp_path), test_batch_size=100000)
+    net = build_model(os.path.join(PKG, 'nets'), opts)
+    minutes = base.test_scan(net, scan, opts)
+    assert 0 <= minutes < 1.0
+    raw = nifti.load(scan).get_data()
+    mask = nifti.load(os.path.join(sub, 'tmp', 'MNI_subcortical_mask.nii.gz')).get_data()
+    roi = ndimage.binary_dilation(mask, iterations=10)
+    centers = base.get_mask_voxels(roi)
+    assert 250000 < len(centers) < 450000 and net.last_scan_voxels == len(centers)
+    prob = nifti.load(os.path.join(sub, 'out_subcortical_prob.nii.gz')).get_data()
+    assert prob.shape == raw.shape + (15,) and prob.dtype == np.float64
+    assert np.count_nonzero(prob.sum(-1)) == len(centers) and (prob[~roi] == 0).all()      # every ROI voxel written, nothing else
+    pick = np.sort(np.random.RandomState(1).choice(len(centers), 2000, replace=False))
+    c = centers[pick]
+    got = prob[c[:, 0], c[:, 1], c[:, 2]]
+    # patch path on the same normalised volume: bit-identical
+    vol = net.normalize_volume(raw).cpu().numpy()
+    atlas_rows = base.atlas_rows_from_file(os.path.join(sub, 'tmp', 'MNI_sub_probabilities.nii.gz'), c)
+    X = {'in%d' % (i + 1): base.get_patches(vol, c, (32, 32), m)[:, None] for i, m in enumerate(('axial', 'coronal', 'saggital'))}
+    X['in4'] = atlas_rows
+    p_patch = net.predict_proba(X)
+    # (2 000 rows go through the split-K form of the dense head, the subject's 32 512-row chunks through the tiled one: the same
+    # products summed in a different order)
+    assert np.abs(got - p_patch).max() < 5e-5       # (logits of +-80 on this synthetic subject: 1e-7 relative is 1e-5 of a probability)
+    # ... and bit for bit where the batch is the same: the first internal chunk of the subject (scs_api.hip: balanced_chunk)
+    k = -(-len(centers) // 32768)
+    step = -(-(-(-len(centers) // k)) // 16) * 16
+    c1 = centers[:step]
+    X1 = {'in%d' % (i + 1): base.get_patches(vol, c1, (32, 32), m)[:, None] for i, m in enumerate(('axial', 'coronal', 'saggital'))}
+    X1['in4'] = base.atlas_rows_from_file(os.path.join(sub, 'tmp', 'MNI_sub_probabilities.nii.gz'), c1)
+    assert np.array_equal(prob[c1[:, 0], c1[:, 1], c1[:, 2]], net.predict_proba(X1).astype(np.float64))
+    # float64 oracle on literally cut patches of the NumPy-normalised volume
+    vn = R.zscore_inference(raw)
+    sel = pick[::125][:16]
+    cs = [tuple(int(v) for v in centers[i]) for i in sel]
+    views = [np.stack([np.array(R.get_patches(vn, cs, (32, 32), mode=m)).astype(np.float32)], axis=1) for m in ('axial', 'coronal', 'saggital')]
+    atlas = nifti.load(os.path.join(sub, 'tmp', 'MNI_sub_probabilities.nii.gz')).get_data()
+    p_ref = O.forward(weights, views[0], views[1], views[2], R.atlas_vectors(atlas, cs))
+    g16 = prob[tuple(np.array(cs).T)]
+    assert np.abs(g16 - p_ref).max() < 1e-4
+    # labels: the post-processed file exists with the T1's geometry; the raw labels of a second call are argmax of the probabilities
+    seg = nifti.load(os.path.join(sub, 'out_subcortical_seg_prec.nii.gz')).get_data()
+    assert seg.shape == raw.shape and seg.dtype == raw.dtype
+    base.test_scan(net, scan, options(str(tmp_path), test_batch_size=100000, post_process='False', out_probabilities='False'))
+    rawseg = nifti.load(os.path.join(sub, 'out_subcortical_rawseg.nii.gz')).get_data()
+    assert np.array_equal(rawseg[c[:, 0], c[:, 1], c[:, 2]], got.argmax(1)) and (rawseg[~roi] == 0).all()
+    assert np.array_equal(seg, R.post_process_segmentation(rawseg, mask.astype(bool)) if False else base.post_process_mask(rawseg, mask))

@@ -144,6 +144,119 @@ __global__ __launch_bounds__(256, WPC) void gemm_mfma_kernel(GemmArgs g) {
         }
 }
 
+// The throughput configuration with 16-byte global loads (every operand row a multiple of 4 floats and 16-byte aligned - the
+// inference GEMMs: lda 540 / 556, packed W rows of 208 / 560 / 272 floats): workgroup tile (64 MT) x (16 NT), K slabs of 16.
+// A thread fetches MT float4 of A (row (t >> 2) + 64 i, k = 4 (t & 3) .. + 3) and up to two float4 of W per slab instead of 14
+// single floats, and parks them in LDS with 8- / 16-byte stores; the LDS images and the fragment reads are those of
+// gemm_mfma_kernel (A rows of 18 floats: bank = 2 row + k; W rows padded to 16 mod 32).  Rows >= M and k >= K read as zero.
+template <int MT, int NT, int WPC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPC, WPC))) void gemm_mfma_v4_kernel(GemmArgs g) {
+    constexpr int BK = 16, BM = 64 * MT, BN = 16 * NT, BS = (BN % 32 == 16) ? BN : BN + 16, AS = BK + 2;
+    constexpr int B4 = BK * BN / 4;                                    // float4 of a W slab
+    static_assert(B4 <= 512 && BN % 4 == 0, "two W pieces per thread at most");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_a = smem;                                  // [2][BM][AS]
+    float* s_b = smem + 2 * BM * AS;                    // [2][BK][BS]
+    const int z = blockIdx.z;
+    const GemmProblem P = z == 0 ? g.p[0] : (z == 1 ? g.p[1] : g.p[2]);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kmax = g.K ? g.K : g.K4;
+
+    // this thread's pieces: A rows a_row + 64 i at k offset 4 a_k4; W rows b_kr[j], columns n0 + 4 b_c4[j]
+    const int a_k4 = tid & 3, a_row = tid >> 2;
+    const float* __restrict__ ap0 = P.A + (size_t)min(m0 + a_row, g.M - 1) * P.lda + 4 * a_k4;      // row a_row + 64 i: ap0 + 64 i lda
+    const size_t a_step = (size_t)64 * P.lda;
+    const int a_rows_left = g.M - (m0 + a_row);                        // row a_row + 64 i exists while 64 i < a_rows_left
+    // (named scalars, not small arrays indexed inside a lambda: those end up in scratch memory)
+    const int b_kr0 = tid / (BN / 4), b_c40 = tid - b_kr0 * (BN / 4);
+    const int b_kr1 = (tid + 256) / (BN / 4), b_c41 = (tid + 256) - b_kr1 * (BN / 4);
+    const bool b_ok0 = tid < B4 && n0 + 4 * b_c40 < P.NS, b_ok1 = tid + 256 < B4 && n0 + 4 * b_c41 < P.NS;
+    const float* __restrict__ bp0 = P.W + (size_t)b_kr0 * P.NS + n0 + 4 * b_c40;
+    const float* __restrict__ bp1 = P.W + (size_t)b_kr1 * P.NS + n0 + 4 * b_c41;
+    float4 ra[MT], rb0, rb1;
+#define SCS_V4_LOAD(k0)                                                                                                   \
+    {                                                                                                                     \
+        const bool ka = (k0) + 4 * a_k4 < g.K4;                                                                           \
+        /* (assign-then-overwrite, not `cond ? *p : zero`: the compiler turns that into a select of POINTERS - one of them into   \
+           scratch memory - behind a flat load) */                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                   \
+            ra[i] = float4{0.f, 0.f, 0.f, 0.f};                                                                            \
+            if (64 * i < a_rows_left && ka) ra[i] = *reinterpret_cast<const float4*>(ap0 + i * a_step + (k0));              \
+        }                                                                                                                 \
+        rb0 = float4{0.f, 0.f, 0.f, 0.f}; rb1 = float4{0.f, 0.f, 0.f, 0.f};                                                 \
+        if (b_ok0 && (k0) + b_kr0 < kmax) rb0 = *reinterpret_cast<const float4*>(bp0 + (size_t)(k0) * P.NS);                \
+        if (b_ok1 && (k0) + b_kr1 < kmax) rb1 = *reinterpret_cast<const float4*>(bp1 + (size_t)(k0) * P.NS);                \
+    }
+#define SCS_V4_STORE(buf)                                                                                                 \
+    {                                                                                                                     \
+        float* da = s_a + (buf) * BM * AS + a_row * AS + 4 * a_k4;                                                         \
+        float* db = s_b + (buf) * BK * BS;                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                   \
+            *reinterpret_cast<float2*>(da + 64 * i * AS) = float2{ra[i].x, ra[i].y};                                        \
+            *reinterpret_cast<float2*>(da + 64 * i * AS + 2) = float2{ra[i].z, ra[i].w};                                    \
+        }                                                                                                                 \
+        if (tid < B4) *reinterpret_cast<float4*>(db + b_kr0 * BS + 4 * b_c40) = rb0;                                        \
+        if (tid + 256 < B4) *reinterpret_cast<float4*>(db + b_kr1 * BS + 4 * b_c41) = rb1;                                  \
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nslab = (g.K4 + BK - 1) / BK;
+    SCS_V4_LOAD(0)
+    SCS_V4_STORE(0)
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        if (s + 1 < nslab) SCS_V4_LOAD((s + 1) * BK)
+        const float* sa = s_a + (s & 1) * BM * AS + (wave * 16 * MT + lr) * AS + kq;
+        const float* sb = s_b + (s & 1) * BK * BS + kq * BS + lr;
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = sa[i * 16 * AS + ks * 4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = sb[ks * 4 * BS + j * 16];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nslab) SCS_V4_STORE((s + 1) & 1)
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + j * 16 + lr;
+            if (col >= g.N) continue;
+            const float bv = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wave * 16 * MT + i * 16 + kq * 4 + r;
+                if (row < g.M) gemm_store(P, g.relu, row, col, acc[i][j][r] + bv);
+            }
+        }
+}
+
+#undef SCS_V4_LOAD
+#undef SCS_V4_STORE
+
+template <int MT, int NT>
+struct GemmV4Tile {
+    static constexpr int BM = 64 * MT, BN = 16 * NT, BS = (BN % 32 == 16) ? BN : BN + 16;
+    static constexpr size_t LDS = (size_t)(2 * BM * 18 + 2 * 16 * BS) * 4;
+};
+
 // Latency configuration for the training batches (M = 256: a few dozen 64-row tiles on 256 CUs, one wave per SIMD, every
 // k-step waiting for its own operands): workgroup tile 16 rows x 48 columns, and the FOUR WAVES SPLIT K - wave w owns a
 // contiguous quarter of the k-steps.  Since no operand is shared between the waves there is nothing to stage: every lane
@@ -419,6 +532,11 @@ inline void dense_wgrad_launch(const WgGroupArgs& g, int nproblems, hipStream_t 
     hipLaunchKernelGGL(dense_wgrad_kernel<>, dim3((mr + 15) / 16, (mc + 47) / 48, nproblems + (g.loss_rows ? 1 : 0)), dim3(256), 0, st, g);
 }
 
+#ifndef SCS_GEMM_MT
+#define SCS_GEMM_MT 2            // 16-row tiles per wave of the vectorised throughput configuration (workgroup tile 64 MT x 96) and
+#define SCS_GEMM_V4WPC 4         // workgroups per CU: d1 / FC1 / fc_2 at 91 / 92 / 75 TFLOP/s (71 / 64 / 56 with MT 4 and 2 per CU, 76 / 76 / 71
+                                 // with 3 and 3; the scalar-load form they replace: 77 / 78 / 65) - profiles/r03_gemm_ab.txt
+#endif
 #ifndef SCS_GEMM_BK
 #define SCS_GEMM_BK 16           // K slab and workgroups per CU of the throughput (128 x 96) configuration: a 16-wide
 #define SCS_GEMM_WPC 3           // slab keeps the LDS image at 32 KB, so 3-4 workgroups share a CU (BK 32 / 2 per CU: -9 %)
@@ -430,6 +548,9 @@ inline hipError_t gemm_set_attrs() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<1, 3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)GemmTile<1, 3, 32>::LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_v4_kernel<SCS_GEMM_MT, 6, SCS_GEMM_V4WPC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)GemmV4Tile<SCS_GEMM_MT, 6>::LDS);
     if (e != hipSuccess) return e;
     return hipSuccess;                                  // gemm_splitk_kernel uses static LDS only
 }
@@ -443,7 +564,12 @@ inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
     using Lat = GemmSplitK;
     const long big_wgs = (long)((g.M + Big::BM - 1) / Big::BM) * ((g.N + Big::BN - 1) / Big::BN) * nproblems;
     const long small_wgs = (long)((g.M + Small::BM - 1) / Small::BM) * ((g.N + Small::BN - 1) / Small::BN) * nproblems;
-    if (big_wgs >= 192) {
+    using V4 = GemmV4Tile<SCS_GEMM_MT, 6>;
+    const long v4_wgs = (long)((g.M + V4::BM - 1) / V4::BM) * ((g.N + V4::BN - 1) / V4::BN) * nproblems;
+    if (v4_wgs >= 192 && gemm_vec4_ok(g, nproblems)) {
+        dim3 grid((g.M + V4::BM - 1) / V4::BM, (g.N + V4::BN - 1) / V4::BN, nproblems);
+        hipLaunchKernelGGL((gemm_mfma_v4_kernel<SCS_GEMM_MT, 6, SCS_GEMM_V4WPC>), grid, dim3(256), V4::LDS, st, g);
+    } else if (big_wgs >= 192) {
         dim3 grid((g.M + Big::BM - 1) / Big::BM, (g.N + Big::BN - 1) / Big::BN, nproblems);
         hipLaunchKernelGGL((gemm_mfma_kernel<2, 6, SCS_GEMM_BK, SCS_GEMM_WPC>), grid, dim3(256), Big::LDS, st, g);
     } else if (small_wgs > 256) {

@@ -1023,7 +1023,6 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         float* part = w->wg_part + (size_t)(i - 1) * kTowers * kWgPartFloats;
         for (int t = 0; t < kTowers; ++t) {
             wa.X[t] = w->X[t][i]; wa.w1[t] = w->w1p[t]; wa.dZ[t] = w->dZ[t][i];
-            wa.Z[t] = w->Z[t][i]; wa.dUp[t] = dUp.p[t]; wa.cf[t] = reinterpret_cast<const float*>(w->cf4[t][i]);
         }
         wa.x0 = x0;
         constexpr int kParts[kConvs] = {0, WG2::NB, WG3::NB, WG4::NB, WG5::NB};

@@ -32,13 +32,13 @@ using DG3N = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3, 0,
 constexpr int kFinMaxBatch = 512;
 
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
-// <CIN, COUT, HIN, row bands, workgroups per CU, X source, d z source, patches per staging round>.  d z is read from memory
-// (ZSRC 0: the data-gradient kernel of the layer stores it as a by-product of its staging, which costs it nothing, while
-// forming it again here costs 3-15 us per layer - tools/tbench.hip); conv2's X is the recomputed conv1 block output.
-using WG2 = WgCfg<20, 20, 30, 4, 3, 1, 0, 1>;
-using WG3 = WgCfg<20, 40, 14, 2, 3, 0, 0, 1>;
-using WG4 = WgCfg<40, 40, 12, 5, 2, 0, 0, 1, 1>;     // software-pipelined staging (8 patches per workgroup)
-using WG5 = WgCfg<40, 60, 5, 1, 2, 0, 0, 1>;
+// <CIN, COUT, HIN, row bands, workgroups per CU, X source, software-pipelined staging>.  d z is read from memory (the data-gradient
+// kernel of the layer stores it as a by-product of its staging, which costs it nothing, while forming it again in the weight-
+// gradient kernel cost 3-15 us per layer - profiles/r02_tbench_final.txt); conv2's X is the recomputed conv1 block output.
+using WG2 = WgCfg<20, 20, 30, 4, 3, 1>;
+using WG3 = WgCfg<20, 40, 14, 2, 3, 0>;
+using WG4 = WgCfg<40, 40, 12, 5, 2, 0, 1>;           // software-pipelined staging (8 patches per workgroup)
+using WG5 = WgCfg<40, 60, 5, 1, 2, 0>;
 constexpr size_t kWgPartFloats = (size_t)256 * 60 * 40 * 9;   // per tower and layer: room for 256 partials of the largest layer
 constexpr int kL1Bands = DG2::NB;
 

@@ -7,16 +7,16 @@
 //   cols  = output channels (16-wide v_mfma_f32_16x16x4_f32 blocks + 4-wide v_mfma_f32_4x4x1_16b_f32 blocks),
 //   k     = output pixels, 4 per step: the output row is padded to a multiple of 4 with ZERO dz columns so a k-step
 //           never straddles image rows and every operand address is base + immediate.
-// A workgroup walks a slice of the batch, GP patches per staging round, with its accumulators live, then writes one
+// A workgroup walks a slice of the batch, one patch per staging round, with its accumulators live, then writes one
 // partial dW; partials are summed in a fixed order (deterministic gradients) by wgrad_final_kernel.
 //
 // Operand sources (the training step keeps neither X1 nor any d z pass of its own):
 //   XSRC 0  X is read from global memory ([n][CIN][HIN][HIN]);
 //   XSRC 1  X is the conv1 block output (conv2's weight gradient), recomputed per patch band from the 32x32 input rows with
 //           the batch-statistics-folded conv1 operands (conv_mfma.h: conv1_to_lds);
-//   ZSRC 0  d z is read from global memory ([n][COUT][HO][HO]);
-//   ZSRC 1  d z = [sc z + sh > 0] sc dUp + ca z + cb is computed while staging from the layer's raw output z and the
-//           upstream gradient dUp (same form as conv_mfma.h SRC_DZ_PAD2);  ZSRC 2: the same through a 2x2 max-pool.
+//   d z is read from global memory ([n][COUT][HO][HO]): the data-gradient kernel of the layer stores it as a by-product of its
+//   staging.  (Forming d z here instead, and staging several patches per round, were measured in round 2 and cost 3-15 us per
+//   layer: profiles/r02_tbench_final.txt; those variants are no longer part of this header.)
 #pragma once
 #include <type_traits>
 
@@ -24,11 +24,10 @@
 
 namespace scs {
 
-template <int CIN_, int COUT_, int HIN_, int NB_ = 1, int WPC_ = 1, int XSRC_ = 0, int ZSRC_ = 0, int GP_ = 1, int PIPE_ = 0>
+template <int CIN_, int COUT_, int HIN_, int NB_ = 1, int WPC_ = 1, int XSRC_ = 0, int PIPE_ = 0>
 struct WgCfg {
-    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2, XSRC = XSRC_, ZSRC = ZSRC_, GP = GP_;
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, HO = HIN_ - 2, XSRC = XSRC_;
     static constexpr bool PIPE = PIPE_ != 0;                 // one patch per round, the next patch's loads in flight during the matrix phase
-    static_assert(!PIPE_ || (GP_ == 1 && ZSRC_ == 0), "the pipelined walk stages one patch from stored d z");
     // a workgroup owns band `b` of NB bands of output rows (HOB rows of dz, HOB + 2 rows of X) of the patches of its
     // batch slice: smaller LDS footprint -> WPC workgroups share a CU and overlap staging with the matrix phase
     static constexpr int NB = NB_, WPC = WPC_, HOB = HO / NB_, HXB = HOB + 2;
@@ -43,21 +42,16 @@ struct WgCfg {
     static constexpr int X_FLOATS = (CIN_ * XPL + 3) / 4 * 4, Z_FLOATS = (COUT_ * ZPL + 3) / 4 * 4;   // per patch, 16-byte aligned pieces
     static constexpr int X0_ROWS = HXB + 2, X0_FLOATS = XSRC_ ? X0_ROWS * 32 + 4 : 0;                   // input rows per patch
     static constexpr int W1_FLOATS = XSRC_ ? (kW1Floats + 3) / 4 * 4 : 0;
-    static constexpr int CF_FLOATS = ZSRC_ ? 4 * COUT_ : 0;                                             // BN-backward coefficients
-    static constexpr size_t LDS_BYTES = (size_t)(GP_ * (X_FLOATS + Z_FLOATS + X0_FLOATS) + W1_FLOATS + CF_FLOATS) * 4;
+    static constexpr size_t LDS_BYTES = (size_t)(X_FLOATS + Z_FLOATS + X0_FLOATS + W1_FLOATS) * 4;
     static_assert(LDS_BYTES * WPC_ <= 160 * 1024, "LDS budget");
     static_assert(!XSRC_ || (CIN_ == 20 && HIN_ == 30), "the recomputed X is the conv1 block output");
-    static_assert(ZSRC_ != 2 || HO % 2 == 0, "pooled layers have even planes");
 };
 
 struct WgArgs {
     const float* X[kTowers];      // XSRC 0: [n][CIN][HIN][HIN]
     const float* w1[kTowers];     // XSRC 1: conv1 operands (kW1Floats, batch statistics folded)
     X0Src x0;                     // XSRC 1: the input patches
-    const float* dZ[kTowers];     // ZSRC 0: [n][COUT][HO][HO]
-    const float* Z[kTowers];      // ZSRC 1/2: raw conv output of this layer [n][COUT][HO][HO]
-    const float* dUp[kTowers];    // ZSRC 1: [n][COUT][HO][HO]; ZSRC 2: [n][COUT][HO/2][HO/2]
-    const float* cf[kTowers];     // ZSRC 1/2: float4 [COUT] (sc, sh, ca, cb)
+    const float* dZ[kTowers];     // [n][COUT][HO][HO]
     float* part;                  // [tower][slice][band][CIN*9][COUT]
     int n, slices;
 };
@@ -65,11 +59,10 @@ struct WgArgs {
 template <class C>
 __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_x = smem;                                   // [GP][X_FLOATS]
-    float* s_z = s_x + C::GP * C::X_FLOATS;              // [GP][Z_FLOATS]
-    float* s_x0 = s_z + C::GP * C::Z_FLOATS;             // [GP][X0_FLOATS]
-    float* s_w1 = s_x0 + C::GP * C::X0_FLOATS;
-    const float4* s_cf = reinterpret_cast<const float4*>(s_w1 + C::W1_FLOATS);
+    float* s_x = smem;                                   // [X_FLOATS]
+    float* s_z = s_x + C::X_FLOATS;                      // [Z_FLOATS]
+    float* s_x0 = s_z + C::Z_FLOATS;                     // [X0_FLOATS]
+    float* s_w1 = s_x0 + C::X0_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
@@ -78,14 +71,10 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
     const int per = (a.n + a.slices - 1) / a.slices, n0 = slice * per, n1 = min(a.n, n0 + per);
 
     // zero once: dz padding columns and the X plane tails stay zero for the whole kernel
-    for (int e = tid; e < C::GP * (C::X_FLOATS + C::Z_FLOATS); e += 256) smem[e] = 0.f;
+    for (int e = tid; e < C::X_FLOATS + C::Z_FLOATS; e += 256) smem[e] = 0.f;
     if constexpr (C::XSRC == 1) {
         const float* __restrict__ w1g = pick3(a.w1, tower);
         for (int e = tid; e < kW1Floats; e += 256) s_w1[e] = w1g[e];
-    }
-    if constexpr (C::ZSRC != 0) {
-        const float* __restrict__ cfg = pick3(a.cf, tower);
-        for (int e = tid; e < 4 * C::COUT; e += 256) (s_w1 + C::W1_FLOATS)[e] = cfg[e];
     }
 
     // per-lane row bases of this wave's (c,tap) tiles; rows beyond J are clamped (computed, never stored)
@@ -109,11 +98,11 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
     }
 
     // the matrix phase of one staged patch (all of its band's output rows)
-    auto mma_patch = [&](int g) {
+    auto mma_patch = [&](int) {
 #pragma unroll 1
         for (int y = 0; y < C::HOB; ++y) {
-            const float* __restrict__ sxr = s_x + g * C::X_FLOATS + y * C::HIN;
-            const float* __restrict__ szr = s_z + g * C::Z_FLOATS + y * C::WOP;
+            const float* __restrict__ sxr = s_x + y * C::HIN;
+            const float* __restrict__ szr = s_z + y * C::WOP;
 #pragma unroll
             for (int xg = 0; xg < C::WOP / 4; ++xg) {
                 float b[C::NT16 > 0 ? C::NT16 : 1], b4[C::NT4 > 0 ? C::NT4 : 1];
@@ -184,136 +173,48 @@ __global__ __launch_bounds__(256, C::WPC) void wgrad_mfma_kernel(WgArgs a) {
             mma_patch(0);
         }
     } else
-    for (int nb = n0; nb < n1; nb += C::GP) {
-        __syncthreads();                                                   // previous round consumed (and the zero fill)
-        const int ng = min(C::GP, n1 - nb);                                // patches of this round; the others keep d z = 0
+    for (int nb = n0; nb < n1; ++nb) {
+        __syncthreads();                                                   // previous patch consumed (and the zero fill)
         // ---- X
         if constexpr (C::XSRC == 1) {
-#pragma unroll
-            for (int g = 0; g < C::GP; ++g)
-                if (g < ng) load_x0_rows<C::X0_ROWS, 256>(a.x0, tower, nb + g, y0, s_x0 + g * C::X0_FLOATS, tid);
+            load_x0_rows<C::X0_ROWS, 256>(a.x0, tower, nb, y0, s_x0, tid);
         } else {
             // rows y0 .. y0+HXB of every X plane are one contiguous run of XB floats
             constexpr int HW = C::HIN * C::HIN, XB = C::HXB * C::HIN;
             const float* __restrict__ xs = pick3(a.X, tower) + (size_t)nb * C::CIN * HW + y0 * C::HIN;
-            const int planes = ng * C::CIN;
             if constexpr (HW % 4 == 0 && XB % 4 == 0 && (C::HOB * C::HIN) % 4 == 0) {
-                staged_copy<C::GP * C::CIN * XB / 4, float4>(
-                    tid, [&](int e) { const int pl = min(e / (XB / 4), planes - 1), r = e % (XB / 4);
-                                      return reinterpret_cast<const float4*>(xs + (size_t)pl * HW)[r]; },
-                    [&](int e, float4 v) { const int pl = e / (XB / 4), r = e - pl * (XB / 4), g = pl / C::CIN, c = pl - g * C::CIN;
-                                           reinterpret_cast<float4*>(s_x + g * C::X_FLOATS)[c * (C::XPL / 4) + r] = v; });
+                staged_copy<C::CIN * XB / 4, float4>(
+                    tid, [&](int e) { const int pl = e / (XB / 4), r = e % (XB / 4); return reinterpret_cast<const float4*>(xs + (size_t)pl * HW)[r]; },
+                    [&](int e, float4 v) { const int c = e / (XB / 4), r = e - c * (XB / 4); reinterpret_cast<float4*>(s_x)[c * (C::XPL / 4) + r] = v; });
             } else if constexpr (HW % 2 == 0 && XB % 2 == 0 && (C::HOB * C::HIN) % 2 == 0) {
-                staged_copy<C::GP * C::CIN * XB / 2, float2>(
-                    tid, [&](int e) { const int pl = min(e / (XB / 2), planes - 1), r = e % (XB / 2);
-                                      return reinterpret_cast<const float2*>(xs + (size_t)pl * HW)[r]; },
-                    [&](int e, float2 v) { const int pl = e / (XB / 2), r = e - pl * (XB / 2), g = pl / C::CIN, c = pl - g * C::CIN;
-                                           reinterpret_cast<float2*>(s_x + g * C::X_FLOATS)[c * (C::XPL / 2) + r] = v; });
+                staged_copy<C::CIN * XB / 2, float2>(
+                    tid, [&](int e) { const int pl = e / (XB / 2), r = e % (XB / 2); return reinterpret_cast<const float2*>(xs + (size_t)pl * HW)[r]; },
+                    [&](int e, float2 v) { const int c = e / (XB / 2), r = e - c * (XB / 2); reinterpret_cast<float2*>(s_x)[c * (C::XPL / 2) + r] = v; });
             } else {
-                staged_copy<C::GP * C::CIN * XB, float>(
-                    tid, [&](int e) { const int pl = min(e / XB, planes - 1), r = e % XB; return xs[(size_t)pl * HW + r]; },
-                    [&](int e, float v) { const int pl = e / XB, r = e - pl * XB, g = pl / C::CIN, c = pl - g * C::CIN;
-                                          s_x[g * C::X_FLOATS + c * C::XPL + r] = v; });
+                staged_copy<C::CIN * XB, float>(
+                    tid, [&](int e) { const int pl = e / XB, r = e % XB; return xs[(size_t)pl * HW + r]; },
+                    [&](int e, float v) { const int c = e / XB, r = e - c * XB; s_x[c * C::XPL + r] = v; });
             }
         }
-        // ---- d z (zero for the patches beyond the slice)
+        // ---- d z
         constexpr int PZ = C::HO * C::HO, ZB = C::HOB * C::HO;
-        const int zplanes = ng * C::COUT;
-        if constexpr (C::ZSRC == 0) {
-            const float* __restrict__ zs = pick3(a.dZ, tower) + (size_t)nb * C::COUT * PZ + y0 * C::HO;
-            if constexpr (C::WOP == C::HO && PZ % 4 == 0 && ZB % 4 == 0) {
-                // no row padding: a band of a dz plane is one contiguous run, in global memory and in LDS
-                staged_copy<C::GP * C::COUT * ZB / 4, float4>(
-                    tid, [&](int e) { const int pl = e / (ZB / 4), r = e - pl * (ZB / 4);
-                                      return pl < zplanes ? reinterpret_cast<const float4*>(zs + (size_t)pl * PZ)[r] : float4{0.f, 0.f, 0.f, 0.f}; },
-                    [&](int e, float4 v) { const int pl = e / (ZB / 4), r = e - pl * (ZB / 4), g = pl / C::COUT, o = pl - g * C::COUT;
-                                           reinterpret_cast<float4*>(s_z + g * C::Z_FLOATS)[o * (C::ZPL / 4) + r] = v; });
-            } else {
-                staged_copy<C::GP * C::COUT * ZB, float>(
-                    tid, [&](int e) { const int pl = e / ZB, r = e - pl * ZB; return pl < zplanes ? zs[(size_t)pl * PZ + r] : 0.f; },
-                    [&](int e, float v) { const int pl = e / ZB, r = e - pl * ZB, y = r / C::HO, x = r - y * C::HO, g = pl / C::COUT, o = pl - g * C::COUT;
-                                          s_z[g * C::Z_FLOATS + o * C::ZPL + y * C::WOP + x] = v; });
-            }
-        } else if constexpr (C::ZSRC == 1) {
-            const float* __restrict__ zs = pick3(a.Z, tower) + (size_t)nb * C::COUT * PZ + y0 * C::HO;
-            const float* __restrict__ ds = pick3(a.dUp, tower) + (size_t)nb * C::COUT * PZ + y0 * C::HO;
-            struct V { float z, d; };
-            staged_copy<C::GP * C::COUT * ZB, V, 256, 0>(
-                tid,
-                [&](int e) { const int pl = e / ZB, r = e - pl * ZB; V v;
-                             if (pl < zplanes) { v.z = zs[(size_t)pl * PZ + r]; v.d = ds[(size_t)pl * PZ + r]; }
-                             else { v.z = v.d = 0.f; }
-                             return v; },
-                [&](int e, V v) { const int pl = e / ZB, r = e - pl * ZB, y = r / C::HO, x = r - y * C::HO, g = pl / C::COUT, o = pl - g * C::COUT;
-                                  const float4 cf = s_cf[o];
-                                  const float dz = ((fmaf(v.z, cf.x, cf.y) > 0.f) ? cf.x * v.d : 0.f) + fmaf(cf.z, v.z, cf.w);
-                                  s_z[g * C::Z_FLOATS + o * C::ZPL + y * C::WOP + x] = (pl < zplanes) ? dz : 0.f; });
+        const float* __restrict__ zs = pick3(a.dZ, tower) + (size_t)nb * C::COUT * PZ + y0 * C::HO;
+        if constexpr (C::WOP == C::HO && PZ % 4 == 0 && ZB % 4 == 0) {
+            // no row padding: a band of a dz plane is one contiguous run, in global memory and in LDS
+            staged_copy<C::COUT * ZB / 4, float4>(
+                tid, [&](int e) { const int pl = e / (ZB / 4), r = e - pl * (ZB / 4); return reinterpret_cast<const float4*>(zs + (size_t)pl * PZ)[r]; },
+                [&](int e, float4 v) { const int o = e / (ZB / 4), r = e - o * (ZB / 4); reinterpret_cast<float4*>(s_z)[o * (C::ZPL / 4) + r] = v; });
         } else {
-            // window rows that touch the band: wy0 .. wy0 + NWR (an odd band start shares its first window row with the band above)
-            constexpr int HP = C::HO / 2, NWR = C::HOB / 2 + 1, WPP = NWR * HP;
-            const int wy0 = y0 >> 1;
-            const float* __restrict__ zs = pick3(a.Z, tower) + (size_t)nb * C::COUT * PZ;
-            const float* __restrict__ ds = pick3(a.dUp, tower) + (size_t)nb * C::COUT * HP * HP;
-            struct V { float2 r0, r1; float d; };
-            staged_copy<C::GP * C::COUT * WPP, V, 256, 0>(
-                tid,
-                [&](int e) { const int pl = e / WPP, w = e - pl * WPP, wy = wy0 + w / HP, wx = w % HP; V v;
-                             if (pl < zplanes && wy < HP && 2 * wy < y0 + C::HOB) {
-                                 const float* q = zs + (size_t)pl * PZ + (2 * wy) * C::HO + 2 * wx;
-                                 v.r0 = *reinterpret_cast<const float2*>(q); v.r1 = *reinterpret_cast<const float2*>(q + C::HO);
-                                 v.d = ds[(size_t)pl * HP * HP + wy * HP + wx];
-                             } else { v.r0 = v.r1 = float2{0.f, 0.f}; v.d = 0.f; }
-                             return v; },
-                [&](int e, V v) { const int pl = e / WPP, w = e - pl * WPP, wy = wy0 + w / HP, wx = w % HP, g = pl / C::COUT, o = pl - g * C::COUT;
-                                  float4 cf = s_cf[o];
-                                  if (pl >= zplanes) cf = float4{0.f, 0.f, 0.f, 0.f};                 // patches beyond the slice: d z = 0
-                                  const float t0 = fmaf(v.r0.x, cf.x, cf.y), t1 = fmaf(v.r0.y, cf.x, cf.y);
-                                  const float t2 = fmaf(v.r1.x, cf.x, cf.y), t3 = fmaf(v.r1.y, cf.x, cf.y);
-                                  const float m = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
-                                  const float gr = (m > 0.f) ? cf.x * v.d : 0.f;
-                                  float* d = s_z + g * C::Z_FLOATS + o * C::ZPL + 2 * wx;
-                                  const int ya = 2 * wy - y0, yb = ya + 1;                         // band-local rows of the window
-                                  if (wy < HP && ya >= 0 && ya < C::HOB)
-                                      *reinterpret_cast<float2*>(d + ya * C::WOP) = float2{(t0 == m ? gr : 0.f) + fmaf(cf.z, v.r0.x, cf.w),
-                                                                                         (t1 == m ? gr : 0.f) + fmaf(cf.z, v.r0.y, cf.w)};
-                                  if (wy < HP && yb >= 0 && yb < C::HOB)
-                                      *reinterpret_cast<float2*>(d + yb * C::WOP) = float2{(t2 == m ? gr : 0.f) + fmaf(cf.z, v.r1.x, cf.w),
-                                                                                         (t3 == m ? gr : 0.f) + fmaf(cf.z, v.r1.y, cf.w)}; });
+            staged_copy<C::COUT * ZB, float>(
+                tid, [&](int e) { const int pl = e / ZB, r = e - pl * ZB; return zs[(size_t)pl * PZ + r]; },
+                [&](int e, float v) { const int o = e / ZB, r = e - o * ZB, y = r / C::HO, x = r - y * C::HO; s_z[o * C::ZPL + y * C::WOP + x] = v; });
         }
         __syncthreads();
         if constexpr (C::XSRC == 1) {
-#pragma unroll
-            for (int g = 0; g < C::GP; ++g)
-                if (g < ng) conv1_to_lds<C::XPL, C::HXB, 4>(s_x0 + g * C::X0_FLOATS, s_w1, s_x + g * C::X_FLOATS, wave, lane);
+            conv1_to_lds<C::XPL, C::HXB, 4>(s_x0, s_w1, s_x, wave, lane);
             __syncthreads();
         }
-#pragma unroll 1
-        for (int g = 0; g < ng; ++g) {
-#pragma unroll 1
-            for (int y = 0; y < C::HOB; ++y) {
-                const float* __restrict__ sxr = s_x + g * C::X_FLOATS + y * C::HIN;
-                const float* __restrict__ szr = s_z + g * C::Z_FLOATS + y * C::WOP;
-#pragma unroll
-                for (int xg = 0; xg < C::WOP / 4; ++xg) {
-                    float b[C::NT16 > 0 ? C::NT16 : 1], b4[C::NT4 > 0 ? C::NT4 : 1];
-#pragma unroll
-                    for (int nt = 0; nt < C::NT16; ++nt) b[nt] = szr[zoff16 + nt * 16 * C::ZPL + 4 * xg];
-#pragma unroll
-                    for (int u = 0; u < C::NT4; ++u) b4[u] = szr[zoff4 + u * 4 * C::ZPL + 4 * xg];
-#pragma unroll
-                    for (int m = 0; m < C::MTW; ++m) {
-                        if ((3 + 4 * m) >= C::MT && (wave + 4 * m) >= C::MT) continue;   // wave-uniform: no such row tile
-                        const float av = sxr[xbase[m] + 4 * xg];
-#pragma unroll
-                        for (int nt = 0; nt < C::NT16; ++nt)
-                            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[nt], acc[m][nt], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < C::NT4; ++u)
-                            acc4[m][u] = __builtin_amdgcn_mfma_f32_4x4x1f32(b4[u], av, acc4[m][u], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        mma_patch(0);
     }
 
     // ---- partial dW of this slice: part[tower][slice][band][j = c*9 + tap][o]  (output channel fastest: the 16 lanes of an

@@ -41,3 +41,39 @@ for bs in (128, 256):
     durs = [r['dur'] for r in net.train_history_]
     print('batch %d, compact set (gather-fused): %d samples, epoch times %s s -> %.0f samples/s (second epoch, training + hold-out pass)'
           % (bs, n, ['%.2f' % d for d in durs], n / durs[-1]), flush=True)
+
+# the UNCHANGED call sequence of train_model.py:36-60 on subject folders: load_data -> generate_training_set -> net.fit(dict, y).
+# load_data returns lazy patch arrays, generate_training_set lazy views of one compact set, fit() trains gather-fused.
+import tempfile
+from cnn_cort import base, nifti
+from scipy import ndimage
+with tempfile.TemporaryDirectory() as d:
+    t0 = time.time()
+    for s in range(4):
+        folder = os.path.join(d, 'train', 's%d' % s)
+        os.makedirs(os.path.join(folder, 'tmp'))
+        shape = (160, 192, 160)
+        vol = synth.smooth_volume(shape, seed=s, as_int=True)
+        atlas = synth.toy_atlas(shape, seed=10 + s)
+        lab = synth.toy_labels(shape, atlas)
+        # thicken the structures so that the four subjects give ~n samples in all (every label 1..14 voxel + as many boundary voxels)
+        fg = ndimage.binary_dilation(lab > 0, iterations=2) & (vol > 0)
+        lab = np.where(fg & (lab == 0), 15, lab).astype(np.uint8)
+        nifti.save(vol, os.path.join(folder, 'T1.nii.gz'))
+        nifti.save(lab, os.path.join(folder, 'gt_15_classes.nii.gz'))
+        nifti.save(atlas.astype(np.float32), os.path.join(folder, 'tmp', 'MNI_sub_probabilities.nii.gz'))
+    opts = {'train_folder': os.path.join(d, 'train'), 't1_name': 'T1.nii.gz', 'roi_name': 'gt_15_classes.nii.gz', 'patch_size': [32, 32],
+            'debug': 'False', 'seed': 5}
+    t1 = time.time()
+    x_ax, x_co, x_sa, y_ax, x_atl, names = base.load_data(opts)
+    tr = base.generate_training_set(x_ax, x_co, x_sa, x_atl, y_ax, opts)
+    t2 = time.time()
+    N = len(tr[4])
+    print('unchanged call sequence: 4 subjects written in %.1f s; load_data + generate_training_set %.2f s for %d samples '
+          '(%s)' % (t1 - t0, t2 - t1, N, type(tr[0]).__name__), flush=True)
+    for bs in (128, 256):
+        net = Net(max_epochs=2, patience=50, eval_size=0.25, batch_size=bs, verbose=0, device=0, seed=1)
+        net.fit({'in1': tr[0], 'in2': tr[1], 'in3': tr[2], 'in4': tr[3]}, tr[4])
+        durs = [r['dur'] for r in net.train_history_]
+        print('batch %d, unchanged call sequence (lazy views -> gather-fused): %d samples, epoch times %s s -> %.0f samples/s (second epoch, '
+              'training + hold-out pass)' % (bs, N, ['%.2f' % x for x in durs], N / durs[-1]), flush=True)

@@ -202,8 +202,7 @@ static void run_wg(const char* name, int n, int slices, int rounds, double macs_
     CK(wgrad_set_attr<C>());
     WgArgs a{};
     for (int t = 0; t < kTowers; ++t) {
-        a.X[t] = g_pool.in[t]; a.w1[t] = g_pool.coef[t] + 1024; a.dZ[t] = g_pool.in2[t]; a.Z[t] = g_pool.in2[t]; a.dUp[t] = g_pool.in3[t];
-        a.cf[t] = g_pool.coef[t] + 512; a.x0.views[t] = g_pool.in3[t];
+        a.X[t] = g_pool.in[t]; a.w1[t] = g_pool.coef[t] + 1024; a.dZ[t] = g_pool.in2[t]; a.x0.views[t] = g_pool.in3[t];
     }
     a.part = g_pool.part; a.n = n; a.slices = slices;
     if ((size_t)slices * C::NB > 1024) { printf("%s: too many partials for the tbench pool\n", name); return; }
@@ -327,7 +326,7 @@ int main(int argc, char** argv) {
         run_conv<ConvCfg<60, 40, 7, 3, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 1, 0, 6, 0, 3>>("DG5 G3 KS3 WPS1 no FIN", n, rounds, c5, true);
         run_conv<ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 1>>("DG5 one patch, tiles over waves (FIN)", n, rounds, c5, true);
         for (int sl : {4, 8, 16, 32}) run_wg_small<WgSmallCfg<40, 60, 5>>("WG5 split-K GEMM", n, sl, rounds, c5);
-        run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 1>>("WG5 per-patch staging (round 2 form)", n, 64, rounds, c5);
+        run_wg<WgCfg<40, 60, 5, 1, 2, 0>>("WG5 per-patch staging (round 2 form)", n, 64, rounds, c5);
         return 0;
     }
     if (!strcmp(what, "c5stamps")) {
@@ -380,14 +379,14 @@ int main(int argc, char** argv) {
     }
     if (!strcmp(what, "wgs")) {
         // weight-gradient kernels with and without the software-pipelined staging, over the number of batch slices
-        for (int sl : {64, 32}) run_wg<WgCfg<20, 20, 30, 4, 3, 1, 0, 1, 0>>("WG2", n, sl, rounds, c2);
-        for (int sl : {64, 32}) run_wg<WgCfg<20, 20, 30, 4, 3, 1, 0, 1, 1>>("WG2 pipelined", n, sl, rounds, c2);
-        for (int sl : {128, 64, 32}) run_wg<WgCfg<20, 40, 14, 2, 3, 0, 0, 1, 0>>("WG3", n, sl, rounds, c3);
-        for (int sl : {128, 64, 32}) run_wg<WgCfg<20, 40, 14, 2, 3, 0, 0, 1, 1>>("WG3 pipelined", n, sl, rounds, c3);
-        for (int sl : {64, 32, 16}) run_wg<WgCfg<40, 40, 12, 5, 3, 0, 0, 1, 0>>("WG4", n, sl, rounds, c4);
-        for (int sl : {64, 32, 16}) run_wg<WgCfg<40, 40, 12, 5, 2, 0, 0, 1, 1>>("WG4 pipelined WPC2", n, sl, rounds, c4);
-        for (int sl : {128, 64, 32}) run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 1, 0>>("WG5", n, sl, rounds, c5);
-        for (int sl : {128, 64, 32}) run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 1, 1>>("WG5 pipelined", n, sl, rounds, c5);
+        for (int sl : {64, 32}) run_wg<WgCfg<20, 20, 30, 4, 3, 1>>("WG2", n, sl, rounds, c2);
+        for (int sl : {64, 32}) run_wg<WgCfg<20, 20, 30, 4, 3, 1, 1>>("WG2 pipelined", n, sl, rounds, c2);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<20, 40, 14, 2, 3, 0>>("WG3", n, sl, rounds, c3);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<20, 40, 14, 2, 3, 0, 1>>("WG3 pipelined", n, sl, rounds, c3);
+        for (int sl : {64, 32, 16}) run_wg<WgCfg<40, 40, 12, 5, 3, 0>>("WG4", n, sl, rounds, c4);
+        for (int sl : {64, 32, 16}) run_wg<WgCfg<40, 40, 12, 5, 2, 0, 1>>("WG4 pipelined WPC2", n, sl, rounds, c4);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<40, 60, 5, 1, 2, 0>>("WG5", n, sl, rounds, c5);
+        for (int sl : {128, 64, 32}) run_wg<WgCfg<40, 60, 5, 1, 2, 0, 1>>("WG5 pipelined", n, sl, rounds, c5);
         return 0;
     }
     if (!strcmp(what, "sweep")) {
@@ -421,17 +420,17 @@ int main(int argc, char** argv) {
         run_conv<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 3>>("TF4 G1 WPS3", n, rounds, c4);
         run_wg<WG2>("WG2 (shipped)", n, 64, rounds, c2);
         run_wg<WG2>("WG2 (shipped)", n, 32, rounds, c2);
-        run_wg<WgCfg<20, 20, 30, 7, 4, 1, 0, 1>>("WG2 NB7 WPC4", n, 64, rounds, c2);
-        run_wg<WgCfg<20, 20, 30, 7, 4, 1, 0, 1>>("WG2 NB7 WPC4", n, 32, rounds, c2);
-        run_wg<WgCfg<20, 20, 30, 2, 2, 1, 0, 1>>("WG2 NB2 WPC2", n, 128, rounds, c2);
+        run_wg<WgCfg<20, 20, 30, 7, 4, 1>>("WG2 NB7 WPC4", n, 64, rounds, c2);
+        run_wg<WgCfg<20, 20, 30, 7, 4, 1>>("WG2 NB7 WPC4", n, 32, rounds, c2);
+        run_wg<WgCfg<20, 20, 30, 2, 2, 1>>("WG2 NB2 WPC2", n, 128, rounds, c2);
         run_wg<WG3>("WG3 (shipped)", n, 128, rounds, c3);
         run_wg<WG3>("WG3 (shipped)", n, 64, rounds, c3);
-        run_wg<WgCfg<20, 40, 14, 1, 3, 0, 0, 1>>("WG3 NB1", n, 256, rounds, c3);
-        run_wg<WgCfg<20, 40, 14, 3, 4, 0, 0, 1>>("WG3 NB3 WPC4", n, 128, rounds, c3);
+        run_wg<WgCfg<20, 40, 14, 1, 3, 0>>("WG3 NB1", n, 256, rounds, c3);
+        run_wg<WgCfg<20, 40, 14, 3, 4, 0>>("WG3 NB3 WPC4", n, 128, rounds, c3);
         run_wg<WG4>("WG4 (shipped)", n, 128, rounds, c4);
-        run_wg<WgCfg<40, 40, 12, 2, 2, 0, 0, 1>>("WG4 NB2 WPC2", n, 128, rounds, c4);
-        run_wg<WgCfg<40, 40, 12, 5, 3, 0, 0, 1>>("WG4 NB5 WPC3", n, 64, rounds, c4);
-        run_wg<WgCfg<40, 40, 12, 5, 2, 0, 0, 1>>("WG4 NB5 WPC2", n, 64, rounds, c4);
+        run_wg<WgCfg<40, 40, 12, 2, 2, 0>>("WG4 NB2 WPC2", n, 128, rounds, c4);
+        run_wg<WgCfg<40, 40, 12, 5, 3, 0>>("WG4 NB5 WPC3", n, 64, rounds, c4);
+        run_wg<WgCfg<40, 40, 12, 5, 2, 0>>("WG4 NB5 WPC2", n, 64, rounds, c4);
         run_wg<WG5>("WG5 (shipped)", n, 64, rounds, c5);
         run_wg<WG5>("WG5 (shipped)", n, 128, rounds, c5);
         run_wg<WG5>("WG5 (shipped)", n, 32, rounds, c5);
@@ -454,20 +453,16 @@ int main(int argc, char** argv) {
         run_wg<WG3>("WG3 (shipped)", n, 128, rounds, c3);
         run_wg<WG4>("WG4 (shipped)", n, 256, rounds, c4);
         run_wg<WG5>("WG5 (shipped)", n, 64, rounds, c5);
-        run_wg<WgCfg<20, 20, 30, 4, 3, 0, 0, 1>>("WG2 plain (X, dz from memory)", n, 64, rounds, c2);
-        run_wg<WgCfg<20, 20, 30, 4, 3, 1, 0, 1>>("WG2 conv1 recompute, dz from memory", n, 64, rounds, c2);
-        run_wg<WgCfg<20, 40, 14, 2, 3, 0, 0, 1>>("WG3 plain GP1", n, 128, rounds, c3);
-        run_wg<WgCfg<20, 40, 14, 2, 3, 0, 0, 2>>("WG3 plain GP2", n, 128, rounds, c3);
-        run_wg<WgCfg<20, 40, 14, 2, 3, 0, 1, 1>>("WG3 dz computed GP1", n, 128, rounds, c3);
-        run_wg<WgCfg<40, 40, 12, 1, 3, 0, 0, 1>>("WG4 plain", n, 256, rounds, c4);
-        run_wg<WgCfg<40, 40, 12, 2, 3, 0, 0, 2>>("WG4 plain NB2 GP2", n, 128, rounds, c4);
-        run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 1>>("WG5 plain GP1", n, 64, rounds, c5);
-        run_wg<WgCfg<40, 60, 5, 1, 3, 0, 0, 1>>("WG5 plain GP1 WPC3", n, 64, rounds, c5);
-        run_wg<WgCfg<40, 40, 12, 2, 3, 0, 0, 1>>("WG4 plain NB2 GP1", n, 128, rounds, c4);
-        run_wg<WgCfg<40, 40, 12, 2, 3, 0, 0, 1>>("WG4 plain NB2 GP1", n, 256, rounds, c4);
-        run_wg<WgCfg<40, 40, 12, 1, 3, 0, 0, 1>>("WG4 plain", n, 128, rounds, c4);
-        run_wg<WgCfg<40, 40, 12, 1, 2, 0, 0, 1>>("WG4 plain WPC2", n, 256, rounds, c4);
-        run_wg<WgCfg<40, 60, 5, 1, 2, 0, 0, 4>>("WG5 plain GP4", n, 64, rounds, c5);
+        run_wg<WgCfg<20, 20, 30, 4, 3, 0>>("WG2 plain (X, dz from memory)", n, 64, rounds, c2);
+        run_wg<WgCfg<20, 20, 30, 4, 3, 1>>("WG2 conv1 recompute, dz from memory", n, 64, rounds, c2);
+        run_wg<WgCfg<20, 40, 14, 2, 3, 0>>("WG3 plain GP1", n, 128, rounds, c3);
+        run_wg<WgCfg<40, 40, 12, 1, 3, 0>>("WG4 plain", n, 256, rounds, c4);
+        run_wg<WgCfg<40, 60, 5, 1, 2, 0>>("WG5 plain GP1", n, 64, rounds, c5);
+        run_wg<WgCfg<40, 60, 5, 1, 3, 0>>("WG5 plain GP1 WPC3", n, 64, rounds, c5);
+        run_wg<WgCfg<40, 40, 12, 2, 3, 0>>("WG4 plain NB2 GP1", n, 128, rounds, c4);
+        run_wg<WgCfg<40, 40, 12, 2, 3, 0>>("WG4 plain NB2 GP1", n, 256, rounds, c4);
+        run_wg<WgCfg<40, 40, 12, 1, 3, 0>>("WG4 plain", n, 128, rounds, c4);
+        run_wg<WgCfg<40, 40, 12, 1, 2, 0>>("WG4 plain WPC2", n, 256, rounds, c4);
     }
     return 0;
 }

@@ -1,0 +1,356 @@
+// The dense head of the training step as ONE launch (small batches): d1 x3 -> FC1 -> fc_2 -> out + softmax + cross-entropy ->
+// fc_2 / FC1 / d1 data gradients.  Replaces, for the batch sizes nolearn trains at, the seven dependent GEMM launches + the head
+// launch that scs_train.hip issues otherwise (DenseLayer nodes of /root/reference/cnn_cort/nets.py:179, 217, 227, 231 and their
+// Theano gradients): at batch 256 each of those is 144 workgroups that live for ONE global round trip and 80 MFMAs per wave -
+// 8 - 10 us as a launch of its own, about 1.5 us of work.
+//
+// The chain is row-local: rows [16 b, 16 b + 16) of every layer depend on the same rows of the layer before and on nothing else.
+// A CLUSTER of 9 workgroups owns one block of 16 rows; member j computes column block j (64 columns) of each layer - the tiling,
+// the 8-wave K split and the order of every sum are those of gemm_splitk4_kernel / head_train_kernel, so both forms of the step
+// give the same bits (tests/test_gpu_train.py).  Between layers the members exchange their columns through global memory and
+// meet at a cluster barrier.
+//
+// A hand-off between XCDs costs ~2 us per hop on this GPU (write-through store, memory-side atomic, device-scope load: measured,
+// profiles/r03_notes.txt - the chain then takes as long as the launches it replaces), one inside an XCD 0.7 - 0.9 us for the whole
+// barrier: the L2 of an XCD is shared by its CUs.  So a cluster is formed INSIDE one XCD, whatever the dispatcher does: a
+// workgroup reads the XCC_ID register, takes a ticket from THAT XCD's counter (an L2 atomic; only workgroups of this XCD ever
+// touch the line) and becomes member (ticket % 9) of this XCD's cluster (ticket / 9), which owns row block 8 * cluster + xcd.
+// With the round-robin dispatch of gfx942 / gfx950 every XCD receives grid / 8 workgroups = whole clusters.  Inside a cluster:
+//   * outputs are plain stores (the CU's L1 writes through to the XCD's L2); the storing waves drain them (vmcnt(0)) in front of
+//     the workgroup barrier behind which ONE lane adds its arrival to the cluster's counter - an L2 atomic - and polls it with
+//     returning L2 atomics (a load could be served by the CU's L1 for ever);
+//   * operands written by other members are loaded behind that barrier, for the first time in this launch by this CU, so the L1
+//     cannot hold them (it is invalid at kernel start); a 16-row block of every exchanged array is a whole number of 128-byte
+//     lines (row strides 540, 556, 272, 16 floats from 256-byte aligned bases), so no line is shared with another cluster;
+//   * the counters are zeroed by the prep launch at the start of every step.  A poll that does not complete within
+//     kChainSpinLimit rounds (an XCD that did not receive whole clusters) gives up, poisons the loss of its rows with NaN and lets
+//     the kernel end: wrong placement is loud, never silent.
+// The grid (72 x ceil(row blocks / 8) workgroups of 512 threads, at most kChainMaxBatch rows) is co-resident by size.
+//
+// What it buys (profiles/r03_chain_stamps.txt, r03_notes.txt): a tile costs 7.5 - 8 us in either form - 2.7 us until the first
+// wave has its operands (1.4 us when they are hot), 3.5 us until the last wave is through its 80 MFMAs (two waves share a SIMD's
+// matrix pipe: 2.4 us is the floor of a 16 x 64 x 540 tile on one CU), 1 us reduction + stores, 0.9 us drain + barrier against
+// 2 - 3 us between dependent launches.  At batch 128 the step gains 1.5 % (0.467 against 0.475 ms), at 256 it loses 0.5 %; the
+// default bound is therefore 128.  Prefetching the weights - from the matrix waves, from extra waves, from spare workgroups on
+// the idle CUs - did not move the operand phase and is not kept.
+#pragma once
+#include "gemm_mfma.h"
+
+namespace scs {
+
+constexpr int kChainMembers = 9;                 // column blocks of 64 of a 540-wide layer = workgroups per cluster
+constexpr int kChainMaxBatch = 384;              // 24 clusters = 216 workgroups <= 256 CUs
+constexpr int kChainDefaultMaxBatch = 128;       // the step takes this form up to here unless SCS_DENSE_CHAIN_MAX_BATCH says otherwise
+constexpr int kChainLine = 32;                   // counter stride in words: one 128-byte line per counter
+constexpr int kXcds = 8;
+constexpr int kChainClustersPerXcd = (kChainMaxBatch / 16 + kXcds - 1) / kXcds;
+constexpr int kChainCounterWords = kXcds * (1 + kChainClustersPerXcd) * kChainLine;   // per XCD: ticket line, then one barrier line per cluster
+constexpr unsigned int kChainSpinLimit = 1u << 20;
+
+struct DenseChainArgs {
+    GemmProblem d1[kTowers], fc1, fc2;           // forward problems (as scs_train.hip hands them to gemm_launch)
+    GemmProblem dcat, dfeat, dh5[kTowers];       // data-gradient problems
+    const float* outW; const float* outb;        // out layer [270][15], [15]
+    const uint8_t* y;                            // batch labels
+    float* probs; float* dlog; float* loss_rows; // [n][16], [n][16], [n]
+    float* R2; float* dR2;                       // [n][kFC2ld]
+    unsigned int* counters;                      // kChainCounterWords, zero at launch
+    unsigned long long* stamps;                  // diagnostic (SCS_CHAIN_STAMPS): kChainStamps 100 MHz time stamps per workgroup, or null
+    int n;
+};
+constexpr int kChainStamps = 64;
+struct ChainStamper {
+    unsigned long long* p; int i;
+    __device__ __forceinline__ void seek(int to) { i = to; }
+    __device__ __forceinline__ void hit() { if (p && threadIdx.x == 0) { p[i] = __builtin_amdgcn_s_memrealtime(); ++i; } }
+    __device__ __forceinline__ void drained() { if (p) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); hit(); } }
+};
+
+// XCC_ID of the XCD this wave runs on (hardware register 20, bits 3:0)
+__device__ __forceinline__ int xcc_id() { return (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15; }
+
+// L2 atomics of one XCD (no device scope: they execute in the XCD's L2 and are coherent for the workgroups of that XCD)
+__device__ __forceinline__ unsigned int l2_add(unsigned int* p, unsigned int v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned int l2_read(unsigned int* p) {        // a compare-and-swap that never swaps: the current value, from L2
+    unsigned int expected = 0xFFFFFFFFu;
+    __hip_atomic_compare_exchange_strong(p, &expected, 0xFFFFFFFFu, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expected;
+}
+
+// Arrival of this workgroup at barrier number `round` (1-based) of its cluster, then wait for all kChainMembers.
+// Returns false in every thread when the wait gave up.
+// ROLE of a wave: 0 = waves 0..3 (matrix work, reduction, stores - they drain their stores here), 1 = waves 4..7 (matrix work
+// only).  Both roles execute the same workgroup barriers in the same order.
+template <int ROLE>
+__device__ __forceinline__ bool chain_barrier(unsigned int* ctr, unsigned int round, volatile int* s_flag, ChainStamper& ts) {
+    if (ROLE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are in the XCD's L2
+    __syncthreads();
+    ts.hit();                                                   // [4] stores drained, workgroup together
+    if (threadIdx.x == 0) {
+        const unsigned int target = round * kChainMembers;
+        unsigned int seen = l2_add(ctr, 1u) + 1u;
+        unsigned int spins = 0;
+        while (seen < target && spins < kChainSpinLimit) {
+            __builtin_amdgcn_s_sleep(1);
+            seen = l2_read(ctr);
+            ++spins;
+        }
+        *s_flag = seen >= target ? 1 : 0;
+    }
+    __syncthreads();
+    ts.hit();                                                   // [5] cluster together
+    return *s_flag != 0;
+}
+
+// One 16 x 64 output tile of C = epilogue(A W + b): gemm_splitk4_kernel's arithmetic (same K split over the 8 matrix waves, same
+// order of sums).  Straight-line loads from clamped (always valid) addresses; what lies outside the problem becomes zero by
+// select.  s_r: 8 * 4 * 64 f32x4 of LDS.
+template <int ROLE>
+__device__ __forceinline__ void chain_tile(const GemmProblem& P, int M, int K4, int K, int N, int relu, int m0, int n0,
+                                           f32x4* s_r, ChainStamper& ts) {
+    ts.hit();                                                   // [0] tile start
+    using T = GemmSplitK4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int ecol = n0 + 4 * lr + wave;
+    f32x4 acc[4];
+    float e_bias_raw = 0.f, e_gate[4] = {1.f, 1.f, 1.f, 1.f};
+    unsigned char e_mask[4] = {1, 1, 1, 1};
+    {
+        const int kmax = K ? K : K4;
+        const int groups = (K4 + 15) / 16, per = (groups + T::NW - 1) / T::NW;  // per <= GMAX: K4 <= 640 (checked on the host)
+        const int g_beg = min(groups, wave * per), g_end = min(groups, g_beg + per);
+        const int row = m0 + lr;
+        const bool row_ok = row < M;
+        const float* arow = P.A + (size_t)(row_ok ? row : 0) * P.lda;
+        const bool col_ok = n0 + 4 * lr < P.NS;
+        const float* __restrict__ wcol = P.W + min(n0 + 4 * lr, P.NS - 4);
+        float4 av[T::GMAX], wv[T::GMAX][4];
+#pragma unroll
+        for (int u = 0; u < T::GMAX; ++u) {
+            const bool on = (g_beg + u) < g_end;
+            const int k = on ? 16 * (g_beg + u) + 4 * kq : 0;   // a group this wave does not own: rows 0..3 (cached)
+            av[u] = *reinterpret_cast<const float4*>(arow + (k < K4 ? k : 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[u][i] = *reinterpret_cast<const float4*>(wcol + (size_t)min(k + i, kmax - 1) * P.NS);
+        }
+        if (ROLE == 0) {
+            // bias, dropout mask and ReLU gate of the outputs this wave will store, requested with the operands (absent operands:
+            // a load from a valid address whose value is ignored - a branch here would serialise the loads)
+            const int ecl = min(ecol, N - 1);
+            const float* __restrict__ bp = P.bias ? P.bias + ecl : P.W;
+            const unsigned char* __restrict__ mp = P.mask ? P.mask + ecl : reinterpret_cast<const unsigned char*>(P.W);
+            const float* gp = P.gate ? P.gate + ecl : P.W;
+            const int ldm = P.mask ? P.ldm : 0, ldg = P.gate ? P.ldg : 0;
+            e_bias_raw = *bp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = min(m0 + kq * 4 + r, M - 1);
+                e_mask[r] = mp[(size_t)orow * ldm];
+                e_gate[r] = gp[(size_t)orow * ldg];
+            }
+        }
+        ts.drained();                                           // [1] operands have arrived (diagnostic runs only)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < T::GMAX; ++u) {
+            const bool on = (g_beg + u) < g_end;
+            const int k = 16 * (g_beg + u) + 4 * kq;
+            const float4 a = (on && row_ok && k < K4) ? av[u] : zero4;
+            const float a4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 w = (on && col_ok && k + i < kmax) ? wv[u][i] : zero4;
+                const float w4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], w4[j], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                            // s_r may still be read by the previous tile's epilogue
+    ts.hit();                                                   // [2] matrix work done in every wave
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_r[(wave * 4 + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (ROLE == 0) {
+        const int j = wave;
+        f32x4 v = s_r[(0 * 4 + j) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < T::NW; ++q) { const f32x4 u = s_r[(q * 4 + j) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        if (ecol < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = m0 + kq * 4 + r;
+                if (orow < M) {
+                    float x = v[r] + (P.bias ? e_bias_raw : 0.f);
+                    if (relu) x = fmaxf(x, 0.f);
+                    if (P.C2) {
+                        P.C[(size_t)orow * P.ldc + ecol] = x;
+                        P.C2[(size_t)orow * P.ldc2 + ecol] = e_mask[r] ? 2.f * x : 0.f;
+                    } else {
+                        if (P.mask) x = e_mask[r] ? 2.f * x : 0.f;
+                        if (P.gate) x = e_gate[r] > 0.f ? x : 0.f;
+                        P.C[(size_t)orow * P.ldc + ecol] = x;
+                    }
+                }
+            }
+        }
+    }
+    ts.hit();                                                   // [3] outputs issued
+}
+
+// head_train_kernel's body for rows [row0, row0 + 16) inside the chain's workgroup:
+// logits on waves 0..3 (the K split and the order of the partial sums of the stand-alone kernel), softmax on threads 0..255,
+// dR2's 17 column tiles over the 8 matrix waves.
+// R2 was written by other members of the cluster, dR2 is read by them.
+__device__ __forceinline__ void chain_head(const DenseChainArgs& a, int row0, f32x4* s_r, float (*s_d)[17]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int n = a.n;
+    __syncthreads();                                            // s_r: the previous tile's epilogue is done with it
+    if (wave < 4) {
+        constexpr int SPW = 17;
+        const int arow = min(row0 + lr, n - 1);
+        const float* ap = a.R2 + (size_t)arow * kFC2ld + kq;
+        float av[SPW], bv[SPW];
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+            const int k = 4 * (wave * SPW + i) + kq;
+            av[i] = k < kFC2 ? ap[4 * (wave * SPW + i)] : 0.f;
+            bv[i] = (k < kFC2 && lr < 15) ? a.outW[k * 15 + lr] : 0.f;
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+        s_r[wave * 64 + lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const int r = tid >> 4, c = tid & 15;
+        const int row = row0 + r;
+        const int src = (r >> 2) * 16 + c;
+        const float z = (c < 15 ? a.outb[c] : 0.f) + ((s_r[0 * 64 + src][r & 3] + s_r[1 * 64 + src][r & 3]) + (s_r[2 * 64 + src][r & 3] + s_r[3 * 64 + src][r & 3]));
+        float mx = c < 15 ? z : -3.0e38f;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = c < 15 ? expf(z - mx) : 0.f;
+        float sum = e;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float pr = e / sum;
+        const int yi = row < n ? a.y[row] : 0;
+        const float dl = (c < 15 && row < n) ? (pr - (c == yi ? 1.f : 0.f)) / (float)n : 0.f;
+        s_d[r][c] = dl;
+        if (row < n) {
+            a.probs[(size_t)row * 16 + c] = c < 15 ? pr : 0.f;
+            a.dlog[(size_t)row * 16 + c] = dl;
+            if (c == yi) a.loss_rows[row] = -(z - mx - logf(sum));
+        }
+    }
+    __syncthreads();
+    {
+        float a4[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) a4[s4] = s_d[lr][4 * s4 + kq];
+        for (int t = wave; t < 17; t += 8) {
+            const int col = 16 * t + lr;
+            float w4[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { const int cl = 4 * s4 + kq; w4[s4] = (col < kFC2 && cl < 15) ? a.outW[col * 15 + cl] : 0.f; }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], w4[s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int orow = row0 + 4 * kq + i;
+                if (orow < n) {
+                    const float gate = col < kFC2 ? a.R2[(size_t)orow * kFC2ld + col] : 0.f;
+                    a.dR2[(size_t)orow * kFC2ld + col] = gate > 0.f ? acc[i] : 0.f;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // waves 4..7 stored too, and the barrier drains waves 0..3 only
+    }
+}
+
+// The chain as a wave of role ROLE executes it: the same tiles and the same workgroup barriers in the same order.
+template <int ROLE>
+__device__ __forceinline__ void chain_body(const DenseChainArgs& a, int j, int m0, unsigned int* ctr, f32x4* s_r, float (*s_d)[17],
+                                           volatile int* s_flag, ChainStamper& ts) {
+    const int n = a.n, n0 = j * GemmSplitK4::BN;
+    bool ok = true;
+    // d1 x3: member j = (tower j / 3, column block j % 3); H5 comes from the launch before
+    const int t1 = j / 3, n1 = (j - 3 * t1) * GemmSplitK4::BN;
+    const GemmProblem P1 = t1 == 0 ? a.d1[0] : (t1 == 1 ? a.d1[1] : a.d1[2]);
+    chain_tile<ROLE>(P1, n, kFlat, kFlat, kD1, 1, m0, n1, s_r, ts);
+    ok = chain_barrier<ROLE>(ctr, 1, s_flag, ts);
+    ts.seek(8);
+    if (ok) {                                                   // FC1 (K = 540 features of the three towers)
+        chain_tile<ROLE>(a.fc1, n, kFC1, kFC1, kFC1, 1, m0, n0, s_r, ts);
+        ok = chain_barrier<ROLE>(ctr, 2, s_flag, ts);
+    }
+    ts.seek(16);
+    if (ok) {                                                   // fc_2 on [FC1 | atlas]: 5 column blocks
+        if (n0 < kFC2) chain_tile<ROLE>(a.fc2, n, kFC1ld, kFC1 + kAtlas, kFC2, 1, m0, n0, s_r, ts);
+        ok = chain_barrier<ROLE>(ctr, 3, s_flag, ts);
+    }
+    ts.seek(24);
+    if (ok) {
+        if (j == 0) chain_head(a, m0, s_r, s_d);
+        ok = chain_barrier<ROLE>(ctr, 4, s_flag, ts);
+    }
+    ts.seek(32);
+    if (ok) {
+        chain_tile<ROLE>(a.dcat, n, kFC2ld, kFC2, kFC1, 0, m0, n0, s_r, ts);
+        ok = chain_barrier<ROLE>(ctr, 5, s_flag, ts);
+    }
+    ts.seek(40);
+    if (ok) {
+        chain_tile<ROLE>(a.dfeat, n, kFC1, kFC1, kFlat, 0, m0, n0, s_r, ts);
+        ok = chain_barrier<ROLE>(ctr, 6, s_flag, ts);
+    }
+    ts.seek(48);
+    if (ok) {                                                   // d1 x3 data gradients: three tiles per member
+        chain_tile<ROLE>(a.dh5[0], n, kD1, kD1, kFlat, 0, m0, n0, s_r, ts);
+        chain_tile<ROLE>(a.dh5[1], n, kD1, kD1, kFlat, 0, m0, n0, s_r, ts);
+        chain_tile<ROLE>(a.dh5[2], n, kD1, kD1, kFlat, 0, m0, n0, s_r, ts);
+    }
+    if (!ok && threadIdx.x == 0) a.loss_rows[m0] = __builtin_nanf("");   // a barrier gave up: the step's loss says so
+}
+
+__global__ __launch_bounds__(512, 1) void dense_chain_kernel(DenseChainArgs a) {
+    __shared__ f32x4 s_r[GemmSplitK4::NW * 4 * 64];
+    __shared__ float s_d[16][17];
+    __shared__ int s_flag;
+    const int n = a.n, nblocks = (n + 15) / 16;
+    const unsigned long long t_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // membership: a ticket from the counter of the XCD this workgroup runs on
+    const int xcd = __builtin_amdgcn_readfirstlane(xcc_id() & (kXcds - 1));
+    unsigned int* const xbase = a.counters + (size_t)xcd * (1 + kChainClustersPerXcd) * kChainLine;
+    if (threadIdx.x == 0) s_flag = (int)l2_add(xbase, 1u);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(s_flag);   // wave-uniform: member, row block and column block live in SGPRs
+    __syncthreads();                                            // s_flag is reused by the barriers
+    const int cluster = ticket / kChainMembers, j = ticket - cluster * kChainMembers;
+    const int block = cluster * kXcds + xcd;
+    if (cluster >= kChainClustersPerXcd || block >= nblocks) return;   // a whole cluster leaves together
+    const int m0 = block * 16;
+    unsigned int* ctr = xbase + (size_t)(1 + cluster) * kChainLine;
+    ChainStamper ts{a.stamps ? a.stamps + (size_t)(block * kChainMembers + j) * kChainStamps : nullptr, 0};
+    if (ts.p && threadIdx.x == 0) { ts.p[62] = t_start; ts.p[63] = __builtin_amdgcn_s_memrealtime(); }
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave < 4) chain_body<0>(a, j, m0, ctr, s_r, s_d, &s_flag, ts);
+    else chain_body<1>(a, j, m0, ctr, s_r, s_d, &s_flag, ts);
+}
+
+inline dim3 dense_chain_grid(int n) { return dim3(kXcds * kChainMembers * (((n + 15) / 16 + kXcds - 1) / kXcds)); }
+
+inline bool dense_chain_ok(int n, const GemmArgs& probe, int nproblems) { return n > 0 && n <= kChainMaxBatch && gemm_vec4_ok(probe, nproblems); }
+
+}  // namespace scs

@@ -29,6 +29,7 @@
 
 #include "conv_mfma.h"
 #include "gemm_mfma.h"
+#include "dense_chain.h"
 #include "scs_ctx.h"
 #include "wgrad_mfma.h"
 #include "train_cfg.h"
@@ -38,13 +39,14 @@ namespace scs {
 // profiling stages of scs_train_step_profiled (one per launch)
 enum Stage { ST_PREP, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
              ST_FC2, ST_HEAD, ST_DCAT, ST_DFEAT, ST_DH5, ST_BN5B, ST_DG5, ST_FINB4, ST_DG4, ST_FINB3, ST_DG3, ST_FINB2, ST_DG2,
-             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_COUNT };
+             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_CHAIN, ST_COUNT };
 static const char* const kStageNames[ST_COUNT] = {
     "prep (weight packs, dropout masks, atlas columns) + input moments", "bn1 finalize", "conv1+conv2 fwd", "bn2 finalize",
     "conv3 fwd", "bn3 finalize", "conv4 fwd", "bn4 finalize", "conv5 fwd", "bn5 + dropout", "d1 x3 fwd", "FC1 fwd", "fc_2 fwd",
     "out + softmax + CE", "fc_2 dgrad", "FC1 dgrad", "d1 x3 dgrad", "bn5 backward", "conv5 dgrad", "bn4 bwd finalize", "conv4 dgrad",
     "bn3 bwd finalize", "conv3 dgrad", "bn2 bwd finalize", "conv2 dgrad + layer-1 sums", "layer-1 gradients", "dense wgrad (grouped)",
-    "conv5 wgrad", "conv4 wgrad", "conv3 wgrad", "conv2 wgrad", "conv3..5 wgrad reduce", "conv2 wgrad reduce"};
+    "conv5 wgrad", "conv4 wgrad", "conv3 wgrad", "conv2 wgrad", "conv3..5 wgrad reduce", "conv2 wgrad reduce",
+    "dense head, one launch (d1 x3, FC1, fc_2, out + softmax + CE, fc_2 / FC1 / d1 dgrad)"};
 
 }  // namespace scs
 
@@ -84,6 +86,8 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     double* mom = nullptr;                     // [3][100] R (9x9), S (column 9), count
     bool tickets_dirty = false;                // a step failed between launches: the tickets are zeroed before the next one
     double* fin_grp = nullptr;                 // group records of the in-kernel finalize steps (inside `base`)
+    unsigned long long* chain_stamps = nullptr; // diagnostic time stamps of dense_chain_kernel (SCS_CHAIN_STAMPS)
+    unsigned int* chain_counter = nullptr;     // cluster barriers of dense_chain_kernel (inside `base`; zeroed by the prep launch)
     unsigned int* fin_counter = nullptr;       // arrival tickets of the in-kernel finalize steps (inside `base`; zero between launches)
     float* wg_part = nullptr;                  // [4 layers][3][kWgPartFloats] partial weight gradients
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
@@ -100,6 +104,9 @@ namespace scs {
 
 static size_t al64(size_t f) { return (f + 63) / 64 * 64; }
 constexpr int kW2Floats = kFC1ld * kFC2ld;              // fc_2.W padded to [556][272] (16-byte rows for the float4 GEMM)
+// Leading dimension of the transposed dense weights: 544 floats = 17 lines of 128 bytes, so that the 64-column slice a GEMM
+// workgroup reads of a row is exactly two lines (with 540 it straddles three).  No measurable effect on the kernels' times.
+constexpr int kTld = 544;
 
 void train_free(scs_ctx* h) {
     if (!h->tws) return;
@@ -146,7 +153,8 @@ static int train_ensure(scs_ctx* h, int n) {
         for (int t = 0; t < kTowers; ++t)
             for (int i = 1; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
-        SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * 540 + 540 * 540 + 3 * 180 * 540 + kW2Floats) * sizeof(float)));
+        SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats) * sizeof(float)));
+        SCS_HIP(hipMemset(w->wT, 0, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats) * sizeof(float)));   // pad columns stay zero
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)4 * kTowers * kWgPartFloats * sizeof(float)));
         SCS_HIP(hipMalloc(&w->mom, (size_t)kTowers * 100 * sizeof(double)));
         // coefficient tables: per tower and conv layer 64 x (float2 + float4 + float4), then the conv1 tables
@@ -196,7 +204,8 @@ static int train_ensure(scs_ctx* h, int n) {
                  o_sp = take((size_t)kTowers * c * 8 * 64 * 2),     // up to 8 bands x 64 channels x 2 sums
                  o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * std::max<size_t>(256, (c + kMomentPpb - 1) / kMomentPpb) * 128),
                  o_fc = take(kTowers * fin_counter_words(c)),                 // one workgroup per patch in the FIN configurations
-                 o_fg = take(kTowers * fin_groups(c) * kFinRec * 2 * 2);      // group records (doubles)
+                 o_fg = take(kTowers * fin_groups(c) * kFinRec * 2 * 2),      // group records (doubles)
+                 o_cc = take((size_t)kChainCounterWords);
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
     for (int t = 0; t < kTowers; ++t) {
@@ -212,6 +221,7 @@ static int train_ensure(scs_ctx* h, int n) {
     w->stat_part = w->base + o_sp; w->l1_part = w->base + o_l1; w->mom_part = w->base + o_mp;
     w->fin_counter = reinterpret_cast<unsigned int*>(w->base + o_fc);
     w->fin_grp = reinterpret_cast<double*>(w->base + o_fg);
+    w->chain_counter = reinterpret_cast<unsigned int*>(w->base + o_cc);
     SCS_HIP(hipMalloc(&w->masks, c * kFlat * 5 + c));
     w->yb = w->masks + c * kFlat * 5;
     w->cap = (int)c;
@@ -228,6 +238,7 @@ struct PrepArgs {
     const float* atlas; const uint8_t* y; const int32_t* index; float* cat2; uint8_t* yb; int n, n_rows;   // n_rows: rows atlas / y hold
     uint8_t* masks; size_t mask_total; uint64_t seed;       // masks == null: the caller supplied them
     const float* fc2W; float* w2p;                           // fc_2.W [555][270] -> [556][272] zero padded
+    unsigned int* chain_counter;                             // cluster barrier counters of the dense chain: zeroed here
 };
 
 // blockIdx.y selects the job:
@@ -282,6 +293,7 @@ __device__ __forceinline__ void prep_body(const PrepArgs& a, int job) {
             a.cat2[(size_t)row * kFC1ld + kFC1 + c] = c < 15 ? a.atlas[(size_t)src * 15 + c] : 0.f;
             if (c == 0) a.yb[row] = a.y[src];
         }
+        for (int e = t0; e < kChainCounterWords; e += stride) a.chain_counter[e] = 0u;
         for (int e = t0; e < kW2Floats; e += stride) {
             const int k = e / kFC2ld, c = e - k * kFC2ld;
             a.w2p[e] = (k < kFC1 + kAtlas && c < kFC2) ? a.fc2W[(size_t)k * kFC2 + c] : 0.f;
@@ -851,22 +863,22 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     const uint8_t* mask5 = masks;                                  // [3][n][540]
     const uint8_t* mask1 = masks + (size_t)3 * n * kFlat;          // f1_drop [n][540]
     const uint8_t* mask2 = mask1 + (size_t)n * kFlat;              // f2_drop [n][540]
-    float* wT2 = w->wT;                       // [270][540]  = fc_2.W[:540]^T
-    float* wT1 = wT2 + 270 * 540;             // [540][540]  = FC1.W^T
-    float* wTd = wT1 + 540 * 540;             // [3][180][540] = d1.W^T
-    float* w2p = wTd + 3 * 180 * 540;         // [556][272]  = fc_2.W zero padded
+    float* wT2 = w->wT;                       // [270][544]  = fc_2.W[:540]^T
+    float* wT1 = wT2 + 270 * kTld;            // [540][544]  = FC1.W^T
+    float* wTd = wT1 + 540 * kTld;            // [3][180][544] = d1.W^T
+    float* w2p = wTd + 3 * 180 * kTld;        // [556][272]  = fc_2.W zero padded
     {
         PrepArgs pa{};
         for (int t = 0; t < kTowers; ++t) {
             const TowerOff T = tower_off(t * kTowerFloats);
             for (int i = 1; i < kConvs; ++i) pa.pack[t * (kConvs - 1) + i - 1] = PackJob{P + T.convW[i], w->wpk[t][i], w->wdg[t][i], kCin[i], kCout[i]};
-            pa.tr[2 + t] = TrProblem{P + T.d1W, kD1, wTd + t * kD1 * kFlat, kFlat, kFlat, kD1};
+            pa.tr[2 + t] = TrProblem{P + T.d1W, kD1, wTd + t * kD1 * kTld, kTld, kFlat, kD1};
         }
-        pa.tr[0] = TrProblem{P + H.fc2W, kFC2, wT2, kFC1, kFC1, kFC2};
-        pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kFlat, kFlat, kFC1};
+        pa.tr[0] = TrProblem{P + H.fc2W, kFC2, wT2, kTld, kFC1, kFC2};
+        pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kTld, kFlat, kFC1};
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
         pa.n_rows = index ? x0.n_samples : n;
-        pa.fc2W = P + H.fc2W; pa.w2p = w2p;
+        pa.fc2W = P + H.fc2W; pa.w2p = w2p; pa.chain_counter = w->chain_counter;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
         // ---- forward, training mode: the input moments ride in the same launch
         run(ST_PREP, st, [&] {
@@ -926,17 +938,30 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         g.p[t] = GemmProblem{w->H5[t], kFlat, P + T.d1W, kD1, P + T.d1b, w->feat + t * kD1, kFlat,
                              mask1 + t * kD1, kFlat, nullptr, 0, w->featd + t * kD1, kFlat};
     }
-    run(ST_D1, st, [&] { gemm_launch(g, kTowers, st); });
+    // Small batches: the whole dense head - these three layers, the out layer with its loss, and the three data-gradient
+    // layers below - is ONE launch of 9-workgroup clusters (dense_chain.h; same tiles, same sums, same bits); otherwise one
+    // launch per layer.  SCS_DENSE_CHAIN_MAX_BATCH overrides the bound (0: never; tests run both forms at one batch size);
+    // SCS_CHAIN_STAMPS prints the one-launch form's per-tile phase times to stderr (diagnostic, synchronises).
+    const char* chain_env = getenv("SCS_DENSE_CHAIN_MAX_BATCH");
+    const int chain_max = chain_env ? std::min(atoi(chain_env), kChainMaxBatch) : kChainDefaultMaxBatch;
+    DenseChainArgs ch{};
+    for (int t = 0; t < kTowers; ++t) ch.d1[t] = g.p[t];
+    const bool chain = n <= chain_max && dense_chain_ok(n, g, kTowers);
+    if (!chain) run(ST_D1, st, [&] { gemm_launch(g, kTowers, st); });
     g.K4 = kFC1; g.K = kFC1; g.N = kFC1;
     g.p[0] = GemmProblem{w->featd, kFlat, P + H.fc1W, kFC1, P + H.fc1b, w->R1, kFC1, mask2, kFC1, nullptr, 0, w->cat2, kFC1ld};
-    run(ST_FC1, st, [&] { gemm_launch(g, 1, st); });                    // R1 = relu(.), cat2[:, :540] = f2_drop(R1)
+    ch.fc1 = g.p[0];
+    if (!chain) run(ST_FC1, st, [&] { gemm_launch(g, 1, st); });        // R1 = relu(.), cat2[:, :540] = f2_drop(R1)
     g.K4 = kFC1ld; g.K = kFC1 + kAtlas; g.N = kFC2;
     g.p[0] = GemmProblem{w->cat2, kFC1ld, w2p, kFC2ld, P + H.fc2b, w->R2, kFC2ld};
-    run(ST_FC2, st, [&] { gemm_launch(g, 1, st); });
-    run(ST_HEAD, st, [&] {
-        hipLaunchKernelGGL(head_train_kernel, dim3((n + 15) / 16), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,
-                           w->loss_rows, w->dR2);
-    });
+    ch.fc2 = g.p[0];
+    if (!chain) {
+        run(ST_FC2, st, [&] { gemm_launch(g, 1, st); });
+        run(ST_HEAD, st, [&] {
+            hipLaunchKernelGGL(head_train_kernel, dim3((n + 15) / 16), dim3(256), 0, st, w->R2, P + H.outW, P + H.outb, w->yb, n, w->probs, w->dlog,
+                               w->loss_rows, w->dR2);
+        });
+    }
 
     // ---- backward: dense head.  d logits and dR2 (through fc_2's ReLU) came out of head_train_kernel's pass.  Data
     // gradients stay on the caller's stream (st); every dense weight / bias gradient is one grouped launch on the side
@@ -944,11 +969,50 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     GemmArgs bg{};
     bg.relu = 0;
     bg.M = n; bg.K4 = kFC2ld; bg.K = kFC2; bg.N = kFC1;
-    bg.p[0] = GemmProblem{w->dR2, kFC2ld, wT2, kFC1, nullptr, w->dcat, kFC1, mask2, kFC1, w->R1, kFC1, nullptr, 0};
-    run(ST_DCAT, st, [&] { gemm_launch(bg, 1, st); });                  // through f2_drop and FC1's ReLU in the epilogue
+    bg.p[0] = GemmProblem{w->dR2, kFC2ld, wT2, kTld, nullptr, w->dcat, kFC1, mask2, kFC1, w->R1, kFC1, nullptr, 0};
+    ch.dcat = bg.p[0];
+    if (!chain) run(ST_DCAT, st, [&] { gemm_launch(bg, 1, st); });      // through f2_drop and FC1's ReLU in the epilogue
     bg.M = n; bg.K4 = kFC1; bg.K = kFC1; bg.N = kFlat;
-    bg.p[0] = GemmProblem{w->dcat, kFC1, wT1, kFlat, nullptr, w->dfeat, kFlat, mask1, kFlat, w->feat, kFlat, nullptr, 0};
-    run(ST_DFEAT, st, [&] { gemm_launch(bg, 1, st); });                 // through f1_drop and the d1 ReLUs in the epilogue
+    bg.p[0] = GemmProblem{w->dcat, kFC1, wT1, kTld, nullptr, w->dfeat, kFlat, mask1, kFlat, w->feat, kFlat, nullptr, 0};
+    ch.dfeat = bg.p[0];
+    if (!chain) run(ST_DFEAT, st, [&] { gemm_launch(bg, 1, st); });     // through f1_drop and the d1 ReLUs in the epilogue
+    if (chain) {
+        for (int t = 0; t < kTowers; ++t)
+            ch.dh5[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kTld, kTld, nullptr, w->dH5[t], kFlat,
+                                    mask5 + (size_t)t * n * kFlat, kFlat, nullptr, 0, nullptr, 0};
+        ch.outW = P + H.outW; ch.outb = P + H.outb; ch.y = w->yb; ch.probs = w->probs; ch.dlog = w->dlog; ch.loss_rows = w->loss_rows;
+        ch.R2 = w->R2; ch.dR2 = w->dR2; ch.counters = w->chain_counter; ch.n = n;
+        static const bool stamps_on = getenv("SCS_CHAIN_STAMPS") != nullptr;
+        if (stamps_on && !w->chain_stamps) {
+            SCS_HIP(hipMalloc(&w->chain_stamps, (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps * sizeof(unsigned long long)));
+        }
+        ch.stamps = stamps_on ? w->chain_stamps : nullptr;
+        if (stamps_on) SCS_HIP(hipMemsetAsync(w->chain_stamps, 0, (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps * sizeof(unsigned long long), st));
+        run(ST_CHAIN, st, [&] { hipLaunchKernelGGL(dense_chain_kernel, dense_chain_grid(n), dim3(512), 0, st, ch); });
+        if (stamps_on) {                                                // diagnostic: where the chain's time goes, per stage (stderr)
+            SCS_HIP(hipStreamSynchronize(st));
+            const int wgs = ((n + 15) / 16) * kChainMembers;
+            std::vector<unsigned long long> hs((size_t)wgs * kChainStamps);
+            SCS_HIP(hipMemcpy(hs.data(), w->chain_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int g2 = 0; g2 < wgs; ++g2) { t0 = std::min(t0, hs[(size_t)g2 * kChainStamps + 62]); for (int i = 0; i < kChainStamps; ++i) t1 = std::max(t1, hs[(size_t)g2 * kChainStamps + i]); }
+            fprintf(stderr, "dense chain, n = %d, %d workgroups: span %.2f us (first start to last stamp)\n", n, wgs, (double)(t1 - t0) * 0.01);
+            static const char* const kNames[7] = {"d1", "FC1", "fc_2", "head", "dcat", "dfeat", "dH5[0]"};
+            for (int sidx = 0; sidx < 7; ++sidx) {
+                double d[6] = {0, 0, 0, 0, 0, 0}, at0 = 0, at5 = 0; int cnt = 0;
+                for (int g2 = 0; g2 < wgs; ++g2) {
+                    const unsigned long long* q = hs.data() + (size_t)g2 * kChainStamps + 8 * sidx;
+                    const int last = sidx == 6 ? 3 : 5;
+                    bool full = true; for (int i = 0; i <= last; ++i) full = full && q[i] != 0;
+                    if (!full) continue;
+                    for (int i = 1; i <= last; ++i) d[i] += (double)(q[i] - q[i - 1]) * 0.01;
+                    at0 += (double)(q[0] - t0) * 0.01; at5 += (double)(q[last] - t0) * 0.01; ++cnt;
+                }
+                if (cnt) fprintf(stderr, "  %-7s (%3d wgs) starts %6.2f ends %6.2f us | operands %5.2f  matrix %5.2f  reduce+store %5.2f  drain %5.2f  barrier %5.2f\n",
+                                 kNames[sidx], cnt, at0 / cnt, at5 / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt);
+            }
+        }
+    }
     fork();                                                             // dlog, dR2, dcat, dfeat are final for sd
     {
         WgGroupArgs wg{};
@@ -965,9 +1029,9 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     }
     bg.M = n; bg.K4 = kD1; bg.K = kD1; bg.N = kFlat;
     for (int t = 0; t < kTowers; ++t)         // through the dropout in front of d1 (mask5 of the tower) in the epilogue
-        bg.p[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kFlat, kFlat, nullptr, w->dH5[t], kFlat,
+        bg.p[t] = GemmProblem{w->dfeat + t * kD1, kFlat, wTd + t * kD1 * kTld, kTld, nullptr, w->dH5[t], kFlat,
                               mask5 + (size_t)t * n * kFlat, kFlat, nullptr, 0, nullptr, 0};
-    run(ST_DH5, st, [&] { gemm_launch(bg, kTowers, st); });
+    if (!chain) run(ST_DH5, st, [&] { gemm_launch(bg, kTowers, st); });
 
     // ---- backward: conv blocks 5..2.  Per layer i: BN-backward coefficients from the partial sums (left by the data
     // gradient of layer i+1, or computed directly for the 3x3 planes of conv5), then the data-gradient kernel of layer i

@@ -406,6 +406,34 @@ def test_training_step_with_the_finalize_as_its_own_launch(fresh, weights, monke
     print('finalize launches: worst relative gradient error %.3g; %r' % (worst, forced))
 
 
+@pytest.mark.parametrize('n', [1, 16, 37, 128, 256, 257, 384])
+def test_dense_head_as_one_launch_gives_the_bits_of_the_layer_launches(weights, monkeypatch, n):
+    """Up to batch 256 the dense head of the step (d1 x3 .. out + loss .. d1 data gradients) is one launch of 9-workgroup
+    clusters that meet at device-scope barriers (csrc/dense_chain.h), beyond that one launch per layer.  Both forms use the same
+    tiles and the same order of sums: three steps through each (same draws, same dropout seeds, Adam applied) must leave the
+    same parameter arena, gradient arena and losses, bit for bit - at sizes with ragged row blocks too, and at 384 (the largest
+    batch the one-launch form accepts, forced)."""
+    from cnn_cort import synth, _hip
+    out = {}
+    for form, bound in (('layers', '0'), ('chain', '384')):
+        monkeypatch.setenv('SCS_DENSE_CHAIN_MAX_BATCH', bound)
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        st = torch.cuda.current_stream().cuda_stream
+        losses = []
+        for step in range(3):
+            ax, co, sa, at = synth.patch_batch(n, seed=700 + n + step)
+            y = np.random.RandomState(n + step).randint(0, 15, n).astype(np.uint8)
+            losses.append(h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=11 + step, stream=st))
+            h.adam_apply(stream=st)
+        torch.cuda.synchronize()
+        out[form] = (np.array(losses), arena(h, 'grad').copy(), arena(h, 'param').copy())
+        h.close()
+    assert np.isfinite(out['chain'][0]).all(), out['chain'][0]
+    for got, ref, what in zip(out['chain'], out['layers'], ('losses', 'gradient arena', 'parameter arena')):
+        assert np.array_equal(got, ref), '%s differ between the one-launch dense head and the layer launches at n = %d' % (what, n)
+
+
 def _run_ranks(worker, out_dir, backend, world=2):
     import os
     import socket

@@ -284,7 +284,9 @@ def cohort_mode(args, torch, dist, rank, world, local, weights):
     S = max(1, args.subjects)
     cpus = usable_cpus()
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
-    readers = args.readers or max(1, min(6, cpus // max(1, local_world) - 1))
+    share = max(2, cpus // max(1, local_world))                       # host threads of this rank: readers, writers and the caller
+    readers = args.readers or max(1, min(10, (share - 1) * 2 // 3))
+    writers = args.writers or max(2, min(6, share - 1 - readers))
     root = tempfile.mkdtemp(prefix='scs_cohort_r%d_' % rank, dir=os.environ.get('SCS_BENCH_TMP'))
     try:
         t_make = time.perf_counter()
@@ -292,7 +294,7 @@ def cohort_mode(args, torch, dist, rank, world, local, weights):
         t_make = time.perf_counter() - t_make
         opts = {'experiment': 'miccai2012_v1', 'net_verbose': 0, 'train_split': 0.25, 'max_epochs': 1, 'patience': 20,
                 'patch_size': [32, 32], 'load_weights': 'True', 'batch_size': 128, 'device': local, 'crop': 'True',
-                'test_batch_size': 100000, 'out_probabilities': 'True', 'post_process': 'True', 'debug': 'False'}
+                'test_batch_size': 100000, 'out_probabilities': 'True', 'post_process': 'True', 'debug': 'False', 'towers': args.towers}
         net = build_model(os.path.join(PKG, 'nets'), opts)
         base.test_scan(net, scans[0], opts)                            # warm-up: library, workspace, page cache of the code paths
         n_roi = int(getattr(net, 'last_scan_voxels', 0))
@@ -301,7 +303,7 @@ def cohort_mode(args, torch, dist, rank, world, local, weights):
         torch.cuda.synchronize()
         dist.barrier()
         c0, t0 = time.process_time(), time.perf_counter()
-        res = base.test_cohort(net, scans[1:], opts, shard=False, readers=readers)
+        res = base.test_cohort(net, scans[1:], opts, shard=False, readers=readers, writers=writers)
         torch.cuda.synchronize()
         dist.barrier()
         dt = dist.max_scalar(time.perf_counter() - t0)
@@ -311,17 +313,20 @@ def cohort_mode(args, torch, dist, rank, world, local, weights):
         value = world * S / dt * 3600.0
         per_rank_rate = S / dt                                         # subjects per second and rank
         out = {'metric': 'subjects/hour (test_cohort end to end: read, ROI, gather-fused inference, probabilities + post-processed labels written)',
-               'value': value, 'unit': 'subjects/h', 'n_gpus': world, 'steps': S, 'warmup': 1, 'ms_per_step': 1e3 * dt / S,
+               'value': value, 'unit': 'subjects/h', 'n_gpus': args.gpus, 'procs_per_gpu': world // args.gpus, 'ranks_seen': world,
+               'steps': S, 'warmup': 1, 'ms_per_step': 1e3 * dt / S,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': {'workload': 'whole-cohort inference, one subject at a time per GPU, %d synthetic 256x256x192 subjects per rank, '
                                       '~%d ROI voxels each, out_probabilities + post_process (BASELINE configs[4])' % (S, n_roi),
-                          'weights': 'miccai2012_v1 (shipped)', 'parallelism': 'subjects sharded over ranks, no collective'},
+                          'weights': 'miccai2012_v1 (shipped)',
+                          'parallelism': 'subjects sharded over %d rank(s) per GPU, no collective' % (world // args.gpus),
+                          'towers': '%s (ran as: %s)' % (args.towers, getattr(net, 'last_scan_towers', '?'))},
                'host': {'cpu_seconds_per_subject': cpu_s, 'gpu_seconds_per_subject': gpu_s, 'wall_seconds_per_subject_per_rank': dt / S,
-                        'usable_cpus': cpus, 'reader_threads_per_rank': readers,
+                        'usable_cpus': cpus, 'reader_threads_per_rank': readers, 'writer_threads_per_rank': writers,
                         'cores_busy_per_rank': per_rank_rate * cpu_s,
                         'ranks_one_host_share_can_feed': (cpus / (per_rank_rate * cpu_s)) if cpu_s > 0 else None,
                         'synth_seconds': t_make},
-               'gpu_stage_patches_per_s': (n_roi / gpu_s) if gpu_s > 0 else None}
+               'gpu_stage_voxels_per_s': (n_roi / gpu_s) if gpu_s > 0 else None}
         if rank == 0 and world == 1 and not args.no_cpu:
             cb = cpu_baseline_volume(weights)
             per_subject = (n_roi or 400000) / cb['value']
@@ -362,26 +367,37 @@ def main():
     ap.add_argument('--no-train-block', action='store_true', help='forward mode: skip the train_step block')
     ap.add_argument('--train-steps', type=int, default=200, help='timed steps per batch size of the train_step block')
     ap.add_argument('--subjects', type=int, default=6, help='cohort mode: synthetic subjects per rank')
-    ap.add_argument('--readers', type=int, default=0, help='cohort mode: reader threads per rank (0 = usable CPUs / ranks on this host, at most 6)')
+    ap.add_argument('--procs-per-gpu', type=int, default=1,
+                    help='cohort mode: ranks that share one GPU (gloo; the host side of a subject is Python threads, one process cannot '
+                         'keep more than ~6 cores busy)')
+    ap.add_argument('--writers', type=int, default=0, help='cohort mode: writer threads per rank (0 = from the usable CPUs)')
+    ap.add_argument('--towers', choices=['auto', 'patch', 'shared'], default='auto',
+                    help="cohort mode: 'patch' = one tower evaluation per ROI voxel and view (the reference's procedure), 'shared' = tower "
+                         "work shared between neighbouring voxels (same bits), 'auto' = shared for dense ROIs")
+    ap.add_argument('--readers', type=int, default=0, help='cohort mode: reader threads per rank (0 = from the usable CPUs / ranks on this host, at most 10)')
     ap.add_argument('--dry-run', action='store_true',
                     help='launcher rehearsal without a GPU: ranks rendezvous (gloo), run the barrier / max-over-ranks '
                          'timing brackets around an empty step and rank 0 prints a line marked "dry_run": true, value null')
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit('--gpus must be >= 1')
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    per_gpu = max(1, args.procs_per_gpu) if args.mode == 'cohort' else 1
+    want_world = args.gpus * per_gpu                                  # ranks of the job (= --gpus except for a shared-GPU cohort run)
+    if want_world > 1 and 'WORLD_SIZE' not in os.environ:
+        if per_gpu > 1:
+            os.environ['SCS_DIST_BACKEND'] = 'gloo'                    # several ranks per GPU: no RCCL communicator (and no collective on the data path)
+        raise SystemExit(spawn_ranks(want_world, sys.argv[1:]))
     env_world = int(os.environ.get('WORLD_SIZE', '1'))
-    if env_world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but the launcher started %d rank(s); refusing to report a run whose '
-                         'world size differs from --gpus' % (args.gpus, env_world))
+    if env_world != want_world:
+        raise SystemExit('bench.py: --gpus %d (x %d) but the launcher started %d rank(s); refusing to report a run whose '
+                         'world size differs from what was asked' % (args.gpus, per_gpu, env_world))
 
     import torch
     from cnn_cort import dist
 
     if args.dry_run:
         rank, world, _ = dist.init_from_env(backend='gloo')
-        assert world == args.gpus
+        assert world == want_world
         ranks_seen = int(round(dist.sum_scalar(1.0)))
         dist.barrier()
         t0 = time.perf_counter()
@@ -402,11 +418,11 @@ def main():
                          'shared-GPU rehearsal)' % (args.gpus, torch.cuda.device_count()))
     rank, world, local = dist.init_from_env()
     # every rank checks the communicator it actually got, and rank 0 reports how many ranks answered a collective
-    if world != args.gpus or dist.world_size() != args.gpus:
-        raise SystemExit('bench.py: rank %d sees a process group of %d rank(s), --gpus is %d' % (rank, dist.world_size(), args.gpus))
+    if world != want_world or dist.world_size() != want_world:
+        raise SystemExit('bench.py: rank %d sees a process group of %d rank(s), %d were asked for' % (rank, dist.world_size(), want_world))
     ranks_seen = int(round(dist.sum_scalar(1.0)))
-    if ranks_seen != args.gpus:
-        raise SystemExit('bench.py: a sum over the ranks counted %d, --gpus is %d' % (ranks_seen, args.gpus))
+    if ranks_seen != want_world:
+        raise SystemExit('bench.py: a sum over the ranks counted %d, %d were asked for' % (ranks_seen, want_world))
     torch.cuda.set_device(local)
     dev = 'cuda:%d' % local
     weights = P.load_params(os.path.join(PKG, 'nets', 'miccai2012_v1', 'miccai2012_v1'))

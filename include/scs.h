@@ -144,6 +144,18 @@ int scs_roi_prepare(scs_handle h, const void* mask_raw_dev, int dtype, int dim_x
 int scs_roi_centers(scs_handle h, const uint8_t* mask_dev, int dim_x, int dim_y, int dim_z, const int32_t* run_offsets_dev,
                     int32_t* centers_dev, int64_t n_centers, void* stream);
 
+/* test_scan for a whole subject with the tower work SHARED between neighbouring voxels: the same inputs and the same results
+ * - bit for bit - as scs_forward_volume_rows, at about 1/20 of the tower arithmetic when the centres fill their bounding box
+ * densely (an ROI).  The towers are valid convolutions and two 2x2 poolings, so the block-5 output of a patch is a 3x3 window of
+ * a per-slice map that depends only on the patch origin modulo 4; the maps are computed tile by tile with the kernels of the
+ * patch path (csrc/dense_eval.h).  box (HOST memory): xmin, xmax, ymin, ymax, zmin, zmax of the centres - every centre must lie
+ * inside it; the work grows with the box volume, not with n.  Scratch is grown inside the handle (at most ~0.8 GB of tiles +
+ * 6.5 KB per centre).
+ * Replaces: load_patch_batch + get_patches + net.predict_proba of base.py:380-397, 272-308, 425-438 for dense centre sets. */
+int scs_forward_volume_shared(scs_handle h, const float* vol_dev, int dim_x, int dim_y, int dim_z, const int32_t* centers_dev,
+                              const float* atlas_rows_dev, int64_t n, const int32_t* box_host, float* probs_dev,
+                              int32_t* labels_dev, void* stream);
+
 /* Measurement hook (bench.py): scs_forward with HIP events recorded on `stream` around each stage of every
  * chunk; synchronises.  stage_ms[8] receives the summed elapsed milliseconds of
  *   0 conv1+conv2+pool1, 1 conv3, 2 conv4+pool2, 3 conv5, 4 d1 x3, 5 FC1 (+atlas concat), 6 fc_2, 7 out+softmax

@@ -33,6 +33,7 @@ SIGNATURES = {
     'scs_forward_host': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
     'scs_forward_volume': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
     'scs_forward_volume_rows': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
+    'scs_forward_volume_shared': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp, _vp]),
     'scs_forward_profiled': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp, _vp, _c.POINTER(_c.c_int)]),
     'scs_get_activation': (_c.c_int, [_vp, _c.c_int, _vp, _c.c_size_t]),
     'scs_dilate_mask': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp]),
@@ -261,6 +262,19 @@ class Handle:
         _check(self.lib.scs_forward_volume_rows(self.h, _ptr(vol), int(dims[0]), int(dims[1]), int(dims[2]),
                                                 _ptr(centers), _ptr(atlas_rows), int(n), _ptr(probs), _ptr(labels),
                                                 stream or None), 'scs_forward_volume_rows')
+
+    def forward_volume_shared(self, vol, dims, centers, atlas_rows, n, box, probs=None, labels=None, stream=0):
+        """forward_volume_rows with the tower work shared between neighbouring voxels (include/scs.h: scs_forward_volume_shared).
+        box: (xmin, xmax, ymin, ymax, zmin, zmax) of the centres, host integers."""
+        self._check_volume(vol, dims, centers, n, probs, labels)
+        _need(atlas_rows, 15 * n, 'atlas rows')
+        b = np.ascontiguousarray(np.asarray(box, dtype=np.int64).reshape(6))
+        if (b[0::2] > b[1::2]).any() or (b[0::2] < -4096).any() or (b[1::2] - b[0::2] >= 4096).any():
+            raise ValueError('box %r is not (xmin, xmax, ymin, ymax, zmin, zmax) of a centre list' % (b.tolist(),))
+        b32 = b.astype(np.int32)
+        _check(self.lib.scs_forward_volume_shared(self.h, _ptr(vol), int(dims[0]), int(dims[1]), int(dims[2]), _ptr(centers),
+                                                  _ptr(atlas_rows), int(n), b32.ctypes.data, _ptr(probs), _ptr(labels),
+                                                  stream or None), 'scs_forward_volume_shared')
 
     def forward_profiled(self, ax, co, sa, atlas, n, probs=None, labels=None, stream=0):
         """-> (stage_ms float32[8], launches) measured with HIP events on `stream`."""

@@ -34,6 +34,7 @@ Reference quirks and what this module does about them:
 """
 import os
 import random
+import sys
 import time
 
 import numpy as np
@@ -528,11 +529,13 @@ def load_patch_batch(scan_name, options, datatype=np.float32):
 def _scan_predict(net, inputs, options):
     t1, raw, image_norm, centers, atlas_rows, centers_dev, _ = inputs
     want_probs = is_true(options.get('out_probabilities'))
+    # options['towers'] ('auto' | 'patch' | 'shared', nets.Net.predict_volume) is handed on only when set: other nets need not know it
+    how = {'towers': options['towers']} if 'towers' in options else {}
     # the priors stay on the host; only the ROI rows travel (base.py:388-394 rule already applied)
     if centers_dev is not None:                     # volume and voxel list are already on the device (_scan_inputs with a net)
-        return net.predict_volume(image_norm, centers_dev, atlas_rows=atlas_rows, want_probs=want_probs, batch=options['test_batch_size'])
+        return net.predict_volume(image_norm, centers_dev, atlas_rows=atlas_rows, want_probs=want_probs, batch=options['test_batch_size'], **how)
     return net.predict_volume(np.ascontiguousarray(image_norm, dtype=np.float32), centers, atlas_rows=atlas_rows,
-                              want_probs=want_probs, batch=options['test_batch_size'])
+                              want_probs=want_probs, batch=options['test_batch_size'], **how)
 
 
 def _scan_outputs(image_path, inputs, labels, probs, options):
@@ -563,10 +566,11 @@ def test_scan(net, test_scan, options):
     return (time.time() - s_time) / 60.0
 
 
-def test_cohort(net, scan_paths, options, shard=True, readers=4):
+def test_cohort(net, scan_paths, options, shard=True, readers=4, writers=2):
     """test_scan over a list of T1 paths (the loop of train_model.py:74-78) as a three-stage pipeline: while the
     GPU segments subject i, `readers` helper threads already read the next subjects (gunzip of the prior is the
-    longest stage) and another writes the files of subject i-1.  Same files as calling test_scan per path.  Under torchrun every
+    longest stage) and `writers` others write the files of the subjects before it (with the towers shared between voxels the
+    GPU needs 0.02 s per subject and the host threads set the rate).  Same files as calling test_scan per path.  Under torchrun every
     rank takes every world_size-th subject (no collective).  Returns [(path, minutes)] for this rank's subjects,
     minutes = that subject's own load + predict + write time."""
     from concurrent.futures import ThreadPoolExecutor
@@ -592,18 +596,24 @@ def test_cohort(net, scan_paths, options, shard=True, readers=4):
         return _scan_inputs(p, options, dilate=getattr(net, 'dilate_mask', None))
 
     ahead = max(1, int(readers))                   # subjects being read while one is on the GPU
-    with ThreadPoolExecutor(ahead) as loader, ThreadPoolExecutor(2) as writer:      # files of different subjects are independent
+    with ThreadPoolExecutor(ahead) as loader, ThreadPoolExecutor(max(1, int(writers))) as writer:   # files of different subjects are independent
         pending = [loader.submit(timed, read, p) for p in paths[:ahead]]
-        writes = []
+        writes, gpu_times = [], []
         for i, p in enumerate(paths):
             inputs, t_load = pending.pop(0).result()
             if i + ahead < len(paths):
                 pending.append(loader.submit(timed, read, paths[i + ahead]))
             (labels, probs), t_gpu = timed(_scan_predict, net, inputs, options)
+            gpu_times.append(t_gpu)
             writes.append((p, t_load + t_gpu, writer.submit(timed, _scan_outputs, os.path.dirname(p), inputs, labels, probs, options)))
+        stage = [0.0, 0.0]
         for p, t, fut in writes:
             _, t_write = fut.result()
             out.append((p, (t + t_write) / 60.0))
+            stage[0] += t; stage[1] += t_write
+    if os.environ.get('SCS_COHORT_TIMES'):          # diagnostic: mean seconds a subject spends in each stage (not wall: stages overlap)
+        sys.stderr.write('test_cohort: %d subjects, load + predict %.3f s, of which predict %.3f s (caller thread), write %.3f s per subject\n'
+                         % (len(out), stage[0] / len(out), sum(gpu_times) / len(out), stage[1] / len(out)))
     return out
 
 

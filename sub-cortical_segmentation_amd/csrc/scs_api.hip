@@ -21,6 +21,8 @@
 #include "conv_mfma.h"
 #include "gemm_mfma.h"
 #include "scs_ctx.h"
+#include "dense_eval.h"
+#include "dense_eval.h"
 
 namespace scs {
 
@@ -40,6 +42,7 @@ using CfgConv12X = ConvCfg<20, 20, 30, 1, EPI_BIAS_RELU_POOL, SRC_X0, 496, 2, 2>
 using CfgConv3 = ConvCfg<20, 40, 14, 2, EPI_BIAS_RELU, SRC_NCHW, 208, 1, 3>;
 using CfgConv4 = ConvCfg<40, 40, 12, 1, EPI_BIAS_RELU_POOL, SRC_NCHW, 144, 1, 4>;
 using CfgConv5 = ConvCfg<40, 60, 5, 7, EPI_BIAS_RELU, SRC_NCHW, 27, 1, 3>;     // 7 x 9 = 63 of 64 rows: four full tiles
+using CfgConv4NP = ConvCfg<40, 40, 12, 1, EPI_BIAS_RELU, SRC_NCHW, 144, 1, 4>;  // conv4 without pool2 (shared-tower evaluation: pool2 has four window origins)
 
 // ----------------------------------------------------------------------------- packing kernels
 // conv i (Cin >= 4): packed chunks (scs_common.h), element = W[n][4*c4+kk][2-dy][2-dx] * scale[n]  (true conv -> correlation)
@@ -454,10 +457,21 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_pool2[t]; a.w[t] = pk.convw[t][4]; a.bias[t] = pk.convb[t][4]; a.out[t] = h->a_conv5[t]; }
     conv_launch<CfgConv5>(a, st);
     mark(4);
+    const float* c5[kTowers] = {h->a_conv5[0], h->a_conv5[1], h->a_conv5[2]};
+    return forward_head(h, c5, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, x0 ? x0->n_samples : n, atlas_index);
+}
+
+// The fusion head of one chunk: c5[t] = the towers' flattened block-5 outputs [n][540] (nets.py:176-231: d1 x3, FC1 on their
+// concatenation, fc_2 on [FC1 | atlas prior], out + softmax); marks 5..8 of the profiled forward.
+int forward_head(scs_ctx* h, const float* const c5[kTowers], const float* atlas, const float* vol, int dx, int dy, int dz,
+                 const int32_t* centers, const float* atlas4d, int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
+                 int atlas_rows, const int32_t* atlas_index) {
+    const PackedNet& pk = h->pk;
+    auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     // d1 x3 -> feat[:, 180 t : 180 t + 180]
     GemmArgs g{};
     g.M = n; g.K4 = kFlat; g.N = kD1; g.relu = 1;
-    for (int t = 0; t < kTowers; ++t) g.p[t] = GemmProblem{h->a_conv5[t], kFlat, pk.d1w[t], gemm_ns(kD1), pk.d1b[t], h->a_feat + t * kD1, kFlat};
+    for (int t = 0; t < kTowers; ++t) g.p[t] = GemmProblem{c5[t], kFlat, pk.d1w[t], gemm_ns(kD1), pk.d1b[t], h->a_feat + t * kD1, kFlat};
     gemm_launch(g, kTowers, st);
     mark(5);
     // FC1 -> fc1[:, 0:540]; atlas -> fc1[:, 540:556]
@@ -467,7 +481,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     if (vol && atlas4d)
         hipLaunchKernelGGL(atlas_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->a_fc1, n);
     else
-        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, atlas_index, x0 ? x0->n_samples : n, h->a_fc1, n);
+        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, atlas_index, atlas_rows, h->a_fc1, n);
     mark(6);
     // fc_2
     g.K4 = kFC1ld; g.N = kFC2;
@@ -483,6 +497,69 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     return SCS_OK;
 }
 
+// ----------------------------------------------------------------------------- whole subject with shared tower work (dense_eval.h)
+static int grow(float** buf, size_t* have, size_t need) {
+    if (*buf && *have >= need) return SCS_OK;
+    SCS_HIP(hipDeviceSynchronize());                       // a previous call may still be using the old buffer
+    if (*buf) { SCS_HIP(hipFree(*buf)); *buf = nullptr; *have = 0; }
+    SCS_HIP(hipMalloc(buf, need * sizeof(float)));
+    *have = need;
+    return SCS_OK;
+}
+
+constexpr size_t kDenseBudgetFloats = (size_t)192 << 20;   // tile buffers of one slice batch: at most 768 MB
+
+// towers of all n ROI voxels -> h->dense_feat [3][n][540]
+int dense_towers(scs_ctx* h, const float* vol, int dx, int dy, int dz, const int32_t* centers, int64_t n, const int32_t* box, hipStream_t st) {
+    const PackedNet& pk = h->pk;
+    int rc = grow(&h->dense_feat, &h->dense_feat_floats, (size_t)kTowers * n * kFlat);
+    if (rc != SCS_OK) return rc;
+    for (int v = 0; v < kTowers; ++v) {
+        const DenseView V = dense_view(v, box);
+        const size_t per_slice = dense_buffers(V, 1).total;
+        const int sb = (int)std::max<size_t>(1, std::min<size_t>((size_t)V.S, kDenseBudgetFloats / per_slice));
+        const DenseBuffers B = dense_buffers(V, sb);
+        rc = grow(&h->dense_ws, &h->dense_ws_floats, B.total);
+        if (rc != SCS_OK) return rc;
+        float* W = h->dense_ws;
+        int32_t* ctr = reinterpret_cast<int32_t*>(W + B.ctr);
+        float* feat = h->dense_feat + (size_t)v * n * kFlat;
+        for (int s0 = 0; s0 < V.S; s0 += sb) {
+            const int cur = std::min(sb, V.S - s0);
+            ConvArgs a{};
+            a.tower0 = v;
+            // conv1 + conv2 + pool1 on the 32x32 windows of the pool1 tiles
+            a.n = V.n1(cur);
+            hipLaunchKernelGGL(dense_centres_kernel, dense_grid(a.n), dim3(256), 0, st, V, s0, cur, ctr);
+            a.in[v] = vol; a.centers = ctr; a.dimx = dx; a.dimy = dy; a.dimz = dz;
+            a.w[v] = pk.convw[v][1]; a.bias[v] = pk.convb[v][1]; a.w1[v] = pk.conv1w[v]; a.out[v] = W + B.t1;
+            conv_launch<CfgConv12V>(a, st, 1);
+            // conv3 on 14x14 tiles every 12
+            hipLaunchKernelGGL((dense_retile_kernel<20, 14, 14, 12>), dense_grid((long)V.n3(cur) * 20 * 196), dim3(256), 0, st,
+                               W + B.t1, V.t1r, V.t1c, W + B.i3, V.t3r, V.t3c, cur * 4);
+            a.n = V.n3(cur); a.centers = nullptr;
+            a.in[v] = W + B.i3; a.w[v] = pk.convw[v][2]; a.bias[v] = pk.convb[v][2]; a.out[v] = W + B.o3;
+            conv_launch<CfgConv3>(a, st, 1);
+            // conv4 on 12x12 tiles every 10
+            hipLaunchKernelGGL((dense_retile_kernel<40, 12, 12, 10>), dense_grid((long)V.n4(cur) * 40 * 144), dim3(256), 0, st,
+                               W + B.o3, V.t3r, V.t3c, W + B.i4, V.t4r, V.t4c, cur * 4);
+            a.n = V.n4(cur);
+            a.in[v] = W + B.i4; a.w[v] = pk.convw[v][3]; a.bias[v] = pk.convb[v][3]; a.out[v] = W + B.o4;
+            conv_launch<CfgConv4NP>(a, st, 1);
+            // pool2 (four window origins) and conv5 on 5x5 tiles every 3
+            hipLaunchKernelGGL(dense_pool_retile_kernel, dense_grid((long)V.n5(cur) * 40 * 25), dim3(256), 0, st,
+                               W + B.o4, V.t4r, V.t4c, W + B.i5, V.t5r, V.t5c, cur);
+            a.n = V.n5(cur);
+            a.in[v] = W + B.i5; a.w[v] = pk.convw[v][4]; a.bias[v] = pk.convb[v][4]; a.out[v] = W + B.o5;
+            conv_launch<CfgConv5>(a, st, 1);
+            // the 3x3 windows of the voxels of these slices
+            hipLaunchKernelGGL(dense_features_kernel, dense_grid(n * 60), dim3(256), 0, st, V, s0, cur, W + B.o5, centers, (long)n, feat);
+        }
+    }
+    SCS_HIP(hipGetLastError());
+    return SCS_OK;
+}
+
 static int set_kernel_attrs() {
     SCS_HIP(conv_set_attr<CfgConv12>());
     SCS_HIP(conv_set_attr<CfgConv12V>());
@@ -490,6 +567,7 @@ static int set_kernel_attrs() {
     SCS_HIP(conv_set_attr<CfgConv3>());
     SCS_HIP(conv_set_attr<CfgConv4>());
     SCS_HIP(conv_set_attr<CfgConv5>());
+    SCS_HIP(conv_set_attr<CfgConv4NP>());
     SCS_HIP(gemm_set_attrs());
     return SCS_OK;
 }
@@ -542,6 +620,8 @@ int scs_destroy(scs_handle h) {
     if (h->adam_v) (void)hipFree(h->adam_v);
     if (h->packed) (void)hipFree(h->packed);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->dense_ws) (void)hipFree(h->dense_ws);
+    if (h->dense_feat) (void)hipFree(h->dense_feat);
     if (h->stage_dev) (void)hipFree(h->stage_dev);
     if (h->last_train_event) (void)hipEventDestroy(h->last_train_event);
     if (h->host_compute) (void)hipStreamDestroy(h->host_compute);
@@ -631,6 +711,37 @@ int scs_forward_volume_rows(scs_handle h, const float* vol, int dx, int dy, int 
     SCS_ARG(n == 0 || (vol && centers && atlas_rows), "null input pointer");
     SCS_ARG(dx > 0 && dy > 0 && dz > 0, "volume dims must be positive");
     return forward_common(h, nullptr, nullptr, nullptr, atlas_rows, vol, dx, dy, dz, centers, nullptr, n, probs, labels, stream);
+}
+
+int scs_forward_volume_shared(scs_handle h, const float* vol, int dx, int dy, int dz, const int32_t* centers,
+                              const float* atlas_rows, int64_t n, const int32_t* box, float* probs, int32_t* labels, void* stream) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(n >= 0, "n < 0");
+    SCS_ARG(n == 0 || (vol && centers && atlas_rows && box), "null input pointer");
+    SCS_ARG(dx > 0 && dy > 0 && dz > 0, "volume dims must be positive");
+    if (!h->has_params) { set_error("scs_forward_volume_shared before scs_set_params"); return SCS_ERR_STATE; }
+    if (n == 0) return SCS_OK;
+    for (int a = 0; a < 3; ++a) {
+        SCS_ARG(box[2 * a] <= box[2 * a + 1], "box: min > max");
+        SCS_ARG((int64_t)box[2 * a + 1] - box[2 * a] < 4096, "box: extent too large");
+    }
+    SCS_HIP(hipSetDevice(h->device));
+    const int step = balanced_chunk(n, h->chunk);
+    int rc = ensure_workspace(h, step);
+    if (rc != SCS_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
+    rc = dense_towers(h, vol, dx, dy, dz, centers, n, box, st);
+    if (rc != SCS_OK) return rc;
+    for (int64_t s = 0; s < n; s += step) {
+        const int m = (int)((n - s < step) ? (n - s) : step);
+        const float* c5[kTowers];
+        for (int t = 0; t < kTowers; ++t) c5[t] = h->dense_feat + ((size_t)t * n + s) * kFlat;
+        rc = forward_head(h, c5, atlas_rows + s * 15, nullptr, 0, 0, 0, nullptr, nullptr, m, probs ? probs + s * 15 : nullptr,
+                          labels ? labels + s : nullptr, st, nullptr, m, nullptr);
+        if (rc != SCS_OK) return rc;
+    }
+    return SCS_OK;
 }
 
 // Host-pointer entry.  The chunks are double buffered on the device: a helper thread uploads chunk i+1 on the

@@ -35,6 +35,10 @@ struct scs_ctx {
     float* a_logits = nullptr;        // [chunk][16]
     int last_n = 0;
 
+    // shared-tower evaluation of a whole subject (dense_eval.h): tile buffers of one slice batch, block-5 features of all voxels
+    float* dense_ws = nullptr; size_t dense_ws_floats = 0;
+    float* dense_feat = nullptr; size_t dense_feat_floats = 0;
+
     // host staging for the *_host entry points
     float* stage_dev = nullptr;       // [chunk] x (3*1024 + 15 + 15) floats + labels
     size_t stage_floats = 0;
@@ -53,5 +57,8 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
                   int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
                   const X0Src* x0 = nullptr, const int32_t* atlas_index = nullptr);
+int forward_head(scs_ctx* h, const float* const c5[kTowers], const float* atlas, const float* vol, int dx, int dy, int dz,
+                 const int32_t* centers, const float* atlas4d, int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
+                 int atlas_rows, const int32_t* atlas_index);
 void train_free(scs_ctx* h);
 }

@@ -106,6 +106,61 @@ def test_volume_rows_equals_volume_4d(weights):
         net.predict_volume(vol, centers, atlas_rows=np.zeros((3, 15), np.float32))
 
 
+def _roi_case(case):
+    from scipy import ndimage
+    from cnn_cort import synth
+    rng = np.random.RandomState(31)
+    if case == 'blob':                  # a dilated blob well inside the volume: box extents 45 x 41 x 38 (not multiples of anything)
+        shape = (72, 64, 60)
+        m = np.zeros(shape, bool)
+        m[20:45, 18:39, 16:34] = rng.rand(25, 21, 18) > 0.97
+        roi = ndimage.binary_dilation(m, iterations=10)
+    elif case == 'border':              # an ROI that runs into three faces of the volume: patches hang over the edge (zero padding)
+        shape = (40, 44, 36)
+        roi = np.zeros(shape, bool)
+        roi[0:19, 30:44, 0:23] = True
+        roi[5:9, 33:36, 4:9] = False    # with a hole
+    elif case == 'thin':                # one voxel thick along z, 5 along y: degenerate boxes in two views
+        shape = (48, 40, 33)
+        roi = np.zeros(shape, bool)
+        roi[7:40, 17:22, 16] = True
+    else:                               # scattered voxels: the box is mostly empty
+        shape = (60, 60, 60)
+        roi = rng.rand(*shape) > 0.97
+        roi[:3] = roi[-3:] = False
+    vol = base._zscore(synth.smooth_volume(shape, sigma=2.0, seed=32, as_int=True), False).astype(np.float32)
+    centers = np.argwhere(roi)
+    atlas = rng.dirichlet(np.ones(15) * 0.3, len(centers)).astype(np.float32)
+    return vol, centers, atlas
+
+
+@pytest.mark.parametrize('case', ['blob', 'border', 'thin', 'scattered'])
+def test_shared_tower_evaluation_gives_the_bits_of_the_patch_path(weights, case):
+    """scs_forward_volume_shared (csrc/dense_eval.h: per-slice maps computed tile by tile with the patch kernels, 16 pooling phases,
+    3x3 windows gathered per voxel) against scs_forward_volume_rows (one tower evaluation per voxel and view): the same kernels
+    see the same numbers in the same order, so labels AND probabilities must be equal bit for bit - inside the volume, over its
+    border, for degenerate boxes and for a sparse centre list - with host and with device-resident inputs."""
+    import torch
+    vol, centers, atlas = _roi_case(case)
+    net = build_model(os.path.join(PKG, 'nets'), options('/nonexistent'))
+    lp, pp = net.predict_volume(vol, centers, atlas_rows=atlas, want_probs=True, batch=10 ** 9, towers='patch')
+    assert net.last_scan_towers == 'patch'
+    ls, ps = net.predict_volume(vol, centers, atlas_rows=atlas, want_probs=True, towers='shared')
+    assert net.last_scan_towers == 'shared'
+    print('%s: %d centres in a box of %d voxels' % (case, len(centers), np.prod(centers.max(0) - centers.min(0) + 1)))
+    assert np.array_equal(ls, lp)
+    assert np.array_equal(ps, pp), 'max difference %g' % np.abs(ps - pp).max()
+    # device-resident volume and centres, labels only
+    ld, _ = net.predict_volume(torch.from_numpy(vol).cuda(), torch.from_numpy(np.ascontiguousarray(centers, dtype=np.int32)).cuda(), atlas_rows=atlas,
+                               towers='shared')
+    assert np.array_equal(ld, lp)
+    # 'auto' picks by density
+    net.predict_volume(vol, centers, atlas_rows=atlas, towers='auto')
+    assert net.last_scan_towers == ('shared' if case in ('blob', 'border') else 'patch')
+    with pytest.raises(ValueError):
+        net.predict_volume(vol, centers, atlas4d=np.zeros(vol.shape + (15,), np.float32), towers='shared')
+
+
 @pytest.mark.parametrize('shape,iters', [((23, 17, 31), 1), ((40, 44, 36), 10), ((9, 64, 5), 3), ((33, 20, 18), 0)])
 def test_gpu_dilation_equals_scipy(shape, iters):
     """Net.dilate_mask == scipy.ndimage.binary_dilation(mask, iterations) bit for bit (6-neighbour cross, border 0), on

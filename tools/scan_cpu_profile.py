@@ -44,7 +44,7 @@ def main():
             'test_batch_size': 100000, 'out_probabilities': 'True', 'post_process': 'True', 'debug': 'False'}
     if args.no_gpu:
         class StubNet:
-            def predict_volume(self, vol, centers, atlas4d=None, want_probs=True, batch=None, atlas_rows=None):
+            def predict_volume(self, vol, centers, atlas4d=None, want_probs=True, batch=None, atlas_rows=None, towers='auto'):
                 n = len(centers)
                 rng = np.random.RandomState(0)
                 p = rng.dirichlet(np.ones(15), n).astype(np.float32)

@@ -67,7 +67,7 @@ def main():
 
     if args.no_gpu:
         class StubNet:
-            def predict_volume(self, vol, centers, atlas4d=None, want_probs=True, batch=None, atlas_rows=None):
+            def predict_volume(self, vol, centers, atlas4d=None, want_probs=True, batch=None, atlas_rows=None, towers='auto'):
                 n = len(centers)
                 return np.zeros(n, np.int32), (np.zeros((n, 15), np.float32) if want_probs else None)
         net = StubNet()

@@ -48,3 +48,16 @@ def test_bench_line(mode):
             assert abs(blk['ms_per_step'] * blk['value'] / 1e3 - bsz) < 1.0
             assert 0.02 < blk['frac_of_f32_peak'] < 1.0 and blk['launches_per_step'] <= 30
             assert blk['roofline']['bound'] == 'mfma' and blk['roofline']['launch_ms'] > 0 and blk['stages']
+
+
+@pytest.mark.parametrize('procs', [1, 2])
+def test_cohort_line(procs):
+    """`bench.py --mode cohort`: test_cohort end to end on synthetic 256x256x192 subjects (BASELINE configs[4]); the line states the
+    host budget, which form of the tower evaluation ran, and - with several processes sharing the GPU - how many ranks answered."""
+    out = run_bench(['--mode', 'cohort', '--subjects', '2', '--no-cpu', '--procs-per-gpu', str(procs)])
+    assert out['unit'] == 'subjects/h' and out['n_gpus'] == 1 and out['procs_per_gpu'] == procs and out['ranks_seen'] == procs
+    assert out['value'] > 2000 and out['steps'] == 2 and out['dtype'] == 'f32' and out['vs_baseline'] is None
+    assert out['config']['towers'] == 'auto (ran as: shared)'            # a dilated-mask ROI fills its box densely
+    h = out['host']
+    assert 0 < h['gpu_seconds_per_subject'] < 0.2 and 0 < h['cpu_seconds_per_subject'] < 3.0
+    assert h['reader_threads_per_rank'] >= 1 and h['writer_threads_per_rank'] >= 1 and h['usable_cpus'] >= 1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/ of a round is made from, in ONE gpurun call on one MI355X:  bash tools/profile_round.sh r03
-#   bench lines (default = forward + train_step block, train, volume, cohort), rocprofv3 kernel traces of the forward and of the
+#   bench lines (default = forward + train_step block, train, volume, cohort in three forms), test_scan per stage, rocprofv3 kernel traces of the forward and of the
 #   training run (per-kernel statistics, a one-step launch timeline), and the HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in
 #   separate runs, no trace domains beside them).  Results land in gpurun_out/; tools/pmc_traffic.py then writes
 #   profiles/traffic.json against gpurun_out/csrc_sha16.txt.
@@ -15,6 +15,12 @@ echo "== bench default"; timeout -k 10 400 python3 bench.py > $OUT/${R}_bench_de
 echo "== bench train";   timeout -k 10 300 python3 bench.py --mode train --steps 300 --warmup 30 > $OUT/${R}_bench_train.json.log 2>/dev/null || exit 1
 echo "== bench volume";  timeout -k 10 300 python3 bench.py --mode volume > $OUT/${R}_bench_volume.json.log 2>/dev/null || exit 1
 echo "== bench cohort";  timeout -k 10 500 python3 bench.py --mode cohort --subjects 10 > $OUT/${R}_bench_cohort.json.log 2>/dev/null || exit 1
+echo "== bench cohort, towers per voxel (the reference's procedure)"
+timeout -k 10 500 python3 bench.py --mode cohort --subjects 10 --towers patch --no-cpu > $OUT/${R}_bench_cohort_patch_towers.json.log 2>/dev/null || exit 1
+echo "== bench cohort, four processes on the GPU"
+timeout -k 10 500 python3 bench.py --mode cohort --subjects 10 --procs-per-gpu 4 --no-cpu > $OUT/${R}_bench_cohort_4procs.json.log 2>/dev/null || exit 1
+echo "== test_scan, one subject, per stage"
+timeout -k 10 300 python3 tools/scan_cpu_profile.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scan_cpu_profile.txt || exit 1
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel trace forward"
 timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/prof_fwd -- python3 $ROOT/bench.py --no-cpu --no-train-block --steps 10 --warmup 2 > $OUT/prof_fwd.log 2>&1 || exit 1

@@ -149,7 +149,8 @@ int scs_roi_centers(scs_handle h, const uint8_t* mask_dev, int dim_x, int dim_y,
  * densely (an ROI).  The towers are valid convolutions and two 2x2 poolings, so the block-5 output of a patch is a 3x3 window of
  * a per-slice map that depends only on the patch origin modulo 4; the maps are computed tile by tile with the kernels of the
  * patch path (csrc/dense_eval.h).  box (HOST memory): xmin, xmax, ymin, ymax, zmin, zmax of the centres - every centre must lie
- * inside it; the work grows with the box volume, not with n.  Scratch is grown inside the handle (at most ~0.8 GB of tiles +
+ * inside it (a centre outside reads nothing and gets an undefined row of results); the work grows with the box volume, not
+ * with n.  Scratch is grown inside the handle (at most ~0.8 GB of tiles +
  * 6.5 KB per centre).
  * Replaces: load_patch_batch + get_patches + net.predict_proba of base.py:380-397, 272-308, 425-438 for dense centre sets. */
 int scs_forward_volume_shared(scs_handle h, const float* vol_dev, int dim_x, int dim_y, int dim_z, const int32_t* centers_dev,

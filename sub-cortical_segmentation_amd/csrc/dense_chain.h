@@ -36,6 +36,11 @@
 #pragma once
 #include "gemm_mfma.h"
 
+// XCC_ID (hardware register 20), an L2 shared by the CUs of an XCD, vector stores counted by vmcnt: the gfx942 / gfx950 family
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "dense_chain.h: the XCD-local cluster hand-off relies on gfx942/gfx950 hardware (XCC_ID, per-XCD L2, vmcnt-counted stores)"
+#endif
+
 namespace scs {
 
 constexpr int kChainMembers = 9;                 // column blocks of 64 of a 540-wide layer = workgroups per cluster

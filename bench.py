@@ -201,13 +201,16 @@ def train_inputs(torch, B, rank, dev):
 
 def train_stage_profile(h, inputs, B, st, reps=5):
     """Every launch of one training step timed with HIP events on the stream it is issued on (scs_train_step_profiled; the
-    weight-gradient kernels run on the library's side stream), averaged over a few steps -> (roofline of the dominant conv
+    weight-gradient kernels run on the library's side stream), median of a few steps -> (roofline of the dominant conv
     kernel, per-stage table, launches per step, sum of launch times)."""
     ax, co, sa, at, y = inputs
-    acc = {}
+    seen = {}
     for r in range(reps):
         for k, v in h.train_step_profiled(ax, co, sa, at, y, B, seed=1000 + r, stream=st).items():
-            acc[k] = acc.get(k, 0.0) + v / reps
+            seen.setdefault(k, []).append(v)
+    # median over the repetitions: the first launch of a step sits behind an empty queue, so a slow enqueue on the host (the
+    # events are recorded by the GPU when it reaches them) shows up in its time now and then
+    acc = {k: float(sorted(v)[len(v) // 2]) for k, v in seen.items()}
     convs = {k: v for k, v in TRAIN_CONV_MACS.items() if acc.get(k, 0.0) > 0}
     dom = max(convs, key=lambda k: acc[k])
     dur = acc[dom] * 1e-3

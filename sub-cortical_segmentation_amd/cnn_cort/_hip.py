@@ -140,6 +140,8 @@ IO_SIGNATURES = {
     'scs_io_last_error': (_c.c_char_p, []),
     'scs_gz_gather': (_c.c_int, [_c.c_char_p, _vp, _c.c_int64, _c.c_int, _vp, _c.POINTER(_c.c_int64)]),
     'scs_gz_read': (_c.c_int, [_c.c_char_p, _c.c_int64, _c.c_int64, _vp]),
+    'scs_gz_member': (_c.c_int, [_vp, _c.c_int64, _vp, _c.c_int64, _c.POINTER(_c.c_int64)]),
+    'scs_gz_member_scatter': (_c.c_int, [_c.c_int64, _vp, _c.c_int, _vp, _vp, _c.c_int64, _vp, _c.c_int64, _c.POINTER(_c.c_int64)]),
 }
 _io_lib = None
 
@@ -183,6 +185,42 @@ def gz_read(path, offset, out):
     if rc != 0:
         raise _io_error(lib, 'scs_gz_read', rc)
     return out
+
+
+def gz_member(buf):
+    """One gzip member holding the bytes of `buf` (any C-contiguous buffer), by the library's encoder for sparse volumes
+    (scs_gz_member): zero runs and 8-byte repeats are matches, the rest literals."""
+    lib = load_io_library()
+    src = np.frombuffer(buf, dtype=np.uint8)
+    out = np.empty(src.size + src.size // 8 + 64, dtype=np.uint8)
+    n = ctypes.c_int64(0)
+    rc = lib.scs_gz_member(src.ctypes.data, int(src.size), out.ctypes.data, int(out.size), ctypes.byref(n))
+    if rc != 0:
+        raise _io_error(lib, 'scs_gz_member', rc)
+    return out[:n.value].tobytes()
+
+
+def gz_member_scatter(n_elements, fill, index, values):
+    """One gzip member holding n_elements copies of the scalar `fill` (its dtype is the element type) with values[k] at element
+    index[k] (scs_gz_member_scatter: the buffer is built and deflated inside the library, no interpreter lock held)."""
+    lib = load_io_library()
+    values = np.ascontiguousarray(values)
+    fill = np.asarray(fill, dtype=values.dtype).reshape(1)
+    index = np.ascontiguousarray(index, dtype=np.int64)
+    if index.shape != values.shape or values.ndim != 1:
+        raise ValueError('index and values must be 1-D arrays of the same length')
+    item = values.dtype.itemsize
+    nbytes = int(n_elements) * item
+    n = ctypes.c_int64(0)
+    for cap in (nbytes // 32 + values.nbytes * 9 // 8 + 1024, nbytes + nbytes // 8 + 64):     # sparse rows deflate to a few per cent
+        out = np.empty(cap, dtype=np.uint8)
+        rc = lib.scs_gz_member_scatter(nbytes, fill.ctypes.data, item, index.ctypes.data, values.ctypes.data, int(values.size),
+                                       out.ctypes.data, int(cap), ctypes.byref(n))
+        if rc == 0:
+            return out[:n.value].tobytes()
+        if b'too small' not in (lib.scs_io_last_error() or b''):
+            break
+    raise _io_error(lib, 'scs_gz_member_scatter', rc)
 
 
 class Handle:

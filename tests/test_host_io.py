@@ -111,3 +111,89 @@ def test_load_rows_native_and_python_paths_agree(tmp_path, monkeypatch):
         assert whole.dtype == whole_py.dtype and whole.flags['F_CONTIGUOUS'] and np.array_equal(whole, whole_py) and np.array_equal(whole, a)
         assert native.dtype == python.dtype == np.float32
         assert np.array_equal(native, python) and np.array_equal(native, a[vox[:, 0], vox[:, 1], vox[:, 2]])
+
+
+def test_sparse_gzip_member_round_trips_through_zlib():
+    """scs_gz_member (the run / 8-byte-repeat deflate writer of libscs_io.so) against zlib's and gzip's inflaters: every zero-run
+    length around the 258-byte match limit, runs next to data, constants, float64 values that came from float32, dense random
+    bytes (no compression, still valid), and 300 random structured buffers."""
+    import gzip
+    import zlib
+    from cnn_cort import _hip
+    rng = np.random.RandomState(5)
+
+    def check(b):
+        b = bytes(b)
+        m = _hip.gz_member(b)
+        assert zlib.decompress(m, 31) == b and gzip.decompress(m) == b
+        return len(m)
+
+    for n in list(range(0, 20)) + list(range(250, 275)) + list(range(510, 530)) + [1000, 4096, 65535, 65536, 100003]:
+        check(b'\x00' * n)
+        check(b'\x07' + b'\x00' * n + b'\x09')
+        check(b'\x05' * n)
+    assert check(b'\x00' * (1 << 22)) < 30000                              # 13 bits per 258 bytes
+    a = np.zeros(200000, np.float64)
+    a[60000:90000] = rng.dirichlet(np.ones(15) * 0.3, 30000)[:, 0].astype(np.float32)
+    assert check(a.tobytes()) < 0.8 * 30000 * 8                            # the three zero mantissa bytes of every value are matches
+    assert check(np.full(100001, 3, np.uint8).tobytes()) < 1000
+    assert check(np.full(70000, -7, np.int16).tobytes()) < 1500
+    dense = rng.bytes(100000)
+    assert check(dense) < 100000 * 9 // 8 + 64                             # literals only: 8 - 9 bits per byte
+    for k in range(300):
+        n = rng.randint(0, 3000)
+        b = bytearray(n)
+        for _ in range(rng.randint(0, 6)):
+            if n < 2:
+                break
+            lo = rng.randint(0, n - 1)
+            hi = min(n, lo + rng.randint(1, 400))
+            b[lo:hi] = rng.bytes(hi - lo) if rng.rand() < 0.5 else bytes([rng.randint(0, 256)]) * (hi - lo)
+        check(b)
+    # concatenated members are one stream for the library's own inflate too
+    with pytest.raises(Exception):
+        _hip.gz_member(np.zeros((4, 4))[:, ::2])                           # not C-contiguous
+
+
+def test_sparse_volume_files_are_the_same_volume_with_either_encoder(tmp_path, monkeypatch):
+    """nifti.save_sparse through the library's encoder and through zlib (SCS_GZIP=zlib): different gzip bytes, the same volume -
+    read back with the native inflate and with the Python streaming reader."""
+    from cnn_cort import nifti
+    rng = np.random.RandomState(6)
+    shape = (40, 36, 30, 15)
+    vox = np.argwhere(rng.rand(*shape[:3]) > 0.9)
+    vals = rng.dirichlet(np.ones(15) * 0.3, len(vox)).astype(np.float32).astype(np.float64)
+    nifti.save_sparse(str(tmp_path / 'native.nii.gz'), shape, np.float64, vox, vals)
+    monkeypatch.setenv('SCS_GZIP', 'zlib')
+    nifti.save_sparse(str(tmp_path / 'zlib.nii.gz'), shape, np.float64, vox, vals)
+    monkeypatch.delenv('SCS_GZIP')
+    a = nifti.load(str(tmp_path / 'native.nii.gz')).get_data()
+    b = nifti.load(str(tmp_path / 'zlib.nii.gz')).get_data()
+    monkeypatch.setenv('SCS_NO_NATIVE_IO', '1')
+    c = nifti.load(str(tmp_path / 'native.nii.gz')).get_data()
+    dense = np.zeros(shape, np.float64)
+    dense[vox[:, 0], vox[:, 1], vox[:, 2]] = vals
+    assert np.array_equal(a, dense) and np.array_equal(b, dense) and np.array_equal(c, dense)
+    assert open(str(tmp_path / 'native.nii.gz'), 'rb').read() != open(str(tmp_path / 'zlib.nii.gz'), 'rb').read()
+
+
+def test_sparse_member_from_index_and_values():
+    """scs_gz_member_scatter: the member of `n` fill elements with values at given indices equals the member's worth of a NumPy
+    array built the same way - for a zero and a non-zero fill, several element sizes, duplicate indices (the later one wins) -
+    and an index outside the member is an error, not a write."""
+    import zlib
+    rng = np.random.RandomState(7)
+    for dtype, fill in ((np.float64, 0.0), (np.int16, 0), (np.int16, 9), (np.uint8, 3), (np.float32, -1.5)):
+        n = 50000
+        idx = np.sort(rng.choice(n, 700, replace=False)).astype(np.int64)
+        idx = np.concatenate([idx, idx[:5]])                                 # duplicates
+        vals = (rng.rand(idx.size) * 100).astype(dtype)
+        ref = np.full(n, fill, dtype=dtype)
+        ref[idx] = vals
+        m = _hip.gz_member_scatter(n, dtype(fill), idx, vals)
+        assert zlib.decompress(m, 31) == ref.tobytes(), dtype
+    assert zlib.decompress(_hip.gz_member_scatter(10, np.float64(0), np.zeros(0, np.int64), np.zeros(0, np.float64)), 31) == bytes(80)
+    with pytest.raises(IOError):
+        _hip.gz_member_scatter(100, np.int16(0), np.array([100], np.int64), np.array([1], np.int16))
+    with pytest.raises(ValueError):
+        _hip.gz_member_scatter(100, np.int16(0), np.array([1, 2], np.int64), np.array([1], np.int16))

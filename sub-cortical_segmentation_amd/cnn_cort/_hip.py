@@ -135,7 +135,7 @@ def _table(x, cols, what, dtype):
 
 # ---- libscs_io.so: host-side file helpers (include/scs_io.h).  No HIP dependency: safe to load before torch has brought its own
 # HIP runtime into the process (libscs.so must NOT be: it would pull /opt/rocm's ahead of torch's and leave the process with two).
-IO_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), 'libscs_io.so')
+IO_LIB_PATH = os.environ.get('SCS_IO_LIB_PATH') or os.path.join(os.path.dirname(LIB_PATH), 'libscs_io.so')   # (override: sanitizer builds)
 IO_SIGNATURES = {
     'scs_io_last_error': (_c.c_char_p, []),
     'scs_gz_gather': (_c.c_int, [_c.c_char_p, _vp, _c.c_int64, _c.c_int, _vp, _c.POINTER(_c.c_int64)]),

@@ -30,6 +30,7 @@
 #include "conv_mfma.h"
 #include "gemm_mfma.h"
 #include "dense_chain.h"
+#include "conv5_bwd.h"
 #include "scs_ctx.h"
 #include "wgrad_mfma.h"
 #include "train_cfg.h"
@@ -153,8 +154,8 @@ static int train_ensure(scs_ctx* h, int n) {
         for (int t = 0; t < kTowers; ++t)
             for (int i = 1; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
-        SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats) * sizeof(float)));
-        SCS_HIP(hipMemset(w->wT, 0, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats) * sizeof(float)));   // pad columns stay zero
+        SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats + kTowers * kC5WcFloats) * sizeof(float)));
+        SCS_HIP(hipMemset(w->wT, 0, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats + kTowers * kC5WcFloats) * sizeof(float)));   // pad columns stay zero
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)4 * kTowers * kWgPartFloats * sizeof(float)));
         SCS_HIP(hipMalloc(&w->mom, (size_t)kTowers * 100 * sizeof(double)));
         // coefficient tables: per tower and conv layer 64 x (float2 + float4 + float4), then the conv1 tables
@@ -239,6 +240,7 @@ struct PrepArgs {
     uint8_t* masks; size_t mask_total; uint64_t seed;       // masks == null: the caller supplied them
     const float* fc2W; float* w2p;                           // fc_2.W [555][270] -> [556][272] zero padded
     unsigned int* chain_counter;                             // cluster barrier counters of the dense chain: zeroed here
+    const float* c5W; float* wc5; int c5_tower_stride;       // conv5.W [60][40][9] of tower 0 (towers c5_tower_stride apart) -> Wc [3][60][368]
 };
 
 // blockIdx.y selects the job:
@@ -294,6 +296,10 @@ __device__ __forceinline__ void prep_body(const PrepArgs& a, int job) {
             if (c == 0) a.yb[row] = a.y[src];
         }
         for (int e = t0; e < kChainCounterWords; e += stride) a.chain_counter[e] = 0u;
+        for (int e = t0; e < kTowers * 60 * 360; e += stride) {           // Wc[t][o][c*9 + tap] = W[t][o][c][8 - tap]
+            const int t = e / 21600, f = e - t * 21600, o = f / 360, rem = f - o * 360, c = rem / 9, k = rem - c * 9;
+            a.wc5[(size_t)t * kC5WcFloats + o * kC5WS + c * 9 + (8 - k)] = a.c5W[(size_t)t * a.c5_tower_stride + f];
+        }
         for (int e = t0; e < kW2Floats; e += stride) {
             const int k = e / kFC2ld, c = e - k * kFC2ld;
             a.w2p[e] = (k < kFC1 + kAtlas && c < kFC2) ? a.fc2W[(size_t)k * kFC2 + c] : 0.f;
@@ -810,6 +816,7 @@ static int set_train_attrs(TrainWs* w, int device) {
     SCS_HIP(conv_set_attr<TF3N>()); SCS_HIP(conv_set_attr<TF4N>()); SCS_HIP(conv_set_attr<DG5N>()); SCS_HIP(conv_set_attr<DG4N>());
     SCS_HIP(conv_set_attr<DG3N>());
     SCS_HIP(wgrad_set_attr<WG2>()); SCS_HIP(wgrad_set_attr<WG3>()); SCS_HIP(wgrad_set_attr<WG4>()); SCS_HIP(wgrad_set_attr<WG5>());
+    SCS_HIP(conv5_backward_set_attr());
     w->attr_device = device;
     return SCS_OK;
 }
@@ -867,6 +874,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     float* wT1 = wT2 + 270 * kTld;            // [540][544]  = FC1.W^T
     float* wTd = wT1 + 540 * kTld;            // [3][180][544] = d1.W^T
     float* w2p = wTd + 3 * 180 * kTld;        // [556][272]  = fc_2.W zero padded
+    float* wc5 = w2p + kW2Floats;             // [3][60][368] = conv5.W of every tower in correlation form (conv5_bwd.h)
     {
         PrepArgs pa{};
         for (int t = 0; t < kTowers; ++t) {
@@ -879,6 +887,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
         pa.n_rows = index ? x0.n_samples : n;
         pa.fc2W = P + H.fc2W; pa.w2p = w2p; pa.chain_counter = w->chain_counter;
+        pa.c5W = P + T0.convW[4]; pa.wc5 = wc5; pa.c5_tower_stride = kTowerFloats;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
         // ---- forward, training mode: the input moments ride in the same launch
         run(ST_PREP, st, [&] {
@@ -1041,8 +1050,13 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     WgFinalArgs fa{};
     fa.grads = G; fa.tower_stride = kTowerFloats;
     constexpr int kDgBands[kConvs] = {0, DG2::NB, DG3::NB, DG4::NB, DG5::NB};
+    // conv5 block: data gradient + weight gradient as one launch of two small GEMMs per workgroup (conv5_bwd.h) up to
+    // kC5MaxBatch; SCS_C5_FUSED_MAX_BATCH overrides the bound (0: the generic kernels; tests run both forms)
+    const char* c5_env = getenv("SCS_C5_FUSED_MAX_BATCH");
+    const bool c5_fused = n <= (c5_env ? std::min(atoi(c5_env), kC5MaxBatch) : kC5MaxBatch);
+    const int c5_units = conv5_backward_workgroups(n);
     const bool kDgFin[kConvs + 1] = {false, DG2::FIN != 0, DG3::FIN != 0 && fin_in_kernel, DG4::FIN != 0 && fin_in_kernel,
-                                     DG5::FIN != 0 && fin_in_kernel, false};
+                                     c5_fused ? fin_in_kernel : (DG5::FIN != 0 && fin_in_kernel), false};
     for (int i = kConvs - 1; i >= 1; --i) {
         const int C = kCout[i], Hh = kHout[i];
         const double count = (double)n * Hh * Hh;
@@ -1055,10 +1069,47 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             });
         } else if (!kDgFin[i + 1]) {
             run(ST_FINB4 + 2 * (kConvs - 2 - i), st, [&] {
-                hipLaunchKernelGGL(bn_bwd_final_kernel<false>, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, n * kDgBands[i + 1], count, C,
+                const int units = (i + 1 == kConvs - 1 && c5_fused) ? c5_units : n * kDgBands[i + 1];
+                hipLaunchKernelGGL(bn_bwd_final_kernel<false>, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, units, count, C,
                                    c3(w->low4, i), p3(w->cf4, i), G, T0.bn[i], kTowerFloats, CPtr3{}, CPtr3{}, n);
             });
         }                                                               // else: the data-gradient kernel of layer i+1 finalized layer i
+        if (i == kConvs - 1 && c5_fused) {
+            // conv5 block: d z, the weight-gradient partial of every four patch-towers, the data gradient and the conv4 block's
+            // (d beta, d gamma) sums in one launch on the caller's stream; nothing of this layer goes to the side stream
+            C5BArgs b{};
+            float* part = w->wg_part + (size_t)(i - 1) * kTowers * kWgPartFloats;
+            for (int t = 0; t < kTowers; ++t) {
+                b.Z5[t] = w->Z[t][i]; b.dH5[t] = dUp.p[t]; b.cf5[t] = reinterpret_cast<const float*>(w->cf4[t][i]); b.X5[t] = w->X[t][i];
+                b.Wc[t] = wc5 + (size_t)t * kC5WcFloats; b.dX[t] = w->dX[t][i];
+                b.Z4[t] = w->Z[t][i - 1]; b.low4[t] = reinterpret_cast<const float*>(w->low4[t][i - 1]);
+            }
+            b.stats = w->stat_part; b.part = part; b.n = n;
+            b.fin_on = fin_in_kernel ? 1 : 0;
+            b.fin.counter = w->fin_counter; b.fin.grp = w->fin_grp; b.fin.count = (double)n * kHout[i - 1] * kHout[i - 1];
+            for (int t = 0; t < kTowers; ++t) { b.fin.bn[t] = G + T0.bn[i - 1] + t * kTowerFloats; b.fin.coef[t] = reinterpret_cast<float*>(w->cf4[t][i - 1]); }
+            static const bool c5_stamps = getenv("SCS_C5_STAMPS") != nullptr;          // diagnostic: phase times of the launch (stderr)
+            if (c5_stamps && !w->chain_stamps)
+                SCS_HIP(hipMalloc(&w->chain_stamps, (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps * sizeof(unsigned long long)));
+            b.stamps = c5_stamps ? w->chain_stamps : nullptr;
+            run(ST_DG5, st, [&] { conv5_backward_launch(b, st); });
+            if (c5_stamps && (size_t)kTowers * c5_units * 8 <= (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps) {
+                SCS_HIP(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hs((size_t)kTowers * c5_units * 8);
+                SCS_HIP(hipMemcpy(hs.data(), w->chain_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                double d[7] = {0, 0, 0, 0, 0, 0, 0};
+                unsigned long long t0 = ~0ull, t1 = 0;
+                const int wgs = kTowers * c5_units;
+                for (int g2 = 0; g2 < wgs; ++g2) {
+                    for (int k = 1; k <= 6; ++k) d[k] += (double)(hs[g2 * 8 + k] - hs[g2 * 8 + k - 1]) * 0.01 / wgs;
+                    t0 = std::min(t0, hs[g2 * 8]); t1 = std::max(t1, hs[g2 * 8 + 6]);
+                }
+                fprintf(stderr, "conv5 backward, n = %d, %d workgroups, span %.2f us: stage %.2f | wgrad GEMM + partial store %.2f | dgrad GEMM + Y %.2f | "
+                                "col2im %.2f | Z4 to LDS + sums %.2f | reduce + store %.2f\n", n, wgs, (double)(t1 - t0) * 0.01, d[1], d[2], d[3], d[4], d[5], d[6]);
+            }
+            fa.j[i - 1] = WgFinalJob{part, c5_units, kCin[i], C, T0.convW[i]};
+            continue;
+        }
         // data gradient (d z_i while staging, stored for the weight gradient; epilogue: partial sums of layer i-1)
         ConvArgs a{};
         a.n = n;

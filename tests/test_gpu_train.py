@@ -434,6 +434,37 @@ def test_dense_head_as_one_launch_gives_the_bits_of_the_layer_launches(weights, 
         assert np.array_equal(got, ref), '%s differ between the one-launch dense head and the layer launches at n = %d' % (what, n)
 
 
+@pytest.mark.parametrize('n', [1, 3, 37, 256, 257])
+def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monkeypatch, n):
+    """Up to batch 768 the conv5 block's data gradient, weight gradient and the conv4 block's (d beta, d gamma) sums are one launch
+    of two small GEMMs per workgroup (csrc/conv5_bwd.h), beyond that the generic data- and weight-gradient kernels.  Same draws
+    and dropout seeds through both forms: every gradient array agrees to 2e-6 of its scale (the sums are taken in a different
+    order, nothing else differs) and both are deterministic."""
+    from cnn_cort import synth, _hip
+    out = {}
+    for form, bound in (("generic", "0"), ("fused", "1024"), ("fused again", "1024")):
+        monkeypatch.setenv('SCS_C5_FUSED_MAX_BATCH', bound)
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        st = torch.cuda.current_stream().cuda_stream
+        ax, co, sa, at = synth.patch_batch(n, seed=900 + n)
+        y = np.random.RandomState(n).randint(0, 15, n).astype(np.uint8)
+        loss = h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=21, stream=st)
+        out[form] = (loss, P.flat_to_params(arena(h, 'grad')))
+        h.close()
+    assert out['fused'][0] == out['generic'][0]                                  # the forward pass is the same code
+    worst = 0.0
+    for name, shapes in P.LAYER_SPEC:
+        for i, _ in enumerate(shapes):
+            ref, got = out['generic'][1][name][i], out['fused'][1][name][i]
+            assert np.array_equal(got, out['fused again'][1][name][i]), name
+            scale = max(np.abs(ref).max(), 1e-6)
+            err = np.abs(got - ref).max() / scale
+            worst = max(worst, err)
+            assert err <= (2e-6 if n > 1 else 1e-3), '%s[%d]: %g of scale %g' % (name, i, err, scale)
+    print('n = %d: fused vs generic conv5 backward, worst relative difference %.3g' % (n, worst))
+
+
 def _run_ranks(worker, out_dir, backend, world=2):
     import os
     import socket

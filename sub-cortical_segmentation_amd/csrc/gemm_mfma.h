@@ -450,10 +450,13 @@ struct WgGroupArgs {
     const float* loss_rows; float* loss_mean;      // one extra workgroup (blockIdx.z = kWgProblems): mean of the K per-row losses
 };
 
-template <int CH_ = 32>
+// Workgroup tile: 16 MT rows x 16 NT columns.  32 x 64 makes the six problems of the training step 405 workgroups - one
+// generation at two per CU - where 16 x 48 made 1 043 (profiles/r03_notes.txt: 28 -> 17 us).
+constexpr int kWgMT = 2, kWgNT = 4;
+template <int CH_ = 16>
 __global__ __launch_bounds__(256, 2) void dense_wgrad_kernel(WgGroupArgs g) {
-    constexpr int NT = 3, CH = CH_;
-    __shared__ f32x4 s_r[4 * NT * 64];
+    constexpr int MT = kWgMT, NT = kWgNT, CH = CH_;
+    __shared__ f32x4 s_r[4 * MT * NT * 64];
     if ((int)blockIdx.z == kWgProblems) {
         // the batch-mean loss: one workgroup, double, fixed order (lanes by shuffle, then waves 0..3)
         if (blockIdx.x != 0 || blockIdx.y != 0 || !g.loss_rows) return;
@@ -471,51 +474,63 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_kernel(WgGroupArgs g) {
 #pragma unroll
     for (int i = 1; i < kWgProblems; ++i) if ((int)blockIdx.z == i) P = g.p[i];
     const int rows = P.M + (P.bias_out ? 1 : 0);
-    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 48;
+    const int m0 = blockIdx.x * 16 * MT, n0 = blockIdx.y * 16 * NT;
     if (m0 >= rows || n0 >= P.N) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
     const int steps = (g.K + 3) / 4, per = (steps + 3) / 4;
     const int s_beg = min(steps, wave * per), s_end = min(steps, s_beg + per);
-    const int m = m0 + lr;
-    const bool m_act = m < P.M, m_one = (m == P.M) && P.bias_out != nullptr;
-    const float* __restrict__ acol = P.A + (m_act ? m : 0);
+    bool m_act[MT], m_one[MT], col_ok[NT];
+    const float* __restrict__ acol[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = m0 + 16 * t + lr;
+        m_act[t] = m < P.M; m_one[t] = (m == P.M) && P.bias_out != nullptr;
+        acol[t] = P.A + (m_act[t] ? m : 0);
+    }
     const float* __restrict__ wcol = P.W + n0 + lr;
-    bool col_ok[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) col_ok[j] = n0 + j * 16 + lr < P.N;
-    f32x4 acc[NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s0 = s_beg; s0 < s_end; s0 += CH) {
-        float av[CH], bv[CH][NT];
+        float av[CH][MT], bv[CH][NT];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int k = 4 * (s0 + i) + kq;
             const bool on = (s0 + i) < s_end && k < g.K;
-            av[i] = on ? (m_act ? acol[(size_t)k * P.lda] : (m_one ? 1.f : 0.f)) : 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) av[i][t] = on ? (m_act[t] ? acol[t][(size_t)k * P.lda] : (m_one[t] ? 1.f : 0.f)) : 0.f;
 #pragma unroll
             for (int j = 0; j < NT; ++j) bv[i][j] = (on && col_ok[j]) ? wcol[(size_t)k * P.ldw + j * 16] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i][j], acc[j], 0, 0, 0);
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][t], bv[i][j], acc[t][j], 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) s_r[(wave * NT + j) * 64 + lane] = acc[j];
-    __syncthreads();
-    if (wave < NT) {
-        const int j = wave;
-        f32x4 v = s_r[(0 * NT + j) * 64 + lane];
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int q = 1; q < 4; ++q) { const f32x4 u = s_r[(q * NT + j) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        for (int j = 0; j < NT; ++j) s_r[(wave * MT * NT + t * NT + j) * 64 + lane] = acc[t][j];
+    __syncthreads();
+    // the four waves' partial tiles are added in wave order; wave w finishes tiles w, w + 4 of the MT x NT
+    for (int e = wave; e < MT * NT; e += 4) {
+        const int t = e / NT, j = e - t * NT;
+        f32x4 v = s_r[(0 * MT * NT + e) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { const f32x4 u = s_r[(q * MT * NT + e) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
         const int col = n0 + j * 16 + lr;
         if (col < P.N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int orow = m0 + kq * 4 + r;
+                const int orow = m0 + 16 * t + kq * 4 + r;
                 if (orow < P.M) P.C[(size_t)orow * P.ldc + col] = v[r];
                 else if (orow == P.M && P.bias_out) P.bias_out[col] = v[r];
             }
@@ -529,7 +544,8 @@ inline void dense_wgrad_launch(const WgGroupArgs& g, int nproblems, hipStream_t 
         const int rows = g.p[i].M + (g.p[i].bias_out ? 1 : 0);
         mr = rows > mr ? rows : mr; mc = g.p[i].N > mc ? g.p[i].N : mc;
     }
-    hipLaunchKernelGGL(dense_wgrad_kernel<>, dim3((mr + 15) / 16, (mc + 47) / 48, nproblems + (g.loss_rows ? 1 : 0)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(dense_wgrad_kernel<>, dim3((mr + 16 * kWgMT - 1) / (16 * kWgMT), (mc + 16 * kWgNT - 1) / (16 * kWgNT), nproblems + (g.loss_rows ? 1 : 0)),
+                       dim3(256), 0, st, g);
 }
 
 #ifndef SCS_GEMM_MT

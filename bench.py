@@ -188,7 +188,8 @@ def measured_traffic(key):
 TRAIN_CONV_MACS = {'conv1+conv2 fwd': 3 * (162000 + 2822400), 'conv3 fwd': 3 * 1036800, 'conv4 fwd': 3 * 1440000, 'conv5 fwd': 3 * 194400,
                    'conv5 dgrad': 3 * 194400, 'conv4 dgrad': 3 * 1440000, 'conv3 dgrad': 3 * 1036800,
                    'conv2 dgrad + layer-1 sums': 3 * (2822400 + 162000), 'conv5 wgrad': 3 * 194400, 'conv4 wgrad': 3 * 1440000,
-                   'conv3 wgrad': 3 * 1036800, 'conv2 wgrad': 3 * 2822400}
+                   'conv3 wgrad': 3 * 1036800, 'conv2 wgrad': 3 * 2822400,
+                   'conv5 backward, one launch (dgrad + wgrad + bn4 bwd sums)': 3 * 2 * 194400}
 
 
 def train_inputs(torch, B, rank, dev):

@@ -40,14 +40,15 @@ namespace scs {
 // profiling stages of scs_train_step_profiled (one per launch)
 enum Stage { ST_PREP, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
              ST_FC2, ST_HEAD, ST_DCAT, ST_DFEAT, ST_DH5, ST_BN5B, ST_DG5, ST_FINB4, ST_DG4, ST_FINB3, ST_DG3, ST_FINB2, ST_DG2,
-             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_CHAIN, ST_COUNT };
+             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_CHAIN, ST_C5B, ST_COUNT };
 static const char* const kStageNames[ST_COUNT] = {
     "prep (weight packs, dropout masks, atlas columns) + input moments", "bn1 finalize", "conv1+conv2 fwd", "bn2 finalize",
     "conv3 fwd", "bn3 finalize", "conv4 fwd", "bn4 finalize", "conv5 fwd", "bn5 + dropout", "d1 x3 fwd", "FC1 fwd", "fc_2 fwd",
     "out + softmax + CE", "fc_2 dgrad", "FC1 dgrad", "d1 x3 dgrad", "bn5 backward", "conv5 dgrad", "bn4 bwd finalize", "conv4 dgrad",
     "bn3 bwd finalize", "conv3 dgrad", "bn2 bwd finalize", "conv2 dgrad + layer-1 sums", "layer-1 gradients", "dense wgrad (grouped)",
     "conv5 wgrad", "conv4 wgrad", "conv3 wgrad", "conv2 wgrad", "conv3..5 wgrad reduce", "conv2 wgrad reduce",
-    "dense head, one launch (d1 x3, FC1, fc_2, out + softmax + CE, fc_2 / FC1 / d1 dgrad)"};
+    "dense head, one launch (d1 x3, FC1, fc_2, out + softmax + CE, fc_2 / FC1 / d1 dgrad)",
+    "conv5 backward, one launch (dgrad + wgrad + bn4 bwd sums)"};
 
 }  // namespace scs
 
@@ -1092,7 +1093,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             if (c5_stamps && !w->chain_stamps)
                 SCS_HIP(hipMalloc(&w->chain_stamps, (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps * sizeof(unsigned long long)));
             b.stamps = c5_stamps ? w->chain_stamps : nullptr;
-            run(ST_DG5, st, [&] { conv5_backward_launch(b, st); });
+            run(ST_C5B, st, [&] { conv5_backward_launch(b, st); });
             if (c5_stamps && (size_t)kTowers * c5_units * 8 <= (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps) {
                 SCS_HIP(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hs((size_t)kTowers * c5_units * 8);

@@ -29,6 +29,7 @@ TRAIN = {
     'conv4 fwd': r'^conv<40,40,12,1,3,4,',
     'conv5 fwd': r'^conv<40,60,5,\d+,3,5,',
     'conv5 dgrad': r'^conv<60,40,7,',
+    'conv5 backward, one launch (dgrad + wgrad + bn4 bwd sums)': r'conv5_backward_kernel',
     'conv4 dgrad': r'^conv<40,40,14,',
     'conv3 dgrad': r'^conv<40,20,16,',
     'conv2 dgrad + layer-1 sums': r'^conv<20,20,32,',

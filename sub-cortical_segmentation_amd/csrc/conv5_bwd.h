@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
     float4 z4v[Z_IT];
 
     // ---- stage: d z (formed here), X5, Wc - every load of a thread in flight before the first LDS write; the raw conv4 planes
-    // the epilogue needs are requested now too and wait in registers (their LDS space is Wc's, free after the col2im step)
+    // the epilogue needs are requested right behind and wait in registers (their LDS space is Wc's, free after the col2im step)
     {
         constexpr int DZ_IT = kC5Rows * 64 / kC5Threads;                           // 6
         constexpr int X_IT = (kC5XFloats / 4 + kC5Threads - 1) / kC5Threads;       // 2
@@ -92,8 +92,6 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
 #pragma unroll
         for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; wv[k] = wc[min(e, kC5WcFloats / 4 - 1)]; }
 #pragma unroll
-        for (int k = 0; k < Z_IT; ++k) { const int e = tid + kC5Threads * k; z4v[k] = (e < ng * 1000) ? z4g[e] : float4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
         for (int k = 0; k < DZ_IT; ++k) {
             const int e = tid + kC5Threads * k, r = e >> 6, o = e & 63;
             const bool ok = r < ng * 9 && o < 60;
@@ -105,6 +103,9 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
 #pragma unroll
         for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; if (e < kC5WcFloats / 4) reinterpret_cast<float4*>(s_w)[e] = wv[k]; }
     }
+    // (requested behind the staging loads: memory operations retire in order, so in front of them they would hold up the first LDS write)
+#pragma unroll
+    for (int k = 0; k < Z_IT; ++k) { const int e = tid + kC5Threads * k; z4v[k] = (e < ng * 1000) ? z4g[e] : float4{0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();
     stamp(1);
 

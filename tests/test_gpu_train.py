@@ -434,11 +434,12 @@ def test_dense_head_as_one_launch_gives_the_bits_of_the_layer_launches(weights, 
         assert np.array_equal(got, ref), '%s differ between the one-launch dense head and the layer launches at n = %d' % (what, n)
 
 
-@pytest.mark.parametrize('n', [1, 3, 37, 256, 257])
+@pytest.mark.parametrize('n', [1, 3, 37, 256, 257, 1024])
 def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monkeypatch, n):
-    """Up to batch 768 the conv5 block's data gradient, weight gradient and the conv4 block's (d beta, d gamma) sums are one launch
-    of two small GEMMs per workgroup (csrc/conv5_bwd.h), beyond that the generic data- and weight-gradient kernels.  Same draws
-    and dropout seeds through both forms: every gradient array agrees to 2e-6 of its scale (the sums are taken in a different
+    """Up to batch 1024 the conv5 block's data gradient, weight gradient and the conv4 block's (d beta, d gamma) sums are one launch
+    of two small GEMMs per workgroup (csrc/conv5_bwd.h), beyond that the generic data- and weight-gradient kernels (1024 = 256
+    partials per tower: what the partial buffer holds).  Same draws
+    and dropout seeds through both forms: every gradient array agrees to 2e-6 of its scale (1e-5 at batch 1024; the sums are taken in a different
     order, nothing else differs) and both are deterministic."""
     from cnn_cort import synth, _hip
     out = {}
@@ -461,7 +462,8 @@ def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monke
             scale = max(np.abs(ref).max(), 1e-6)
             err = np.abs(got - ref).max() / scale
             worst = max(worst, err)
-            assert err <= (2e-6 if n > 1 else 1e-3), '%s[%d]: %g of scale %g' % (name, i, err, scale)
+            # (n = 1: conv5's BN sees nine values per channel; n = 1024: the sums run over four times as many float32 terms)
+            assert err <= (1e-3 if n == 1 else 2e-6 if n <= 257 else 1e-5), '%s[%d]: %g of scale %g' % (name, i, err, scale)
     print('n = %d: fused vs generic conv5 backward, worst relative difference %.3g' % (n, worst))
 
 

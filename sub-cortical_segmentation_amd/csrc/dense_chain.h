@@ -27,12 +27,15 @@
 //     the kernel end: wrong placement is loud, never silent.
 // The grid (72 x ceil(row blocks / 8) workgroups of 512 threads, at most kChainMaxBatch rows) is co-resident by size.
 //
-// What it buys (profiles/r03_chain_stamps.txt, r03_notes.txt): a tile costs 7.5 - 8 us in either form - 2.7 us until the first
-// wave has its operands (1.4 us when they are hot), 3.5 us until the last wave is through its 80 MFMAs (two waves share a SIMD's
-// matrix pipe: 2.4 us is the floor of a 16 x 64 x 540 tile on one CU), 1 us reduction + stores, 0.9 us drain + barrier against
-// 2 - 3 us between dependent launches.  At batch 128 the step gains 1.5 % (0.467 against 0.475 ms), at 256 it loses 0.5 %; the
-// default bound is therefore 128.  Prefetching the weights - from the matrix waves, from extra waves, from spare workgroups on
-// the idle CUs - did not move the operand phase and is not kept.
+// What it buys (profiles/r03_chain_stamps.txt, r03_notes.txt): a 16 x 64 x 540 tile costs 7.5 - 8 us in either form - 2.7 us until
+// the first wave has its operands (1.4 us when they are hot), 3.5 us until the last wave is through its 80 MFMAs (two waves share a
+// SIMD's matrix pipe: 2.4 us is the floor of such a tile on one CU), 1 us reduction + stores, 0.9 us drain + barrier against 2 - 3 us
+// between dependent launches: with the layers one tile each the chain takes as long as the launches (65 - 68 us).  It pays through
+// what a launch cannot do: the three d1 data gradients of a member (K = 180 each: six of eight waves busy, three operand round
+// trips as launches or tiles) are ONE pass of 18 (tower, wave-partial) jobs over the 8 waves (chain_d1_dgrad): the chain drops to
+// ~50 us and the step by 2.8 % at batch 256 (0.584 against 0.601 ms) and 3 % at 128 (0.441 against 0.455), 2.7 % at 320 and 384 - shipped up to batch 384 (what the co-resident grid allows).
+// Prefetching the weights - from the matrix waves, from extra waves, from spare workgroups on the idle CUs - did not move the
+// operand phase and is not kept.
 #pragma once
 #include "gemm_mfma.h"
 
@@ -45,7 +48,7 @@ namespace scs {
 
 constexpr int kChainMembers = 9;                 // column blocks of 64 of a 540-wide layer = workgroups per cluster
 constexpr int kChainMaxBatch = 384;              // 24 clusters = 216 workgroups <= 256 CUs
-constexpr int kChainDefaultMaxBatch = 128;       // the step takes this form up to here unless SCS_DENSE_CHAIN_MAX_BATCH says otherwise
+constexpr int kChainDefaultMaxBatch = kChainMaxBatch;   // the step takes this form up to here unless SCS_DENSE_CHAIN_MAX_BATCH says otherwise
 constexpr int kChainLine = 32;                   // counter stride in words: one 128-byte line per counter
 constexpr int kXcds = 8;
 constexpr int kChainClustersPerXcd = (kChainMaxBatch / 16 + kXcds - 1) / kXcds;
@@ -284,6 +287,99 @@ __device__ __forceinline__ void chain_head(const DenseChainArgs& a, int row0, f3
     }
 }
 
+// The three d1 data gradients of a member (towers t = 0..2: dH5_t[16 x 64] = dfeat[:, 180 t ..] wTd_t, K = 180) in ONE pass.
+// As tiles of their own each is 12 groups of 16 k over 8 waves - six waves with two groups, two idle - and the three tiles cost
+// three operand round trips (17 us of the chain's 65).  Here the 18 (tower, wave-partial) jobs - partial p of a tile = the MFMA
+// chain over groups 2p, 2p + 1, exactly what wave p computes in gemm_splitk4_kernel - are dealt to the 8 waves (3, 3, 2, ...),
+// all their operands are requested together, and the partials are added per tile in the same order (p = 0..5, then the two
+// zero partials of the idle waves: x + 0 is not x for x = -0), so the bits are those of the layer launches.
+// s_p: 18 * 4 * 64 f32x4 of LDS.
+constexpr int kChainS7Jobs = 18, kChainS7Floats = kChainS7Jobs * 4 * 64 * 4;
+__device__ __forceinline__ void chain_d1_dgrad(const DenseChainArgs& a, int M, int m0, int n0, f32x4* s_p, ChainStamper& ts) {
+    ts.hit();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, kq = lane >> 4;
+    const int row = m0 + lr;
+    const bool row_ok = row < M;
+    constexpr int JW = 3;                                       // jobs per wave (the third only in waves 0, 1)
+    float4 av[JW][2], wv[JW][2][4];
+    unsigned char e_mask[2][4];
+    // the two (tower, column set) pairs this wave finishes: e = wave, wave + 8 of the 12
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int e = wave + 8 * f, t = min(e >> 2, kTowers - 1), jc = e & 3;
+        const GemmProblem& P = t == 0 ? a.dh5[0] : (t == 1 ? a.dh5[1] : a.dh5[2]);
+        const int ecl = min(n0 + 4 * lr + jc, kFlat - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e_mask[f][r] = P.mask[(size_t)min(m0 + kq * 4 + r, M - 1) * P.ldm + ecl];
+    }
+#pragma unroll
+    for (int q = 0; q < JW; ++q) {
+        const int job = min(wave + 8 * q, kChainS7Jobs - 1), t = job / 6, p = job - t * 6;
+        const GemmProblem& P = t == 0 ? a.dh5[0] : (t == 1 ? a.dh5[1] : a.dh5[2]);
+        const float* arow = P.A + (size_t)(row_ok ? row : 0) * P.lda;
+        const float* __restrict__ wcol = P.W + min(n0 + 4 * lr, P.NS - 4);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = 16 * (2 * p + u) + 4 * kq;
+            av[q][u] = *reinterpret_cast<const float4*>(arow + (k < kD1 ? k : 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[q][u][i] = *reinterpret_cast<const float4*>(wcol + (size_t)min(k + i, kD1 - 1) * P.NS);
+        }
+    }
+    const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
+    const bool col_ok = n0 + 4 * lr < a.dh5[0].NS;
+    __syncthreads();                                            // s_p may still be read by the previous tile's epilogue
+#pragma unroll
+    for (int q = 0; q < JW; ++q) {
+        const int job = wave + 8 * q;
+        if (job >= kChainS7Jobs) continue;
+        const int p = job % 6;
+        f32x4 acc[4];
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) acc[jc] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = 16 * (2 * p + u) + 4 * kq;
+            const float4 av4 = (row_ok && k < kD1) ? av[q][u] : zero4;
+            const float a4[4] = {av4.x, av4.y, av4.z, av4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 w = (col_ok && k + i < kD1) ? wv[q][u][i] : zero4;
+                const float w4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int jc = 0; jc < 4; ++jc) acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], w4[jc], acc[jc], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) s_p[(job * 4 + jc) * 64 + lane] = acc[jc];
+    }
+    __syncthreads();
+    ts.hit();
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int e = wave + 8 * f;
+        if (e >= 4 * kTowers) continue;
+        const int t = e >> 2, jc = e & 3;
+        const GemmProblem& P = t == 0 ? a.dh5[0] : (t == 1 ? a.dh5[1] : a.dh5[2]);
+        f32x4 v = s_p[((t * 6 + 0) * 4 + jc) * 64 + lane];
+#pragma unroll
+        for (int p = 1; p < 6; ++p) { const f32x4 u = s_p[((t * 6 + p) * 4 + jc) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+#pragma unroll
+        for (int z = 0; z < 2; ++z) { v[0] += 0.f; v[1] += 0.f; v[2] += 0.f; v[3] += 0.f; }    // the idle waves' partials of the layer launch
+        const int ecol = n0 + 4 * lr + jc;
+        if (ecol < kFlat) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = m0 + kq * 4 + r;
+                if (orow < M) P.C[(size_t)orow * P.ldc + ecol] = e_mask[f][r] ? 2.f * v[r] : 0.f;
+            }
+        }
+    }
+    ts.hit();
+}
+
 // The chain as a wave of role ROLE executes it: the same tiles and the same workgroup barriers in the same order.
 template <int ROLE>
 __device__ __forceinline__ void chain_body(const DenseChainArgs& a, int j, int m0, unsigned int* ctr, f32x4* s_r, float (*s_d)[17],
@@ -321,16 +417,13 @@ __device__ __forceinline__ void chain_body(const DenseChainArgs& a, int j, int m
         ok = chain_barrier<ROLE>(ctr, 6, s_flag, ts);
     }
     ts.seek(48);
-    if (ok) {                                                   // d1 x3 data gradients: three tiles per member
-        chain_tile<ROLE>(a.dh5[0], n, kD1, kD1, kFlat, 0, m0, n0, s_r, ts);
-        chain_tile<ROLE>(a.dh5[1], n, kD1, kD1, kFlat, 0, m0, n0, s_r, ts);
-        chain_tile<ROLE>(a.dh5[2], n, kD1, kD1, kFlat, 0, m0, n0, s_r, ts);
-    }
+    if (ok) chain_d1_dgrad(a, n, m0, n0, s_r, ts);              // d1 x3 data gradients: the member's three tiles in one pass
     if (!ok && threadIdx.x == 0) a.loss_rows[m0] = __builtin_nanf("");   // a barrier gave up: the step's loss says so
 }
 
 __global__ __launch_bounds__(512, 1) void dense_chain_kernel(DenseChainArgs a) {
-    __shared__ f32x4 s_r[GemmSplitK4::NW * 4 * 64];
+    extern __shared__ __attribute__((aligned(16))) float smem_chain[];   // kChainLdsBytes
+    f32x4* s_r = reinterpret_cast<f32x4*>(smem_chain);                  // 8 * 4 * 64 partial tiles; 18 * 4 * 64 in the last stage
     __shared__ float s_d[16][17];
     __shared__ int s_flag;
     const int n = a.n, nblocks = (n + 15) / 16;
@@ -354,6 +447,11 @@ __global__ __launch_bounds__(512, 1) void dense_chain_kernel(DenseChainArgs a) {
     else chain_body<1>(a, j, m0, ctr, s_r, s_d, &s_flag, ts);
 }
 
+constexpr size_t kChainLdsBytes = (size_t)kChainS7Floats * 4;
+static_assert(kChainS7Jobs * 4 >= GemmSplitK4::NW * 4, "the last stage's partials are the larger set");
+inline hipError_t dense_chain_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes);
+}
 inline dim3 dense_chain_grid(int n) { return dim3(kXcds * kChainMembers * (((n + 15) / 16 + kXcds - 1) / kXcds)); }
 
 inline bool dense_chain_ok(int n, const GemmArgs& probe, int nproblems) { return n > 0 && n <= kChainMaxBatch && gemm_vec4_ok(probe, nproblems); }

@@ -818,6 +818,7 @@ static int set_train_attrs(TrainWs* w, int device) {
     SCS_HIP(conv_set_attr<DG3N>());
     SCS_HIP(wgrad_set_attr<WG2>()); SCS_HIP(wgrad_set_attr<WG3>()); SCS_HIP(wgrad_set_attr<WG4>()); SCS_HIP(wgrad_set_attr<WG5>());
     SCS_HIP(conv5_backward_set_attr());
+    SCS_HIP(dense_chain_set_attr());
     w->attr_device = device;
     return SCS_OK;
 }
@@ -998,7 +999,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         }
         ch.stamps = stamps_on ? w->chain_stamps : nullptr;
         if (stamps_on) SCS_HIP(hipMemsetAsync(w->chain_stamps, 0, (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps * sizeof(unsigned long long), st));
-        run(ST_CHAIN, st, [&] { hipLaunchKernelGGL(dense_chain_kernel, dense_chain_grid(n), dim3(512), 0, st, ch); });
+        run(ST_CHAIN, st, [&] { hipLaunchKernelGGL(dense_chain_kernel, dense_chain_grid(n), dim3(512), kChainLdsBytes, st, ch); });
         if (stamps_on) {                                                // diagnostic: where the chain's time goes, per stage (stderr)
             SCS_HIP(hipStreamSynchronize(st));
             const int wgs = ((n + 15) / 16) * kChainMembers;

@@ -25,7 +25,10 @@
 //   * the counters are zeroed by the prep launch at the start of every step.  A poll that does not complete within
 //     kChainSpinLimit rounds (an XCD that did not receive whole clusters) gives up, poisons the loss of its rows with NaN and lets
 //     the kernel end: wrong placement is loud, never silent.
-// The grid (72 x ceil(row blocks / 8) workgroups of 512 threads, at most kChainMaxBatch rows) is co-resident by size.
+// The grid (72 x ceil(row blocks / 8) workgroups of 512 threads, at most kChainMaxBatch rows) is co-resident by size.  Tickets are
+// taken in arrival order, so the first nine workgroups of a launch that become resident on an XCD always form a complete
+// cluster, finish and free their CUs: two training processes sharing one GPU (whose launches together may exceed the CUs) still
+// make progress - one of them holds at least nine of an XCD's 32 slots; four or more could starve each other into the spin limit.
 //
 // What it buys (profiles/r03_chain_stamps.txt, r03_notes.txt): a 16 x 64 x 540 tile costs 7.5 - 8 us in either form - 2.7 us until
 // the first wave has its operands (1.4 us when they are hot), 3.5 us until the last wave is through its 80 MFMAs (two waves share a

@@ -35,8 +35,10 @@
 // SIMD's matrix pipe: 2.4 us is the floor of such a tile on one CU), 1 us reduction + stores, 0.9 us drain + barrier against 2 - 3 us
 // between dependent launches: with the layers one tile each the chain takes as long as the launches (65 - 68 us).  It pays through
 // what a launch cannot do: the three d1 data gradients of a member (K = 180 each: six of eight waves busy, three operand round
-// trips as launches or tiles) are ONE pass of 18 (tower, wave-partial) jobs over the 8 waves (chain_d1_dgrad): the chain drops to
-// ~50 us and the step by 2.8 % at batch 256 (0.584 against 0.601 ms) and 3 % at 128 (0.441 against 0.455), 2.7 % at 320 and 384 - shipped up to batch 384 (what the co-resident grid allows).
+// trips as launches or tiles) are ONE pass of 18 (tower, wave-partial) jobs over the 8 waves (chain_d1_dgrad), and the out layer +
+// loss - a stage that kept one member of nine busy - is computed by every member in front of its fc_2 data-gradient tile
+// (chain_head_dcat): the chain drops to ~48 us and the step by 3 % at batch 256 (0.582 against 0.600 ms) and 4 % at 128 (0.438
+// against 0.455), 2.7 % at 320 and 384 - shipped up to batch 384 (what the co-resident grid allows).
 // Prefetching the weights - from the matrix waves, from extra waves, from spare workgroups on the idle CUs - did not move the
 // operand phase and is not kept.
 #pragma once
@@ -215,36 +217,75 @@ __device__ __forceinline__ void chain_tile(const GemmProblem& P, int M, int K4, 
     ts.hit();                                                   // [3] outputs issued
 }
 
-// head_train_kernel's body for rows [row0, row0 + 16) inside the chain's workgroup:
-// logits on waves 0..3 (the K split and the order of the partial sums of the stand-alone kernel), softmax on threads 0..255,
-// dR2's 17 column tiles over the 8 matrix waves.
-// R2 was written by other members of the cluster, dR2 is read by them.
-__device__ __forceinline__ void chain_head(const DenseChainArgs& a, int row0, f32x4* s_r, float (*s_d)[17]) {
+// out layer + loss + fc_2's data gradient as ONE stage.  The head of 16 rows is a few hundred MFMAs: as a stage of its own it ran
+// on one of the nine members while eight waited (7.8 us with its barrier).  Here EVERY member computes the head of its cluster's
+// rows (logits, softmax, d logits, dR2 = d logits outW' gated by R2) into LDS - member 0 also writes probs, d logits, the row losses
+// and dR2 for the weight gradients - and goes straight on with its dcat tile, A = dR2 from LDS; the tile's weights are requested
+// behind the head's own operands (loads retire in order) and arrive while the head computes.  Arithmetic and order of sums are
+// head_train_kernel's and gemm_splitk4_kernel's.  s_dr2: [16][kFC2ld] floats of LDS behind the partial tiles.
+template <int ROLE>
+__device__ __forceinline__ void chain_head_dcat(const DenseChainArgs& a, int j, int m0, int n0, f32x4* s_r, float (*s_d)[17], float* s_dr2,
+                                                ChainStamper& ts) {
+    ts.hit();
+    using T = GemmSplitK4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
     const int n = a.n;
-    __syncthreads();                                            // s_r: the previous tile's epilogue is done with it
+    const bool writer = j == 0;
+    // ---- the head's operands (waves 0..3: their K slice of R2 and outW)
+    constexpr int SPW = 17;
+    float hav[SPW], hbv[SPW];
     if (wave < 4) {
-        constexpr int SPW = 17;
-        const int arow = min(row0 + lr, n - 1);
-        const float* ap = a.R2 + (size_t)arow * kFC2ld + kq;
-        float av[SPW], bv[SPW];
+        const float* ap = a.R2 + (size_t)min(m0 + lr, n - 1) * kFC2ld + kq;
 #pragma unroll
         for (int i = 0; i < SPW; ++i) {
             const int k = 4 * (wave * SPW + i) + kq;
-            av[i] = k < kFC2 ? ap[4 * (wave * SPW + i)] : 0.f;
-            bv[i] = (k < kFC2 && lr < 15) ? a.outW[k * 15 + lr] : 0.f;
+            hav[i] = ap[k < kFC2 ? 4 * (wave * SPW + i) : 0];
+            hbv[i] = a.outW[min(k, kFC2 - 1) * 15 + min(lr, 14)];
         }
+    }
+    // ---- the dcat tile's weights and epilogue operands, behind them
+    const GemmProblem& P = a.dcat;
+    constexpr int K4 = kFC2ld, KM = kFC2, N = kFC1;
+    constexpr int groups = (K4 + 15) / 16, per = (groups + T::NW - 1) / T::NW;
+    const int g_beg = min(groups, wave * per), g_end = min(groups, g_beg + per);
+    const bool col_ok = n0 + 4 * lr < P.NS;
+    const float* __restrict__ wcol = P.W + min(n0 + 4 * lr, P.NS - 4);
+    float4 wv[per][4];
+#pragma unroll
+    for (int u = 0; u < per; ++u) {
+        const int k = (g_beg + u) < g_end ? 16 * (g_beg + u) + 4 * kq : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[u][i] = *reinterpret_cast<const float4*>(wcol + (size_t)min(k + i, KM - 1) * P.NS);
+    }
+    const int ecol = n0 + 4 * lr + wave;
+    float e_gate[4] = {1.f, 1.f, 1.f, 1.f};
+    unsigned char e_mask[4] = {1, 1, 1, 1};
+    if (ROLE == 0) {
+        const int ecl = min(ecol, N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int orow = min(m0 + kq * 4 + r, n - 1);
+            e_mask[r] = P.mask[(size_t)orow * P.ldm + ecl];
+            e_gate[r] = P.gate[(size_t)orow * P.ldg + ecl];
+        }
+    }
+    // ---- logits: wave w < 4 owns k-steps [17 w, 17 w + 17) of the 68
+    __syncthreads();                                            // s_r: the previous tile's epilogue is done with it
+    if (wave < 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < SPW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+        for (int i = 0; i < SPW; ++i) {
+            const int k = 4 * (wave * SPW + i) + kq;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(k < kFC2 ? hav[i] : 0.f, (k < kFC2 && lr < 15) ? hbv[i] : 0.f, acc, 0, 0, 0);
+        }
         s_r[wave * 64 + lane] = acc;
     }
     __syncthreads();
     if (tid < 256) {
         const int r = tid >> 4, c = tid & 15;
-        const int row = row0 + r;
+        const int row = m0 + r;
         const int src = (r >> 2) * 16 + c;
         const float z = (c < 15 ? a.outb[c] : 0.f) + ((s_r[0 * 64 + src][r & 3] + s_r[1 * 64 + src][r & 3]) + (s_r[2 * 64 + src][r & 3] + s_r[3 * 64 + src][r & 3]));
         float mx = c < 15 ? z : -3.0e38f;
@@ -258,36 +299,84 @@ __device__ __forceinline__ void chain_head(const DenseChainArgs& a, int row0, f3
         const int yi = row < n ? a.y[row] : 0;
         const float dl = (c < 15 && row < n) ? (pr - (c == yi ? 1.f : 0.f)) / (float)n : 0.f;
         s_d[r][c] = dl;
-        if (row < n) {
+        if (writer && row < n) {
             a.probs[(size_t)row * 16 + c] = c < 15 ? pr : 0.f;
             a.dlog[(size_t)row * 16 + c] = dl;
             if (c == yi) a.loss_rows[row] = -(z - mx - logf(sum));
         }
     }
     __syncthreads();
-    {
+    {   // dR2: 17 column tiles of 16 over the 8 waves; K = the 15 classes (4 k-steps)
         float a4[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) a4[s4] = s_d[lr][4 * s4 + kq];
         for (int t = wave; t < 17; t += 8) {
             const int col = 16 * t + lr;
-            float w4[4];
+            float w4[4], gate[4];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) { const int cl = 4 * s4 + kq; w4[s4] = (col < kFC2 && cl < 15) ? a.outW[col * 15 + cl] : 0.f; }
+            for (int s4 = 0; s4 < 4; ++s4) { const int cl = 4 * s4 + kq; w4[s4] = a.outW[min(col, kFC2 - 1) * 15 + min(cl, 14)]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gate[i] = a.R2[(size_t)min(m0 + 4 * kq + i, n - 1) * kFC2ld + min(col, kFC2 - 1)];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], w4[s4], acc, 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], (col < kFC2 && 4 * s4 + kq < 15) ? w4[s4] : 0.f, acc, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int orow = row0 + 4 * kq + i;
+                const int orow = m0 + 4 * kq + i;
+                const float v = (col < kFC2 && gate[i] > 0.f) ? acc[i] : 0.f;       // columns 270, 271: zero
+                s_dr2[(4 * kq + i) * kFC2ld + col] = v;
+                if (writer && orow < n) a.dR2[(size_t)orow * kFC2ld + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+    ts.hit();
+    // ---- the dcat tile: A = dR2 rows from LDS
+    f32x4 acc[4];
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) acc[jc] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool row_ok = m0 + lr < n;
+    const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < T::GMAX; ++u) {                         // (the slots beyond this stage's `per` multiply zeros, as in the stand-alone kernel)
+        const bool on = u < per && (g_beg + u) < g_end;
+        const int k = 16 * (g_beg + u) + 4 * kq;
+        float4 av = zero4;
+        if (u < per) av = *reinterpret_cast<const float4*>(s_dr2 + lr * kFC2ld + (on && k < K4 ? k : 0));
+        const float4 a4v = (on && row_ok && k < K4) ? av : zero4;
+        const float a4[4] = {a4v.x, a4v.y, a4v.z, a4v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 w = (u < per && on && col_ok && k + i < KM) ? wv[u < per ? u : 0][i] : zero4;
+            const float w4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int jc = 0; jc < 4; ++jc) acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], w4[jc], acc[jc], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                            // s_r: the softmax is done with the logits' partials
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) s_r[(wave * 4 + jc) * 64 + lane] = acc[jc];
+    __syncthreads();
+    if (ROLE == 0) {
+        const int jc = wave;
+        f32x4 v = s_r[(0 * 4 + jc) * 64 + lane];
+#pragma unroll
+        for (int q = 1; q < T::NW; ++q) { const f32x4 u = s_r[(q * 4 + jc) * 64 + lane]; v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        if (ecol < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = m0 + kq * 4 + r;
                 if (orow < n) {
-                    const float gate = col < kFC2 ? a.R2[(size_t)orow * kFC2ld + col] : 0.f;
-                    a.dR2[(size_t)orow * kFC2ld + col] = gate > 0.f ? acc[i] : 0.f;
+                    float x = v[r] + 0.f;                          // (no bias)
+                    x = e_mask[r] ? 2.f * x : 0.f;
+                    x = e_gate[r] > 0.f ? x : 0.f;
+                    P.C[(size_t)orow * P.ldc + ecol] = x;
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // waves 4..7 stored too, and the barrier drains waves 0..3 only
     }
+    ts.hit();
 }
 
 // The three d1 data gradients of a member (towers t = 0..2: dH5_t[16 x 64] = dfeat[:, 180 t ..] wTd_t, K = 180) in ONE pass.
@@ -405,19 +494,14 @@ __device__ __forceinline__ void chain_body(const DenseChainArgs& a, int j, int m
         ok = chain_barrier<ROLE>(ctr, 3, s_flag, ts);
     }
     ts.seek(24);
-    if (ok) {
-        if (j == 0) chain_head(a, m0, s_r, s_d);
+    if (ok) {                                                   // out + softmax + loss + fc_2's data gradient, one stage
+        chain_head_dcat<ROLE>(a, j, m0, n0, s_r, s_d, reinterpret_cast<float*>(s_r) + GemmSplitK4::NW * 4 * 64 * 4, ts);
         ok = chain_barrier<ROLE>(ctr, 4, s_flag, ts);
-    }
-    ts.seek(32);
-    if (ok) {
-        chain_tile<ROLE>(a.dcat, n, kFC2ld, kFC2, kFC1, 0, m0, n0, s_r, ts);
-        ok = chain_barrier<ROLE>(ctr, 5, s_flag, ts);
     }
     ts.seek(40);
     if (ok) {
         chain_tile<ROLE>(a.dfeat, n, kFC1, kFC1, kFlat, 0, m0, n0, s_r, ts);
-        ok = chain_barrier<ROLE>(ctr, 6, s_flag, ts);
+        ok = chain_barrier<ROLE>(ctr, 5, s_flag, ts);
     }
     ts.seek(48);
     if (ok) chain_d1_dgrad(a, n, m0, n0, s_r, ts);              // d1 x3 data gradients: the member's three tiles in one pass
@@ -451,7 +535,7 @@ __global__ __launch_bounds__(512, 1) void dense_chain_kernel(DenseChainArgs a) {
 }
 
 constexpr size_t kChainLdsBytes = (size_t)kChainS7Floats * 4;
-static_assert(kChainS7Jobs * 4 >= GemmSplitK4::NW * 4, "the last stage's partials are the larger set");
+static_assert(kChainS7Floats >= GemmSplitK4::NW * 4 * 64 * 4 + 16 * kFC2ld, "the last stage's partials are the larger set; dR2 [16][272] sits behind the 8 x 4 partial tiles");
 inline hipError_t dense_chain_set_attr() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes);
 }

@@ -1008,7 +1008,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             unsigned long long t0 = ~0ull, t1 = 0;
             for (int g2 = 0; g2 < wgs; ++g2) { t0 = std::min(t0, hs[(size_t)g2 * kChainStamps + 62]); for (int i = 0; i < kChainStamps; ++i) t1 = std::max(t1, hs[(size_t)g2 * kChainStamps + i]); }
             fprintf(stderr, "dense chain, n = %d, %d workgroups: span %.2f us (first start to last stamp)\n", n, wgs, (double)(t1 - t0) * 0.01);
-            static const char* const kNames[7] = {"d1", "FC1", "fc_2", "head", "dcat", "dfeat", "dH5[0]"};
+            static const char* const kNames[7] = {"d1", "FC1", "fc_2", "head+dcat", "-", "dfeat", "dH5 x3"};
             for (int sidx = 0; sidx < 7; ++sidx) {
                 double d[6] = {0, 0, 0, 0, 0, 0}, at0 = 0, at5 = 0; int cnt = 0;
                 for (int g2 = 0; g2 < wgs; ++g2) {

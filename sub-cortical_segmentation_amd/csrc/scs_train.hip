@@ -251,9 +251,9 @@ struct PrepArgs {
 //   17       atlas -> columns 540..555 of the fc_2 input rows (ConcatLayer elem_channels2, nets.py:224) + batch labels
 //   18       counter-based dropout keep-masks: one hash per element (splitmix64 finaliser), keep when the top bit is set
 constexpr int kPrepJobs = kPackJobs + kTrJobs + 2, kPrepBlocks = 64;      // the first kPrepBlocks workgroups of a job row work on it
-__device__ __forceinline__ void prep_body(const PrepArgs& a, int job) {
+__device__ __forceinline__ void prep_body(const PrepArgs& a, int job, int bx) {
     __shared__ float tile[32][33];
-    const int stride = kPrepBlocks * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    const int stride = kPrepBlocks * 256, t0 = bx * 256 + threadIdx.x;
     if (job < kPackJobs) {
         const PackJob J = a.pack[job];
         const int tot = (J.cin / 4) * conv_chunk_floats(J.cout);
@@ -274,7 +274,7 @@ __device__ __forceinline__ void prep_body(const PrepArgs& a, int job) {
         const TrProblem P = a.tr[job - kPackJobs];           // out[c][r] = in[r][c]
         const int tr_ = (P.rows + 31) / 32, tc_ = (P.cols + 31) / 32;
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        for (int tl = blockIdx.x; tl < tr_ * tc_; tl += kPrepBlocks) {
+        for (int tl = bx; tl < tr_ * tc_; tl += kPrepBlocks) {
             const int r0 = (tl / tc_) * 32, c0 = (tl % tc_) * 32;
             __syncthreads();
 #pragma unroll
@@ -349,15 +349,163 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
 // P[px][9] = 1, D = P'P holds R[k][k'] = sum_px x0[px+k] x0[px+k'], S[k] = D[k][9] and the pixel count D[9][9].  One
 // matrix product per patch (both MFMA operands are the same register), `ppb` patches per workgroup, the four waves split
 // the rows.  Everything conv1's batch statistics and weight gradient need from the inputs (see bn1_final / l1_final).
-__device__ __forceinline__ void moments_body(const X0Src& x0, float* __restrict__ part /*[t][units][128]*/, int n, int ppb, int units, int t) {
-    __shared__ __attribute__((aligned(16))) float s_x[1024 + 8];
-    __shared__ float s_red[4][256];
+// what turns the input moments into conv1's batch statistics and folded operands (bn1_final_body)
+struct Bn1Args {
+    float* params; int w_off0, bn_off0, tower_stride;
+    double* mom;                  // [3][100] out: R, S, count (l1_final_kernel reads them)
+    Ptr3 w1p, l1p, l1m;
+    unsigned int* counter;        // in-launch finalize: arrival tickets (FinArgs layout, fin_counter_words(units) words per tower), or null
+    double* rec;                  // in-launch finalize: group records [tower][groups][128]
+};
+
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// conv1's batch statistics from the input moments (z = sum_k wf[k] x0[. + k], wf = flipped filter):
+//   mean[c] = wf.S / M,  var[c] = wf' (R/M - S S'/M^2) wf,  inv_std = 1/sqrt(var + eps)      (all in double)
+// then everything later kernels need: the MFMA operands of the fused conv1 with (gamma inv_std, beta - mean gamma inv_std)
+// folded (conv_mfma.h: conv1_to_lds), the plain tap table for the backward pass, and the running averages (alpha 0.1).
+// The arithmetic, whatever runs it: units are summed in GROUPS of kFinGroup (ascending, in double), moment e of the 100 is the
+// sum of eight strided sub-sums (groups = h mod 8, ascending), added in order h = 0..7.  Run by NT threads (a multiple of 128)
+// for tower t.  REC: the group sums are records left inside this launch by the workgroups that completed the groups
+// (write-through stores behind tickets: loads that no L1 can serve); otherwise they are formed here from the unit sums.
+template <bool SC1>
+__device__ __forceinline__ double mom_group_sum(const float* __restrict__ p /* unit 0 of this moment */, int u0, int k) {
+    float r[kFinGroup];
+#pragma unroll
+    for (int i = 0; i < kFinGroup; ++i) { const float* q = p + (size_t)(u0 + min(i, k - 1)) * 128; r[i] = SC1 ? ld_sc1(q) : *q; }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < kFinGroup; ++i) if (i < k) s += r[i];
+    return s;
+}
+template <int NT, bool REC>
+__device__ __forceinline__ void bn1_final_body(const float* __restrict__ part, const double* __restrict__ rec /* [t][groups][128], REC */, int units, int n,
+                                               const Bn1Args& b, int t, double (*s_p)[128], double* s_R, double* s_Q) {
+    static_assert(NT % 128 == 0 && 8 % (NT / 128) == 0, "thread rows of 128");
+    constexpr int HN = NT / 128, HP = 8 / HN;               // thread rows, sub-sums per thread
+    const int e = threadIdx.x & 127, h0 = threadIdx.x >> 7;
+    // the channel threads' filter taps and BN entries: requested first, in flight with the unit sums
+    const int c = threadIdx.x;
+    float* bn = b.params + b.bn_off0 + t * b.tower_stride;  // beta, gamma, mean, inv_std
+    // (the three per-tower tables are picked HERE: with the picks between the rolled loops below, hipcc 7.2 left the third one's
+    // register pair unset on the t == 2 path - a store through a stale pointer)
+    float* const w1 = sel3(b.w1p.p, t);
+    float* const l1 = sel3(b.l1p.p, t) + c * 12;
+    float* const lm = sel3(b.l1m.p, t);
+    float wr[9], b_beta = 0.f, b_gamma = 0.f, b_mean = 0.f, b_inv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = 0.f;
+    if (c < 20) {
+        const float* W = b.params + b.w_off0 + t * b.tower_stride + c * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[k] = W[k];
+        b_beta = bn[c]; b_gamma = bn[20 + c]; b_mean = bn[40 + c]; b_inv = bn[60 + c];
+    }
+    const double M = (double)n * 900.0;
+    double s[HP];
+#pragma unroll
+    for (int i = 0; i < HP; ++i) s[i] = 0;
+    if (e < 100) {
+        const int G = (units + kFinGroup - 1) / kFinGroup;
+        if constexpr (REC) {
+            // up to 4 groups per sub-sum in one round trip (G <= 32: the batches the in-launch form takes), then one by one
+            const double* __restrict__ q = rec + (size_t)t * G * 128 + e;
+            double r[HP][4];
+#pragma unroll
+            for (int i = 0; i < HP; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[i][j] = ld_sc1(q + (size_t)min(h0 + HN * i + 8 * j, G - 1) * 128);
+#pragma unroll
+            for (int i = 0; i < HP; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (h0 + HN * i + 8 * j < G) s[i] += r[i][j];
+                for (int g = h0 + HN * i + 32; g < G; g += 8) s[i] += ld_sc1(q + (size_t)g * 128);
+            }
+        } else {
+            const float* __restrict__ p = part + (size_t)t * units * 128 + e;
+#pragma unroll
+            for (int i = 0; i < HP; ++i) {
+                int g = h0 + HN * i;
+                for (; g + 8 < G; g += 16) {                // two groups (32 unit sums) in flight
+                    const double s0 = mom_group_sum<false>(p, kFinGroup * g, kFinGroup);
+                    const double s1 = mom_group_sum<false>(p, kFinGroup * (g + 8), min(kFinGroup, units - kFinGroup * (g + 8)));
+                    s[i] += s0; s[i] += s1;
+                }
+                if (g < G) s[i] += mom_group_sum<false>(p, kFinGroup * g, min(kFinGroup, units - kFinGroup * g));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < HP; ++i) s_p[h0 + HN * i][e] = s[i];
+    __syncthreads();
+    if (threadIdx.x < 100) {
+        double v = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += s_p[q][threadIdx.x];
+        s_R[threadIdx.x] = v;
+        s_Q[threadIdx.x] = v / M;                           // the quotients of the variance formula, one division each
+        b.mom[t * 100 + threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (c >= 32 && c < 32 + 48) {                           // rows 9..11 of the operand tables are zero
+        const int z = c - 32;
+        if (z < 48) w1[144 + z] = 0.f;                      // main [12][16]: rows 9..11 = elements 144..191
+        if (z < 12) w1[192 + 36 + z] = 0.f;                 // leftover [12][4]: rows 9..11 = elements 228..239
+    }
+    if (c >= 20) return;
+    // (rolled loops over LDS operands: inside the moments launch this body must not raise the kernel's register count)
+    double* wf = &s_p[0][0] + c * 9;                        // s_p has been consumed (barrier above): this thread's flipped taps
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wf[k] = (double)wr[(2 - k / 3) * 3 + (2 - k % 3)];
+    double mean = 0, var = 0;
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) mean += wf[k] * s_R[k * 10 + 9];
+    mean /= M;
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) {
+        const double wk = wf[k], qk = s_Q[k * 10 + 9];
+#pragma unroll
+        for (int k2 = 0; k2 < 9; ++k2) var += wk * wf[k2] * (s_Q[k * 10 + k2] - qk * s_Q[k2 * 10 + 9]);
+    }
+    const double inv = 1.0 / sqrt(fmax(var, 0.0) + (double)kBnEps);
+    const float sc = b_gamma * (float)inv, sh = b_beta - (float)mean * sc;
+    bn[40 + c] = (1.f - kBnAlpha) * b_mean + kBnAlpha * (float)mean;
+    bn[60 + c] = (1.f - kBnAlpha) * b_inv + kBnAlpha * (float)inv;
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) {
+        l1[k] = (float)wf[k];
+        const float v = (float)wf[k] * sc;
+        if (c < 16) w1[k * 16 + c] = v; else w1[192 + k * 4 + (c - 16)] = v;
+    }
+    l1[9] = sc; l1[10] = sh; l1[11] = 0.f;
+    w1[240 + c] = sh;
+    lm[2 * c] = (float)mean; lm[2 * c + 1] = (float)inv;
+}
+
+// With b.counter set, the workgroup that completes a tower's arrival tickets (two levels, as the conv kernels' finalize:
+// conv_mfma.h take_ticket) runs bn1_final_body in this launch.
+__device__ __forceinline__ void moments_body(const X0Src& x0, float* __restrict__ part /*[t][units][128]*/, int n, int ppb, int units, int t,
+                                             int bx, const Bn1Args& b) {
+    // one buffer: the patch rows and the waves' partial products, then (the finalizing workgroup, behind its tickets' barriers)
+    // the finalize's sub-sums over the same bytes
+    __shared__ __attribute__((aligned(16))) double s_buf[8 * 128 + 200];
+    float* s_x = reinterpret_cast<float*>(s_buf);                           // [1024 + 8]
+    float (*s_red)[256] = reinterpret_cast<float (*)[256]>(s_x + 1032);     // [4][256]
+    double (*s_p)[128] = reinterpret_cast<double (*)[128]>(s_buf);          // [8][128]
+    double* s_R = s_buf + 8 * 128; double* s_Q = s_R + 100;
+    __shared__ int s_flag;
+    static_assert((1032 + 4 * 256) * sizeof(float) <= sizeof(s_buf), "moments scratch");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, kq = lane >> 4;
     const int toff = lr < 9 ? (lr / 3) * 32 + lr % 3 : 0;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int g0 = blockIdx.x * ppb, g1 = min(n, g0 + ppb);
+    const int g0 = bx * ppb, g1 = min(n, g0 + ppb);
     for (int g = g0; g < g1; ++g) {
         __syncthreads();
         load_x0_rows<32, 256>(x0, t, g, 0, s_x, tid);
@@ -375,93 +523,41 @@ __device__ __forceinline__ void moments_body(const X0Src& x0, float* __restrict_
     for (int i = 0; i < 4; ++i) s_red[wave][(4 * kq + i) * 16 + lr] = acc[i];
     __syncthreads();
     const int m = tid >> 4, k = tid & 15;
-    if (m < 10 && k < 10)
-        part[((size_t)t * units + blockIdx.x) * 128 + m * 10 + k] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    if (m < 10 && k < 10) {
+        float* dst = part + ((size_t)t * units + bx) * 128 + m * 10 + k;
+        const float v = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        if (b.counter) st_sc1(dst, v); else *dst = v;
+    }
+    if (b.counter) {
+        const unsigned int nwg = (unsigned int)units, grp = bx / kFinGroup, groups = (nwg + kFinGroup - 1) / kFinGroup;
+        unsigned int* cnt = b.counter + t * fin_counter_words(nwg);
+        if (take_ticket(cnt + (size_t)kFinLine * (1 + grp), min((unsigned int)kFinGroup, nwg - grp * kFinGroup), &s_flag)) {
+            // this workgroup completed its group: the group's unit sums -> one record per moment
+            if (tid < 100)
+                st_sc1(b.rec + ((size_t)t * groups + grp) * 128 + tid,
+                       mom_group_sum<true>(part + (size_t)t * units * 128 + tid, kFinGroup * (int)grp, min(kFinGroup, units - kFinGroup * (int)grp)));
+            if (take_ticket(cnt, groups, &s_flag)) bn1_final_body<256, true>(part, b.rec, units, n, b, t, s_p, s_R, s_Q);
+        }
+    }
 }
 
-// First launch of a step: rows [0, kPrepJobs) of the grid are the prep jobs, rows kPrepJobs + t the input moments of tower t
-// (nothing in either half depends on the other; one launch instead of two on the step's critical path.  The prep jobs on the
-// side stream beside the moments was tried: the fork / join events cost more than the 8 us the jobs take - 0.628 against 0.616
-// ms per step, profiles/r03_notes.txt).
-__global__ __launch_bounds__(256) void prep_moments_kernel(PrepArgs a, X0Src x0, float* __restrict__ mom_part, int n, int ppb, int units) {
-    const int job = blockIdx.y;
-    if (job < kPrepJobs) { if ((int)blockIdx.x < kPrepBlocks) prep_body(a, job); }
-    else if ((int)blockIdx.x < units) moments_body(x0, mom_part, n, ppb, units, job - kPrepJobs);
+// First launch of a step, a flat grid: workgroups [0, kTowers * units) are the input moments of the towers - dispatched FIRST, so
+// that the in-launch finalize of conv1's statistics (small batches) runs beside the prep jobs instead of behind them - and the
+// next kPrepJobs * kPrepBlocks the prep jobs (nothing in either half depends on the other; one launch instead of two on the
+// step's critical path.  The prep jobs on the side stream beside the moments was tried: the fork / join events cost more than
+// the 8 us the jobs take - 0.628 against 0.616 ms per step, profiles/r03_notes.txt).
+__global__ __launch_bounds__(256) void prep_moments_kernel(PrepArgs a, X0Src x0, float* __restrict__ mom_part, int n, int ppb, int units, Bn1Args b) {
+    const int bx = blockIdx.x - kTowers * units;
+    if (bx >= 0) prep_body(a, bx / kPrepBlocks, bx % kPrepBlocks);
+    else moments_body(x0, mom_part, n, ppb, units, (int)blockIdx.x / units, (int)blockIdx.x % units, b);
 }
+inline dim3 prep_moments_grid(int units) { return dim3(kPrepJobs * kPrepBlocks + kTowers * units); }
 
-// conv1's batch statistics from the input moments (z = sum_k wf[k] x0[. + k], wf = flipped filter):
-//   mean[c] = wf.S / M,  var[c] = wf' (R/M - S S'/M^2) wf,  inv_std = 1/sqrt(var + eps)      (all in double)
-// then everything later kernels need: the MFMA operands of the fused conv1 with (gamma inv_std, beta - mean gamma inv_std)
-// folded (conv_mfma.h: conv1_to_lds), the plain tap table for the backward pass, and the running averages (alpha 0.1).
-__global__ __launch_bounds__(1024) void bn1_final_kernel(const float* __restrict__ part, int units, int n, float* params, int w_off0, int bn_off0,
-                                                        int tower_stride, double* __restrict__ mom, Ptr3 w1p, Ptr3 l1p, Ptr3 l1m) {
+// The finalize as a launch of its own (batches beyond kBn1FusedMaxBatch): one workgroup per tower.
+__global__ __launch_bounds__(1024) void bn1_final_kernel(const float* __restrict__ part, int units, int n, Bn1Args b) {
     __shared__ double s_p[8][128];
-    __shared__ double s_R[100];
-    const int t = blockIdx.x, e = threadIdx.x & 127, hh = threadIdx.x >> 7;
-    double s = 0;
-    if (e < 100) {
-        const float* __restrict__ p = part + (size_t)t * units * 128 + e;
-        int u = hh;
-        for (; u + 248 < units; u += 256) {                 // 32 units in flight: the 256 units of a training batch are one round trip
-            float r[32];
-#pragma unroll
-            for (int q = 0; q < 32; ++q) r[q] = p[(size_t)(u + 8 * q) * 128];
-#pragma unroll
-            for (int q = 0; q < 32; ++q) s += r[q];
-        }
-        for (; u + 56 < units; u += 64) {
-            float r[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) r[q] = p[(size_t)(u + 8 * q) * 128];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s += r[q];
-        }
-        for (; u < units; u += 8) s += p[(size_t)u * 128];
-    }
-    s_p[hh][e] = s;
-    __syncthreads();
-    if (threadIdx.x < 100) {
-        double v = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v += s_p[q][threadIdx.x];
-        s_R[threadIdx.x] = v;
-        mom[t * 100 + threadIdx.x] = v;
-    }
-    __syncthreads();
-    const int c = threadIdx.x;
-    float* w1 = sel3(w1p.p, t);
-    if (c >= 32 && c < 32 + 48) {                       // rows 9..11 of the operand tables are zero
-        const int z = c - 32;
-        if (z < 48) w1[144 + z] = 0.f;                  // main [12][16]: rows 9..11 = elements 144..191
-        if (z < 12) w1[192 + 36 + z] = 0.f;             // leftover [12][4]: rows 9..11 = elements 228..239
-    }
-    if (c >= 20) return;
-    const float* W = params + w_off0 + t * tower_stride + c * 9;
-    float* bn = params + bn_off0 + t * tower_stride;    // beta, gamma, mean, inv_std
-    const double M = (double)n * 900.0;
-    double wf[9], mean = 0, var = 0;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { wf[k] = (double)W[(2 - k / 3) * 3 + (2 - k % 3)]; mean += wf[k] * s_R[k * 10 + 9]; }
-    mean /= M;
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int k2 = 0; k2 < 9; ++k2) var += wf[k] * wf[k2] * (s_R[k * 10 + k2] / M - (s_R[k * 10 + 9] / M) * (s_R[k2 * 10 + 9] / M));
-    const double inv = 1.0 / sqrt(fmax(var, 0.0) + (double)kBnEps);
-    const float sc = bn[20 + c] * (float)inv, sh = bn[c] - (float)mean * sc;
-    bn[40 + c] = (1.f - kBnAlpha) * bn[40 + c] + kBnAlpha * (float)mean;
-    bn[60 + c] = (1.f - kBnAlpha) * bn[60 + c] + kBnAlpha * (float)inv;
-    float* l1 = sel3(l1p.p, t) + c * 12;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        l1[k] = (float)wf[k];
-        const float v = (float)wf[k] * sc;
-        if (c < 16) w1[k * 16 + c] = v; else w1[192 + k * 4 + (c - 16)] = v;
-    }
-    l1[9] = sc; l1[10] = sh; l1[11] = 0.f;
-    w1[240 + c] = sh;
-    float* lm = sel3(l1m.p, t);
-    lm[2 * c] = (float)mean; lm[2 * c + 1] = (float)inv;
+    __shared__ double s_R[100], s_Q[100];
+    bn1_final_body<1024, false>(part, nullptr, units, n, b, blockIdx.x, s_p, s_R, s_Q);
 }
 
 // Batch statistics of a conv layer from the per-(patch band, channel) units its epilogue left - each the mean and the sum of
@@ -891,17 +987,20 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.fc2W = P + H.fc2W; pa.w2p = w2p; pa.chain_counter = w->chain_counter;
         pa.c5W = P + T0.convW[4]; pa.wc5 = wc5; pa.c5_tower_stride = kTowerFloats;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
-        // ---- forward, training mode: the input moments ride in the same launch
+        // ---- forward, training mode: the input moments ride in the same launch; up to kBn1FusedMaxBatch the workgroup that
+        // completes a tower's moments also finalizes conv1's batch statistics there (beside the prep jobs: no launch of its own on
+        // the step's critical path); SCS_BN1_FUSED_MAX_BATCH overrides the bound (0: always a launch; tests run both forms)
+        Bn1Args b1{P, T0.convW[0], T0.bn[0], kTowerFloats, w->mom, Ptr3{{w->w1p[0], w->w1p[1], w->w1p[2]}}, Ptr3{{w->l1p[0], w->l1p[1], w->l1p[2]}},
+                   Ptr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, nullptr};
+        const char* b1_env = getenv("SCS_BN1_FUSED_MAX_BATCH");
+        const bool bn1_fused = n <= (b1_env ? std::min(atoi(b1_env), w->cap) : kBn1FusedMaxBatch);
+        if (bn1_fused) { b1.counter = w->fin_counter; b1.rec = w->fin_grp; }
         run(ST_PREP, st, [&] {
-            hipLaunchKernelGGL(prep_moments_kernel, dim3(std::max(units1, kPrepBlocks), kPrepJobs + kTowers), dim3(256), 0, st, pa, x0, w->mom_part, n,
-                               ppb, units1);
+            hipLaunchKernelGGL(prep_moments_kernel, prep_moments_grid(units1), dim3(256), 0, st, pa, x0, w->mom_part, n,
+                               ppb, units1, b1);
         });
+        if (!bn1_fused) run(ST_FIN1, st, [&] { hipLaunchKernelGGL(bn1_final_kernel, dim3(kTowers), dim3(1024), 0, st, w->mom_part, units1, n, b1); });
     }
-    Ptr3 w1p{{w->w1p[0], w->w1p[1], w->w1p[2]}}, l1p{{w->l1p[0], w->l1p[1], w->l1p[2]}}, l1m{{w->l1m[0], w->l1m[1], w->l1m[2]}};
-    run(ST_FIN1, st, [&] {
-        hipLaunchKernelGGL(bn1_final_kernel, dim3(kTowers), dim3(1024), 0, st, w->mom_part, units1, n, P, T0.convW[0], T0.bn[0], kTowerFloats,
-                           w->mom, w1p, l1p, l1m);
-    });
     constexpr int kStatBands[kConvs] = {1, TF12::NB, TF3::NB, TF4::NB, TF5::NB};
     for (int i = 1; i < kConvs; ++i) {
         ConvArgs a{};

@@ -30,6 +30,8 @@ using DG5N = ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4
 using DG4N = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3, 0, 4, 0>;
 using DG3N = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3, 0, 4, 0>;
 constexpr int kFinMaxBatch = 512;
+// conv1's statistics (from the input moments) finalized inside the prep + moments launch up to this batch, by bn1_final_kernel beyond
+constexpr int kBn1FusedMaxBatch = 512;
 
 constexpr int kHout[kConvs] = {30, 28, 12, 10, 3};
 // <CIN, COUT, HIN, row bands, workgroups per CU, X source, software-pipelined staging>.  d z is read from memory (the data-gradient

@@ -434,6 +434,34 @@ def test_dense_head_as_one_launch_gives_the_bits_of_the_layer_launches(weights, 
         assert np.array_equal(got, ref), '%s differ between the one-launch dense head and the layer launches at n = %d' % (what, n)
 
 
+@pytest.mark.parametrize('n', [1, 5, 37, 256, 257, 512])
+def test_conv1_statistics_finalized_in_the_moments_launch_give_the_bits_of_the_finalize_launch(weights, monkeypatch, n):
+    """Up to batch 512 the workgroup that completes a tower's input moments (two levels of arrival tickets) also turns them into
+    conv1's batch statistics and folded operands inside the step's first launch; beyond that bn1_final_kernel does, as a launch
+    of its own.  One body, the same order of sums whatever the thread count: two steps through each form (Adam applied) leave
+    the same losses, gradient arena and parameter arena (running statistics included), bit for bit - and the in-launch form
+    re-arms its tickets (second step)."""
+    from cnn_cort import synth, _hip
+    out = {}
+    for form, bound in (('launch', '0'), ('in the moments launch', '512')):
+        monkeypatch.setenv('SCS_BN1_FUSED_MAX_BATCH', bound)
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        st = torch.cuda.current_stream().cuda_stream
+        losses = []
+        for step in range(2):
+            ax, co, sa, at = synth.patch_batch(n, seed=1300 + n + step)
+            y = np.random.RandomState(n + step).randint(0, 15, n).astype(np.uint8)
+            losses.append(h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=31 + step, stream=st))
+            h.adam_apply(stream=st)
+        torch.cuda.synchronize()
+        out[form] = (np.array(losses), arena(h, 'grad').copy(), arena(h, 'param').copy())
+        h.close()
+    assert np.isfinite(out['launch'][0]).all()
+    for got, ref, what in zip(out['in the moments launch'], out['launch'], ('losses', 'gradient arena', 'parameter arena')):
+        assert np.array_equal(got, ref), '%s differ between the two forms of the conv1 finalize at n = %d' % (what, n)
+
+
 @pytest.mark.parametrize('n', [1, 3, 37, 256, 257, 1024])
 def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monkeypatch, n):
     """Up to batch 1024 the conv5 block's data gradient, weight gradient and the conv4 block's (d beta, d gamma) sums are one launch

@@ -95,7 +95,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
     // scs_train_step_profiled
     bool prof = false;
     hipEvent_t pev[2 * scs::ST_COUNT]{};
@@ -125,6 +125,7 @@ void train_free(scs_ctx* h) {
     if (w->side) (void)hipStreamDestroy(w->side);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     if (w->ev_join) (void)hipEventDestroy(w->ev_join);
+    if (w->ev_mid) (void)hipEventDestroy(w->ev_mid);
     for (auto& e : w->pev) if (e) (void)hipEventDestroy(e);
     delete w;
     h->tws = nullptr;
@@ -180,6 +181,7 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
+        SCS_HIP(hipEventCreateWithFlags(&w->ev_mid, hipEventDisableTiming));
     }
     if (n <= w->cap) return SCS_OK;
     SCS_HIP(hipDeviceSynchronize());           // a previous step may still be using the old buffers
@@ -577,10 +579,26 @@ __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const float* __restri
     float* bn = params + bn_off0 + t * tower_stride;               // beta, gamma, mean, inv_std
     float b_beta = 0.f, b_gamma = 0.f, b_mean = 0.f, b_inv = 0.f;
     if (threadIdx.x == 0) { b_beta = bn[c]; b_gamma = bn[C + c]; b_mean = bn[2 * C + c]; b_inv = bn[3 * C + c]; }   // in flight with the partials
+    // APPLY5: the first nine values (and keep-flags) this thread will transform do not depend on the statistics: requested now
+    float zv0[9];
+    uint8_t mk0[9];
+    if constexpr (APPLY5) {
+        const size_t at = ((size_t)min((int)threadIdx.x, n - 1) * C + c) * 9;
+        const float* __restrict__ z = sel3(Z.p, t);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) { zv0[e] = z[at + e]; mk0[e] = mask[(size_t)t * n * kFlat + at + e]; }
+    }
     // one pass: sum of unit means, of their squares (about the first unit's mean: exact in double) and of the unit M2
     const double m0 = (double)p[0].x;
     double s = 0, s2 = 0, q = 0;
-    for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; const double d = (double)v.x - m0; s += d; s2 += d * d; q += v.y; }
+    for (int u0 = threadIdx.x; u0 < units; u0 += 8 * 256) {        // eight units per thread in flight (conv2 at batch 256: 7 per thread, one round trip)
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)min(u0 + 256 * j, units - 1) * C];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (u0 + 256 * j < units) { const double d = (double)v[j].x - m0; s += d; s2 += d * d; q += v[j].y; }
+    }
     block_sum3(s, s2, q, s_red);
     if (threadIdx.x == 0) {
         const double dm = s / units, mean = m0 + dm;
@@ -603,8 +621,13 @@ __global__ __launch_bounds__(256) void bn_fwd_final_kernel(const float* __restri
             const size_t at = ((size_t)ni * C + c) * 9;
             float zv[9];
             uint8_t mk[9];
+            if (ni == (int)threadIdx.x) {
 #pragma unroll
-            for (int e = 0; e < 9; ++e) { zv[e] = z[at + e]; mk[e] = mask[(size_t)t * n * kFlat + at + e]; }
+                for (int e = 0; e < 9; ++e) { zv[e] = zv0[e]; mk[e] = mk0[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) { zv[e] = z[at + e]; mk[e] = mask[(size_t)t * n * kFlat + at + e]; }
+            }
 #pragma unroll
             for (int e = 0; e < 9; ++e) {
                 const float v = fmaxf(fmaf(zv[e], sc, sh), 0.f);
@@ -642,7 +665,14 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
         sb = fb; sg = fg;
     } else {
         const float2* __restrict__ p = reinterpret_cast<const float2*>(part) + (size_t)t * units * C + c;
-        for (int u = threadIdx.x; u < units; u += 256) { const float2 v = p[(size_t)u * C]; sb += v.x; sg += v.y; }
+        for (int u0 = threadIdx.x; u0 < units; u0 += 8 * 256) {
+            float2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(size_t)min(u0 + 256 * j, units - 1) * C];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (u0 + 256 * j < units) { sb += v[j].x; sg += v[j].y; }
+        }
     }
     double unused = 0;
     block_sum3(sb, sg, unused, s_red);
@@ -939,6 +969,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     const char* fin_env = getenv("SCS_FIN_MAX_BATCH");
     const bool fin_in_kernel = n <= (fin_env ? atoi(fin_env) : kFinMaxBatch);
     hipStream_t sd = one_stream ? st : w->side;
+    static const bool fin_main_off = getenv("SCS_WGFIN_SIDE") != nullptr;          // tuning runs: the conv3..5 reduction on the side stream (round-2 form)
+    const bool fin_on_main = !one_stream && !fin_main_off;
 
     w->prof = stage_ms != nullptr;
     if (w->prof) {
@@ -1250,10 +1282,14 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         else run(ST_WG2, sd, [&] { wgrad_launch<WG2>(wa, sd); });
         fa.j[i - 1] = WgFinalJob{part, wa.slices * kParts[i], kCin[i], C, T0.convW[i]};
         if (i == 2) {
-            // partial sums of conv5..conv3 are reduced now, beside the conv2 data gradient (the conv2 weight gradient cannot start
-            // before that one ends): only conv2's own reduction is left for the tail of the step
-            fa.z0 = 1;
-            run(ST_WGFINAL, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, sd, fa); });
+            // the partial sums of conv5..conv3 are complete: their reduction goes to the CALLER's stream behind the layer-1 launch
+            // (below), beside the conv2 weight gradient.  (On the side stream in front of that weight gradient - which cannot start
+            // before the conv2 data gradient ends - it delayed the step's last big kernel by its 11 us + a launch gap.)
+            if (fin_on_main) (void)hipEventRecord(w->ev_mid, sd);
+            else {
+                fa.z0 = 1;
+                run(ST_WGFINAL, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, sd, fa); });
+            }
         }
     }
     // conv1 block: gradients from the layer-1 sums and the input moments (caller's stream); the conv2 weight-gradient
@@ -1262,6 +1298,11 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         hipLaunchKernelGGL(l1_final_kernel, dim3(20, kTowers), dim3(256), 0, st, w->l1_part, n * kL1Bands, n, w->mom,
                            CPtr3{{w->l1p[0], w->l1p[1], w->l1p[2]}}, CPtr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, G, T0.convW[0], T0.bn[0], kTowerFloats);
     });
+    if (fin_on_main) {
+        (void)hipStreamWaitEvent(st, w->ev_mid, 0);
+        fa.z0 = 1;
+        run(ST_WGFINAL, st, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, st, fa); });
+    }
     fa.z0 = 0;
     run(ST_WGFINAL2, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((20 * 20 * 9 + 63) / 64, kTowers, 1), dim3(256), 0, sd, fa); });
     join();                                   // every gradient is in the arena before the caller's stream goes on

@@ -252,7 +252,11 @@ struct PrepArgs {
 //   [12, 17) dense weights transposed for the data-gradient GEMMs
 //   17       atlas -> columns 540..555 of the fc_2 input rows (ConcatLayer elem_channels2, nets.py:224) + batch labels
 //   18       counter-based dropout keep-masks: one hash per element (splitmix64 finaliser), keep when the top bit is set
-constexpr int kPrepJobs = kPackJobs + kTrJobs + 2, kPrepBlocks = 64;      // the first kPrepBlocks workgroups of a job row work on it
+constexpr int kPrepJobs = kPackJobs + kTrJobs + 2, kPrepBlocks = 64;      // kPrepBlocks workgroups per job ...
+// ... and kPrepExtra * kPrepBlocks more for the one job that was the launch's long pole: the 540 x 540 transpose of FC1.W is 289
+// tiles - 4.5 dependent (load, barrier, store) rounds per workgroup at 64 (10 us of prep against 6.6 us without that job)
+constexpr int kPrepBigJob = kPackJobs + 1, kPrepExtra = 3;
+constexpr int kPrepWorkgroups = (kPrepJobs + kPrepExtra) * kPrepBlocks;
 __device__ __forceinline__ void prep_body(const PrepArgs& a, int job, int bx) {
     __shared__ float tile[32][33];
     const int stride = kPrepBlocks * 256, t0 = bx * 256 + threadIdx.x;
@@ -276,7 +280,7 @@ __device__ __forceinline__ void prep_body(const PrepArgs& a, int job, int bx) {
         const TrProblem P = a.tr[job - kPackJobs];           // out[c][r] = in[r][c]
         const int tr_ = (P.rows + 31) / 32, tc_ = (P.cols + 31) / 32;
         const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        for (int tl = bx; tl < tr_ * tc_; tl += kPrepBlocks) {
+        for (int tl = bx; tl < tr_ * tc_; tl += (job == kPrepBigJob ? (1 + kPrepExtra) * kPrepBlocks : kPrepBlocks)) {
             const int r0 = (tl / tc_) * 32, c0 = (tl % tc_) * 32;
             __syncthreads();
 #pragma unroll
@@ -545,15 +549,16 @@ __device__ __forceinline__ void moments_body(const X0Src& x0, float* __restrict_
 
 // First launch of a step, a flat grid: workgroups [0, kTowers * units) are the input moments of the towers - dispatched FIRST, so
 // that the in-launch finalize of conv1's statistics (small batches) runs beside the prep jobs instead of behind them - and the
-// next kPrepJobs * kPrepBlocks the prep jobs (nothing in either half depends on the other; one launch instead of two on the
+// next kPrepWorkgroups the prep jobs (nothing in either half depends on the other; one launch instead of two on the
 // step's critical path.  The prep jobs on the side stream beside the moments was tried: the fork / join events cost more than
 // the 8 us the jobs take - 0.628 against 0.616 ms per step, profiles/r03_notes.txt).
 __global__ __launch_bounds__(256) void prep_moments_kernel(PrepArgs a, X0Src x0, float* __restrict__ mom_part, int n, int ppb, int units, Bn1Args b) {
     const int bx = blockIdx.x - kTowers * units;
-    if (bx >= 0) prep_body(a, bx / kPrepBlocks, bx % kPrepBlocks);
+    if (bx >= kPrepJobs * kPrepBlocks) prep_body(a, kPrepBigJob, bx - (kPrepJobs - 1) * kPrepBlocks);   // the big job's extra workgroups: blocks 64 ..
+    else if (bx >= 0) prep_body(a, bx / kPrepBlocks, bx % kPrepBlocks);
     else moments_body(x0, mom_part, n, ppb, units, (int)blockIdx.x / units, (int)blockIdx.x % units, b);
 }
-inline dim3 prep_moments_grid(int units) { return dim3(kPrepJobs * kPrepBlocks + kTowers * units); }
+inline dim3 prep_moments_grid(int units) { return dim3(kPrepWorkgroups + kTowers * units); }
 
 // The finalize as a launch of its own (batches beyond kBn1FusedMaxBatch): one workgroup per tower.
 __global__ __launch_bounds__(1024) void bn1_final_kernel(const float* __restrict__ part, int units, int n, Bn1Args b) {

@@ -95,7 +95,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // scs_train_step_profiled
     bool prof = false;
     hipEvent_t pev[2 * scs::ST_COUNT]{};
@@ -125,7 +125,6 @@ void train_free(scs_ctx* h) {
     if (w->side) (void)hipStreamDestroy(w->side);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     if (w->ev_join) (void)hipEventDestroy(w->ev_join);
-    if (w->ev_mid) (void)hipEventDestroy(w->ev_mid);
     for (auto& e : w->pev) if (e) (void)hipEventDestroy(e);
     delete w;
     h->tws = nullptr;
@@ -181,7 +180,6 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
-        SCS_HIP(hipEventCreateWithFlags(&w->ev_mid, hipEventDisableTiming));
     }
     if (n <= w->cap) return SCS_OK;
     SCS_HIP(hipDeviceSynchronize());           // a previous step may still be using the old buffers
@@ -974,8 +972,12 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     const char* fin_env = getenv("SCS_FIN_MAX_BATCH");
     const bool fin_in_kernel = n <= (fin_env ? atoi(fin_env) : kFinMaxBatch);
     hipStream_t sd = one_stream ? st : w->side;
-    static const bool fin_main_off = getenv("SCS_WGFIN_SIDE") != nullptr;          // tuning runs: the conv3..5 reduction on the side stream (round-2 form)
-    const bool fin_on_main = !one_stream && !fin_main_off;
+    // The tail of the step.  The conv2 weight gradient - the last big kernel, which cannot start before the conv2 data gradient ends -
+    // follows that kernel on the CALLER's stream (in order: no cross-stream wait on the critical path) with its reduction behind
+    // it; the layer-1 launch and the reduction of the conv3..5 partials go to the side stream, behind the conv3 weight gradient,
+    // and run beside it.  SCS_TAIL_SIDE (tuning runs) restores the round-2 order: everything but the layer-1 launch on the side stream.
+    static const bool tail_side = getenv("SCS_TAIL_SIDE") != nullptr;
+    const bool tail_on_main = !one_stream && !tail_side;
 
     w->prof = stage_ms != nullptr;
     if (w->prof) {
@@ -1284,32 +1286,27 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         if (i == 4) run(ST_WG5, sd, [&] { wgrad_launch<WG5>(wa, sd); });
         else if (i == 3) run(ST_WG4, sd, [&] { wgrad_launch<WG4>(wa, sd); });
         else if (i == 2) run(ST_WG3, sd, [&] { wgrad_launch<WG3>(wa, sd); });
-        else run(ST_WG2, sd, [&] { wgrad_launch<WG2>(wa, sd); });
+        else { hipStream_t s2 = tail_on_main ? st : sd; run(ST_WG2, s2, [&] { wgrad_launch<WG2>(wa, s2); }); }
         fa.j[i - 1] = WgFinalJob{part, wa.slices * kParts[i], kCin[i], C, T0.convW[i]};
-        if (i == 2) {
-            // the partial sums of conv5..conv3 are complete: their reduction goes to the CALLER's stream behind the layer-1 launch
-            // (below), beside the conv2 weight gradient.  (On the side stream in front of that weight gradient - which cannot start
-            // before the conv2 data gradient ends - it delayed the step's last big kernel by its 11 us + a launch gap.)
-            if (fin_on_main) (void)hipEventRecord(w->ev_mid, sd);
-            else {
-                fa.z0 = 1;
-                run(ST_WGFINAL, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, sd, fa); });
-            }
+        if (i == 2 && !tail_on_main) {
+            // round-2 order: partial sums of conv5..conv3 reduced on the side stream in front of the conv2 weight gradient
+            fa.z0 = 1;
+            run(ST_WGFINAL, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, sd, fa); });
         }
     }
-    // conv1 block: gradients from the layer-1 sums and the input moments (caller's stream); the conv2 weight-gradient
-    // partials are reduced on the side stream
-    run(ST_L1FINAL, st, [&] {
-        hipLaunchKernelGGL(l1_final_kernel, dim3(20, kTowers), dim3(256), 0, st, w->l1_part, n * kL1Bands, n, w->mom,
+    // conv1 block: gradients from the layer-1 sums and the input moments; reductions of the weight-gradient partials (streams: see
+    // tail_on_main above; the last fork made the side stream wait for the conv2 data gradient)
+    hipStream_t sl = tail_on_main ? sd : st, s2 = tail_on_main ? st : sd;
+    run(ST_L1FINAL, sl, [&] {
+        hipLaunchKernelGGL(l1_final_kernel, dim3(20, kTowers), dim3(256), 0, sl, w->l1_part, n * kL1Bands, n, w->mom,
                            CPtr3{{w->l1p[0], w->l1p[1], w->l1p[2]}}, CPtr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, G, T0.convW[0], T0.bn[0], kTowerFloats);
     });
-    if (fin_on_main) {
-        (void)hipStreamWaitEvent(st, w->ev_mid, 0);
+    if (tail_on_main) {
         fa.z0 = 1;
-        run(ST_WGFINAL, st, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, st, fa); });
+        run(ST_WGFINAL, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((60 * 40 * 9 + 63) / 64, kTowers, 3), dim3(256), 0, sd, fa); });
     }
     fa.z0 = 0;
-    run(ST_WGFINAL2, sd, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((20 * 20 * 9 + 63) / 64, kTowers, 1), dim3(256), 0, sd, fa); });
+    run(ST_WGFINAL2, s2, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((20 * 20 * 9 + 63) / 64, kTowers, 1), dim3(256), 0, s2, fa); });
     join();                                   // every gradient is in the arena before the caller's stream goes on
     if (hipError_t le = hipGetLastError(); le != hipSuccess) {
         w->tickets_dirty = true;

@@ -966,7 +966,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     float* G = h->grads;
     constexpr HeadOff H = head_off();
     constexpr TowerOff T0 = tower_off(0);
-    static const bool one_stream = getenv("SCS_TRAIN_ONE_STREAM") != nullptr;      // tuning runs: no side stream
+    const bool one_stream = getenv("SCS_TRAIN_ONE_STREAM") != nullptr;             // tuning runs and the stream-order test: no side stream
     // batch-norm finalize inside the producing conv kernel up to kFinMaxBatch, as a launch of its own beyond (train_cfg.h);
     // SCS_FIN_MAX_BATCH overrides the bound (tests run both forms at one batch size)
     const char* fin_env = getenv("SCS_FIN_MAX_BATCH");
@@ -976,7 +976,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // follows that kernel on the CALLER's stream (in order: no cross-stream wait on the critical path) with its reduction behind
     // it; the layer-1 launch and the reduction of the conv3..5 partials go to the side stream, behind the conv3 weight gradient,
     // and run beside it.  SCS_TAIL_SIDE (tuning runs) restores the round-2 order: everything but the layer-1 launch on the side stream.
-    static const bool tail_side = getenv("SCS_TAIL_SIDE") != nullptr;
+    const bool tail_side = getenv("SCS_TAIL_SIDE") != nullptr;
     const bool tail_on_main = !one_stream && !tail_side;
 
     w->prof = stage_ms != nullptr;

@@ -462,6 +462,39 @@ def test_conv1_statistics_finalized_in_the_moments_launch_give_the_bits_of_the_f
         assert np.array_equal(got, ref), '%s differ between the two forms of the conv1 finalize at n = %d' % (what, n)
 
 
+@pytest.mark.parametrize('n', [5, 128, 256])
+def test_stream_order_of_the_last_launches_does_not_change_the_bits(weights, monkeypatch, n):
+    """The step's weight-gradient launches run beside the data gradients on a side stream, in two arrangements of the last ones -
+    conv2's weight gradient and its reduction on the caller's stream with the layer-1 launch and the conv3..5 reduction beside
+    them (default), or everything but the layer-1 launch on the side stream (SCS_TAIL_SIDE) - or, as the reference, with every
+    launch in order on ONE stream (SCS_TRAIN_ONE_STREAM).  Same kernels, same arithmetic: six steps through each (Adam applied)
+    must leave the same arenas bit for bit - a missing dependency between the streams would show here."""
+    from cnn_cort import synth, _hip
+    out = {}
+    for form in ('default', 'side', 'one stream'):
+        monkeypatch.delenv('SCS_TAIL_SIDE', raising=False)
+        monkeypatch.delenv('SCS_TRAIN_ONE_STREAM', raising=False)
+        if form == 'side':
+            monkeypatch.setenv('SCS_TAIL_SIDE', '1')
+        elif form == 'one stream':
+            monkeypatch.setenv('SCS_TRAIN_ONE_STREAM', '1')          # every launch in order on the caller's stream: the reference
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        st = torch.cuda.current_stream().cuda_stream
+        losses = []
+        for step in range(6):
+            ax, co, sa, at = synth.patch_batch(n, seed=1700 + n + step)
+            y = np.random.RandomState(n + step).randint(0, 15, n).astype(np.uint8)
+            losses.append(h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=51 + step, stream=st))
+            h.adam_apply(stream=st)
+        torch.cuda.synchronize()
+        out[form] = (np.array(losses), arena(h, 'grad').copy(), arena(h, 'param').copy())
+        h.close()
+    for form in ('default', 'side'):
+        for got, ref, what in zip(out[form], out['one stream'], ('losses', 'gradient arena', 'parameter arena')):
+            assert np.array_equal(got, ref), '%s of the %s stream order differ from the single-stream step at n = %d' % (what, form, n)
+
+
 @pytest.mark.parametrize('n', [1, 3, 37, 256, 257, 1024])
 def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monkeypatch, n):
     """Up to batch 1024 the conv5 block's data gradient, weight gradient and the conv4 block's (d beta, d gamma) sums are one launch

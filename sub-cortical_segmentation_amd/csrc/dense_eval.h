@@ -97,23 +97,28 @@ __global__ void dense_centres_kernel(DenseView v, int s_begin, int sb, int32_t* 
     }
 }
 
+// The two re-tiling kernels below work one DESTINATION tile per workgroup pass: the divisions by run-time tile counts are per
+// tile, the per-element ones are by constants (as one grid-stride loop over single elements with 64-bit indices they took 2x / 1.3x
+// as long).  The features kernel stays element-wise: a wave per voxel, and a wave testing 64 voxels then copying its hits one
+// after the other, were both slower (136 and 236 us per launch against 125: the hits of a slice batch are neighbours in the list).
+
 // Re-cut a map held as tiles [..][CH][HS][HS] that tessellate it with stride HS into tiles [..][CH][HD][HD] taken every SD rows
 // and columns (the inputs of the next valid convolution: HD = SD + 2).  Same slices and phases on both sides.
 template <int CH, int HS, int HD, int SD>
 __global__ __launch_bounds__(256) void dense_retile_kernel(const float* __restrict__ src, int trs, int tcs, float* __restrict__ dst, int trd, int tcd,
                                                            int planes /* slices x phases */) {
-    const long total = (long)planes * trd * tcd * CH * HD * HD;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        long q = e;
-        const int x = q % HD; q /= HD;
-        const int y = q % HD; q /= HD;
-        const int c = q % CH; q /= CH;
-        const int j = q % tcd; q /= tcd;
-        const int i = q % trd; q /= trd;
-        const int pl = (int)q;
-        const int u = SD * i + y, w = SD * j + x;
-        const int ti = u / HS, tj = w / HS;
-        dst[e] = src[((((size_t)pl * trs + ti) * tcs + tj) * CH + c) * HS * HS + (u - ti * HS) * HS + (w - tj * HS)];
+    constexpr int TILE = CH * HD * HD;
+    const unsigned tiles = (unsigned)planes * trd * tcd;
+    for (unsigned T = blockIdx.x; T < tiles; T += gridDim.x) {
+        const unsigned j = T % (unsigned)tcd, q = T / (unsigned)tcd, i = q % (unsigned)trd, pl = q / (unsigned)trd;
+        const float* __restrict__ sp = src + (size_t)pl * trs * tcs * CH * HS * HS;
+        float* __restrict__ d = dst + (size_t)T * TILE;
+        for (int e = threadIdx.x; e < TILE; e += 256) {
+            const int x = e % HD, y = (e / HD) % HD, c = e / (HD * HD);
+            const int u = SD * (int)i + y, w = SD * (int)j + x;
+            const int ti = u / HS, tj = w / HS;
+            d[e] = sp[(((size_t)ti * tcs + tj) * CH + c) * HS * HS + (u - ti * HS) * HS + (w - tj * HS)];
+        }
     }
 }
 
@@ -121,28 +126,27 @@ __global__ __launch_bounds__(256) void dense_retile_kernel(const float* __restri
 // [slices x 16][t5r][t5c][40][5][5] taken every 3 rows / columns of the pooled map
 __global__ __launch_bounds__(256) void dense_pool_retile_kernel(const float* __restrict__ src, int t4r, int t4c, float* __restrict__ dst, int t5r, int t5c,
                                                                 int slices) {
-    const long total = (long)slices * 16 * t5r * t5c * 40 * 25;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        long k = e;
-        const int x = k % 5; k /= 5;
-        const int y = k % 5; k /= 5;
-        const int c = k % 40; k /= 40;
-        const int j = k % t5c; k /= t5c;
-        const int i = k % t5r; k /= t5r;
-        const int ph = k & 15, s = (int)(k >> 4);
+    const unsigned tiles = (unsigned)slices * 16u * t5r * t5c;
+    for (unsigned T = blockIdx.x; T < tiles; T += gridDim.x) {
+        const unsigned j = T % (unsigned)t5c, k1 = T / (unsigned)t5c, i = k1 % (unsigned)t5r, k = k1 / (unsigned)t5r;
+        const int ph = (int)(k & 15u), sl = (int)(k >> 4);
         const int p = ph >> 2, qr = (ph >> 1) & 1, qc = ph & 1;
-        const int a = 3 * i + y, b = 3 * j + x;
-        const float* __restrict__ base = src + ((size_t)(s * 4 + p) * t4r * t4c) * 4000;
-        float m = -3.0e38f;
+        const float* __restrict__ base = src + ((size_t)(sl * 4 + p) * t4r * t4c) * 4000;
+        float* __restrict__ d = dst + (size_t)T * 1000;
+        for (int e = threadIdx.x; e < 1000; e += 256) {
+            const int x = e % 5, y = (e / 5) % 5, c = e / 25;
+            const int a = 3 * (int)i + y, b = 3 * (int)j + x;
+            float m = -3.0e38f;
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+            for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int u = 2 * a + qr + dy, w = 2 * b + qc + dx;
-                const int ti = u / 10, tj = w / 10;
-                m = fmaxf(m, base[((size_t)ti * t4c + tj) * 4000 + c * 100 + (u - ti * 10) * 10 + (w - tj * 10)]);
-            }
-        dst[e] = m;
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int u = 2 * a + qr + dy, w = 2 * b + qc + dx;
+                    const int ti = u / 10, tj = w / 10;
+                    m = fmaxf(m, base[((size_t)ti * t4c + tj) * 4000 + c * 100 + (u - ti * 10) * 10 + (w - tj * 10)]);
+                }
+            d[e] = m;
+        }
     }
 }
 
@@ -176,5 +180,6 @@ __global__ __launch_bounds__(256) void dense_features_kernel(DenseView v, int s_
 }
 
 inline dim3 dense_grid(long total) { return dim3((unsigned)std::min<long>((total + 255) / 256, 65536)); }
+inline dim3 dense_tile_grid(long tiles) { return dim3((unsigned)std::max<long>(1, std::min<long>(tiles, 1 << 20))); }   // one workgroup per tile
 
 }  // namespace scs

@@ -535,19 +535,19 @@ int dense_towers(scs_ctx* h, const float* vol, int dx, int dy, int dz, const int
             a.w[v] = pk.convw[v][1]; a.bias[v] = pk.convb[v][1]; a.w1[v] = pk.conv1w[v]; a.out[v] = W + B.t1;
             conv_launch<CfgConv12V>(a, st, 1);
             // conv3 on 14x14 tiles every 12
-            hipLaunchKernelGGL((dense_retile_kernel<20, 14, 14, 12>), dense_grid((long)V.n3(cur) * 20 * 196), dim3(256), 0, st,
+            hipLaunchKernelGGL((dense_retile_kernel<20, 14, 14, 12>), dense_tile_grid(V.n3(cur)), dim3(256), 0, st,
                                W + B.t1, V.t1r, V.t1c, W + B.i3, V.t3r, V.t3c, cur * 4);
             a.n = V.n3(cur); a.centers = nullptr;
             a.in[v] = W + B.i3; a.w[v] = pk.convw[v][2]; a.bias[v] = pk.convb[v][2]; a.out[v] = W + B.o3;
             conv_launch<CfgConv3>(a, st, 1);
             // conv4 on 12x12 tiles every 10
-            hipLaunchKernelGGL((dense_retile_kernel<40, 12, 12, 10>), dense_grid((long)V.n4(cur) * 40 * 144), dim3(256), 0, st,
+            hipLaunchKernelGGL((dense_retile_kernel<40, 12, 12, 10>), dense_tile_grid(V.n4(cur)), dim3(256), 0, st,
                                W + B.o3, V.t3r, V.t3c, W + B.i4, V.t4r, V.t4c, cur * 4);
             a.n = V.n4(cur);
             a.in[v] = W + B.i4; a.w[v] = pk.convw[v][3]; a.bias[v] = pk.convb[v][3]; a.out[v] = W + B.o4;
             conv_launch<CfgConv4NP>(a, st, 1);
             // pool2 (four window origins) and conv5 on 5x5 tiles every 3
-            hipLaunchKernelGGL(dense_pool_retile_kernel, dense_grid((long)V.n5(cur) * 40 * 25), dim3(256), 0, st,
+            hipLaunchKernelGGL(dense_pool_retile_kernel, dense_tile_grid(V.n5(cur)), dim3(256), 0, st,
                                W + B.o4, V.t4r, V.t4c, W + B.i5, V.t5r, V.t5c, cur);
             a.n = V.n5(cur);
             a.in[v] = W + B.i5; a.w[v] = pk.convw[v][4]; a.bias[v] = pk.convb[v][4]; a.out[v] = W + B.o5;

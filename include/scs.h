@@ -73,6 +73,23 @@ int scs_get_params(scs_handle h, float* host_arena, size_t n);
  * Returns the value in effect (pass 0 to query). */
 int scs_set_chunk(scs_handle h, int patches_per_chunk);
 
+/* Behaviour switches of the training step, per handle.  Each is initialised ONCE, at scs_create, from the environment variable
+ * named below (tuning scripts), and changed afterwards only here - the step never reads the environment.  value -1 = the
+ * library's default.  Names:
+ *   "fin_max_batch"          SCS_FIN_MAX_BATCH          batch-norm finalize inside the producing conv kernel up to this batch
+ *   "bn1_fused_max_batch"    SCS_BN1_FUSED_MAX_BATCH    conv1's statistics finalized inside the step's first launch up to this batch
+ *   "dense_chain_max_batch"  SCS_DENSE_CHAIN_MAX_BATCH  the dense head as one launch up to this batch (at most 384; only on devices
+ *                                                       where a probe launch finds 8 XCDs with equal shares of a grid)
+ *   "c5_fused_max_batch"     SCS_C5_FUSED_MAX_BATCH     the conv5 block's backward as one launch up to this batch
+ *   "tail_fused"             SCS_TAIL_FUSED             0: bn5 / bn5-backward as launches of their own (the round-3 step)
+ *   "split_max_batch"        SCS_SPLIT_MAX_BATCH        channel-split conv tilings (two workgroups per patch-tower) up to this batch
+ *   "train_one_stream"       SCS_TRAIN_ONE_STREAM       1: every launch in order on the caller's stream
+ *   "tail_side"              SCS_TAIL_SIDE              1: the round-2 stream order of the step's last launches
+ *   "wg_slices_conv2".."wg_slices_conv5"  SCS_WG_SLICES="b,c,d,e"  batch slices of the weight-gradient kernels (0 = default)
+ * Unknown name or value outside [-1, 2^20]: SCS_ERR_ARG. */
+int scs_set_option(scs_handle h, const char* name, int64_t value);
+int scs_get_option(scs_handle h, const char* name, int64_t* value);
+
 /* Deterministic forward on n patches (device pointers).  probs and/or labels may be NULL.
  * labels[i] = argmax_c probs[i][c] (first maximum), i.e. nolearn's predict = argmax(predict_proba).
  * Replaces: net.predict / net.predict_proba (base.py:425-428, 435-438) - one pass yields both. */
@@ -120,8 +137,10 @@ int scs_dilate_mask(scs_handle h, uint8_t* mask_dev, uint8_t* scratch_dev, int d
 #define SCS_F64 5
 
 /* out[x][y][z] (float32, C order) = (v - mean) / std, mean and population std over the NON-ZERO voxels of the raw volume,
- * evaluated in double and rounded once - the inference normalisation `(image - image[nz].mean()) / image[nz].std()` of
- * load_patch_batch (base.py:357-358) followed by the float32 cast of the patches (base.py:380-386).
+ * evaluated in double (two passes: mean, then the squared deviations about it) and rounded once - the inference normalisation
+ * `(image - image[nz].mean()) / image[nz].std()` of load_patch_batch (base.py:357-358) followed by the float32 cast of the
+ * patches (base.py:380-386).  Deviation: for a FLOAT32 T1 the reference evaluates that formula in float32 throughout (NumPy
+ * pairwise sums); the result here differs from it by a few float32 ulps (bounded in tests/test_gpu_scan.py).
  *   raw_dev        the voxels as stored (dtype: SCS_U8 .. SCS_F64), in the file's Fortran order (x fastest; fortran_order = 1)
  *                  or in C order (z fastest; 0)
  *   scratch_dev    3 * 1024 + 3 doubles: per-workgroup partial sums in a fixed order (the result is deterministic), then
@@ -149,9 +168,9 @@ int scs_roi_centers(scs_handle h, const uint8_t* mask_dev, int dim_x, int dim_y,
  * densely (an ROI).  The towers are valid convolutions and two 2x2 poolings, so the block-5 output of a patch is a 3x3 window of
  * a per-slice map that depends only on the patch origin modulo 4; the maps are computed tile by tile with the kernels of the
  * patch path (csrc/dense_eval.h).  box (HOST memory): xmin, xmax, ymin, ymax, zmin, zmax of the centres - every centre must lie
- * inside it (a centre outside reads nothing and gets an undefined row of results); the work grows with the box volume, not
- * with n.  Scratch is grown inside the handle (at most ~0.8 GB of tiles +
- * 6.5 KB per centre).
+ * inside it: the centres are checked against the box on the device and the call returns SCS_ERR_ARG (results invalid) when one
+ * lies outside; the work grows with the box volume, not with n.  The call synchronises `stream` before it returns (it reads that
+ * check back).  Scratch is grown inside the handle (at most ~0.8 GB of tiles + 6.5 KB per centre).
  * Replaces: load_patch_batch + get_patches + net.predict_proba of base.py:380-397, 272-308, 425-438 for dense centre sets. */
 int scs_forward_volume_shared(scs_handle h, const float* vol_dev, int dim_x, int dim_y, int dim_z, const int32_t* centers_dev,
                               const float* atlas_rows_dev, int64_t n, const int32_t* box_host, float* probs_dev,
@@ -237,6 +256,13 @@ int scs_get_train_buffer(scs_handle h, int which, float* host_out, size_t count)
  * what a data-parallel caller all-reduces (RCCL) between scs_train_step and scs_adam_apply. */
 int scs_param_arena(scs_handle h, float** dev_ptr, size_t* n);   /* marks the inference operands stale: the caller may write */
 int scs_grad_arena(scs_handle h, float** dev_ptr, size_t* n);
+
+/* Two-bucket gradient exchange (data-parallel training): makes `stream` wait until the gradients of the dense HEAD (FC1, fc_2,
+ * out_layer: floats [*first_float, *first_float + *n_floats) of the gradient arena, its contiguous tail, 51 % of it) written by
+ * the most recent scs_train_step are final - the grouped dense weight-gradient launch, which ends ~0.3 ms before the step does.
+ * A caller may all-reduce that bucket on `stream` while the conv backward pass is still running and exchange the rest
+ * ([0, *first_float): the towers) behind the step; scs_adam_apply must be ordered behind both.  SCS_ERR_STATE before the first step. */
+int scs_wait_head_grads(scs_handle h, void* stream, size_t* first_float, size_t* n_floats);
 
 /* Device address of the mean loss of the most recent scs_train_step (one float, valid once that step's work on its
  * stream has completed).  Lets a training loop collect the per-batch losses with device-side copies and read them back

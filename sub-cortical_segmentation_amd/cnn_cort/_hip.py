@@ -29,6 +29,8 @@ SIGNATURES = {
     'scs_set_params': (_c.c_int, [_vp, _vp, _c.c_size_t]),
     'scs_get_params': (_c.c_int, [_vp, _vp, _c.c_size_t]),
     'scs_set_chunk': (_c.c_int, [_vp, _c.c_int]),
+    'scs_set_option': (_c.c_int, [_vp, _c.c_char_p, _c.c_int64]),
+    'scs_get_option': (_c.c_int, [_vp, _c.c_char_p, _c.POINTER(_c.c_int64)]),
     'scs_forward': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
     'scs_forward_host': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
     'scs_forward_volume': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     'scs_param_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
     'scs_train_loss': (_c.c_int, [_vp, _c.POINTER(_c.c_void_p)]),
     'scs_grad_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
+    'scs_wait_head_grads': (_c.c_int, [_vp, _vp, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
     'scs_adam_apply': (_c.c_int, [_vp, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
     'scs_eval_batch': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.POINTER(_c.c_double),
                                   _c.POINTER(_c.c_int64), _vp]),
@@ -258,6 +261,15 @@ class Handle:
 
     def set_chunk(self, n):
         return self.lib.scs_set_chunk(self.h, int(n))
+
+    def set_option(self, name, value):
+        """Behaviour switch of the training step on THIS handle (include/scs.h: scs_set_option); -1 restores the default."""
+        _check(self.lib.scs_set_option(self.h, name.encode(), int(value)), 'scs_set_option(%s)' % name)
+
+    def get_option(self, name):
+        v = ctypes.c_int64(0)
+        _check(self.lib.scs_get_option(self.h, name.encode(), ctypes.byref(v)), 'scs_get_option(%s)' % name)
+        return int(v.value)
 
     # ---- inference
     def _check_inputs(self, ax, co, sa, atlas, n, y=None, probs=None, labels=None):
@@ -485,6 +497,13 @@ class Handle:
 
     def grad_arena(self):
         return self._arena(self.lib.scs_grad_arena)
+
+    def wait_head_grads(self, stream):
+        """Make `stream` wait for the dense head's gradients of the last train_step (scs_wait_head_grads) -> (first float, count) of
+        that bucket in the gradient arena."""
+        a, b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _check(self.lib.scs_wait_head_grads(self.h, stream, ctypes.byref(a), ctypes.byref(b)), 'scs_wait_head_grads')
+        return int(a.value), int(b.value)
 
     def param_arena(self):
         return self._arena(self.lib.scs_param_arena)

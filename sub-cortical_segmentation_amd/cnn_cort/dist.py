@@ -122,32 +122,85 @@ def wrap_device_floats(ptr, n, device):
     return t
 
 
-def allreduce_flat(t, n_active):
+def allreduce_flat(t, n_active, first=None):
     """Sum all-reduce of a flat tensor (any backend); returns the scale that turns the sum into the mean over
-    the ranks that contributed."""
+    the ranks that contributed.  first: exchange as two buckets, t[first:] then t[:first] (the order allreduce_grads uses:
+    the dense head's tail of the arena, then the towers) - element for element the same sums."""
     if is_dist() and world_size() > 1:
         td = _td()
-        td.all_reduce(t, op=td.ReduceOp.SUM)
+        if first is None:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+        else:
+            td.all_reduce(t[first:], op=td.ReduceOp.SUM)
+            td.all_reduce(t[:first], op=td.ReduceOp.SUM)
     return 1.0 / max(1, n_active)
 
 
-def allreduce_grads(handle, active, stream=0, n_active=None):
+_comm_streams = {}
+
+
+def dp_buckets():
+    """Buckets of the gradient exchange: 1 (default: one all-reduce of the whole arena behind the step) or 2 (SCS_DP_BUCKETS=2:
+    the dense head's bucket is exchanged on a communication stream while the conv backward pass still runs)."""
+    try:
+        return 2 if int(os.environ.get('SCS_DP_BUCKETS', '1')) == 2 else 1
+    except ValueError:
+        return 1
+
+
+def allreduce_grads(handle, active, stream=0, n_active=None, buckets=None):
     """All-reduce the gradient arena of a libscs handle across ranks (RCCL); returns grad_scale for Adam.
-    `active` False = this rank had no batch this step: its arena is zeroed first."""
+    `active` False = this rank had no batch this step: its arena is zeroed first.
+
+    buckets = 2 (default from SCS_DP_BUCKETS): the arena goes in two collectives, in the same order on every rank -
+    first its tail, the dense head's gradients (FC1 / fc_2 / out_layer, 51 % of the floats), which scs_train_step finishes
+    ~0.3 ms before the step ends: a communication stream waits for exactly that (scs_wait_head_grads) and the all-reduce is issued
+    there, so it runs beside the conv backward pass; then the towers' bucket on the caller's stream behind the step.  The
+    caller's stream waits for the first bucket before this returns (scs_adam_apply is enqueued behind both).  The sums are the
+    same element by element: one bucket or two give the same gradients."""
     if not is_dist():                         # a process group of ONE rank still runs the collective (RCCL rehearsal on one GPU)
         return 1.0
     import torch
     ptr, n = handle.grad_arena()
     g = wrap_device_floats(ptr, n, handle.device)
-    if not active:
-        g.zero_()
     td = _td()
-    td.all_reduce(g, op=td.ReduceOp.SUM)
+    if buckets is None:
+        buckets = dp_buckets()
+    if buckets == 2 and active:
+        dev = g.device
+        comm = _comm_streams.get(dev)
+        if comm is None:
+            comm = _comm_streams[dev] = torch.cuda.Stream(device=dev)
+        first, count = handle.wait_head_grads(comm.cuda_stream)
+        assert first + count == n
+        with torch.cuda.stream(comm):
+            td.all_reduce(g[first:], op=td.ReduceOp.SUM)           # issued on (behind) the communication stream
+            done = torch.cuda.Event()
+            done.record(comm)
+        td.all_reduce(g[:first], op=td.ReduceOp.SUM)               # the towers: behind the step on the caller's stream
+        torch.cuda.current_stream(dev).wait_event(done)
+    else:
+        if not active:
+            g.zero_()
+        if buckets == 2:                                           # same collectives, same order as the active ranks
+            first, count = handle_head_bucket(n)
+            td.all_reduce(g[first:], op=td.ReduceOp.SUM)
+            td.all_reduce(g[:first], op=td.ReduceOp.SUM)
+        else:
+            td.all_reduce(g, op=td.ReduceOp.SUM)
     if n_active is None:                      # callers that know the schedule pass it and skip this exchange
         flag = torch.tensor([1.0 if active else 0.0], device=g.device)
         td.all_reduce(flag, op=td.ReduceOp.SUM)
         n_active = int(flag.item())
     return 1.0 / max(1, n_active)
+
+
+def handle_head_bucket(n):
+    """(first float, count) of the dense head's bucket in an arena of n floats - the layout constant a rank WITHOUT a step of
+    its own needs (an active rank gets it from scs_wait_head_grads)."""
+    from . import params as P
+    first = P.head_first_float()
+    return first, n - first
 
 
 def sync_params(handle):
@@ -183,6 +236,18 @@ def max_scalar(value):
     dev = 'cuda' if td.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
     td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t[0])
+
+
+def min_scalar(value):
+    """Min over ranks (bench: the fastest rank's time next to the slowest's, so stragglers show)."""
+    if world_size() == 1:
+        return float(value)
+    import torch
+    td = _td()
+    dev = 'cuda' if td.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.MIN)
     return float(t[0])
 
 

@@ -26,6 +26,7 @@ net (nets.py:249-253 swallows every exception); files are a float32 blob + JSON 
 """
 import json
 import os
+import threading
 import time
 
 import numpy as np
@@ -129,6 +130,8 @@ class Net:
         self.train_history_ = []
         self._params = None          # host copy, Lasagne layout (OrderedDict)
         self._handle = None          # libscs handle (created lazily on the device)
+        self._handle_lock = threading.RLock()
+        self._tls = threading.local()     # per-thread side streams (side_stream)
         self._dirty = True           # host params newer than device
         self._dev_newer = False      # device params newer than host (after training steps)
         self._step = 0
@@ -148,19 +151,23 @@ class Net:
         return int(self.device)
 
     def _ensure_handle(self):
+        """The libscs handle with the current parameters on the device.  Check-then-act on shared state: test_cohort's reader
+        threads (normalize_volume, roi_centers) and the main thread may all arrive at a cold Net at once, so creation and the
+        parameter upload happen under a lock - one handle, parameters set before anyone sees it."""
         from . import _hip
         torch = self._torch()
-        if self._handle is None:
-            torch.cuda.set_device(self._dev())
-            self._handle = _hip.Handle(self._dev())
-        if self._params is None:
-            self._params = P.init_params(self.seed)       # Lasagne default initialisers (training from scratch)
-            self._dirty = True
-        if self._dirty:
-            self._handle.set_params(P.params_to_flat(self._params))
-            self._dirty = False
-            self._dev_newer = False
-        return self._handle
+        with self._handle_lock:
+            if self._handle is None:
+                torch.cuda.set_device(self._dev())
+                self._handle = _hip.Handle(self._dev())
+            if self._params is None:
+                self._params = P.init_params(self.seed)       # Lasagne default initialisers (training from scratch)
+                self._dirty = True
+            if self._dirty:
+                self._handle.set_params(P.params_to_flat(self._params))
+                self._dirty = False
+                self._dev_newer = False
+            return self._handle
 
     def _sync_host(self):
         if self._dev_newer and self._handle is not None:
@@ -416,10 +423,7 @@ class Net:
     def side_stream(self):
         """Context manager that makes a stream of the calling THREAD's own the current one (test_cohort's reader threads prepare
         the next subjects on the device while the main thread's stream runs the classifier)."""
-        import threading
         torch = self._torch()
-        if not hasattr(self, '_tls'):
-            self._tls = threading.local()
         if getattr(self._tls, 'stream', None) is None:
             self._tls.stream = torch.cuda.Stream(device=self._dev())
         return torch.cuda.stream(self._tls.stream)

@@ -358,6 +358,12 @@ def flat_to_params(flat):
     return params
 
 
+def head_first_float():
+    """First float of the dense head (FC1 .. out_layer: the contiguous tail of the arena) - the second bucket of the
+    two-bucket gradient exchange (csrc/scs_common.h head_off().fc1W; scs_wait_head_grads returns the same number)."""
+    return flat_offsets()[('FC1', 0)][0]
+
+
 def flat_offsets():
     """{(layer_name, array_index): (offset, shape)} into the flat arena."""
     out, off = {}, 0

@@ -61,3 +61,42 @@ def toy_labels(shape, atlas, seed=2):
     ring = ndimage.binary_dilation(fg, iterations=3) & ~fg
     lab[ring] = 15
     return lab
+
+
+def steer_matrix():
+    """[15][15]: row k = the prior vector that makes the shipped net answer class (k + 1) for k < 14 and class 0 (background) for
+    k = 14, i.e. prior channel k steers towards the structure the reference's atlas stores in channel k (channel 14 = background,
+    SURVEY F10).  Vectors: cnn_cort/steer15.json, written by tools/make_steer.py."""
+    import json
+    import os
+    v = np.asarray(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'steer15.json')))['vectors'], np.float32)
+    return np.concatenate([v[1:], v[:1]], axis=0)
+
+
+def steered_atlas(shape, seed=1, radius=(0.10, 0.20)):
+    """Prior [X,Y,Z,15] f32 of a synthetic subject on which the shipped net shows EVERY class at volume level - what smooth volumes
+    with probability-like priors never do (classes 0 and 2 only).  Fourteen blobs as in toy_atlas; inside
+    blob k the prior row is the vector that makes class k + 1 win (steer_matrix), fading linearly into the background vector
+    towards the blob's rim (mixtures: unsaturated probabilities and near ties there), the background vector between the blobs, and
+    all-zero rows far away (the zero-row -> background rule of base.py:391-394).  Returns (prior, structure map: 0 = none,
+    1..14 = blob) - the map's non-zero voxels are what a registered sub-cortical mask would cover."""
+    rng = np.random.RandomState(seed)
+    M = steer_matrix()
+    axes = [np.linspace(-1, 1, s) for s in shape]
+    best = np.zeros(shape, np.float32)
+    who = np.zeros(shape, np.int8)
+    for c in range(14):
+        ctr = rng.uniform(-0.25, 0.25, 3)
+        rad = rng.uniform(*radius)
+        ex, ey, ez = [np.exp(-(a - m) ** 2 / (2 * rad ** 2)).astype(np.float32) for a, m in zip(axes, ctr)]   # a Gaussian blob is separable
+        f = ex[:, None, None] * ey[None, :, None] * ez[None, None, :]
+        take = f > best
+        best[take] = f[take]
+        who[take] = c + 1
+    inside = best > 0.2
+    prior = np.zeros(tuple(shape) + (15,), np.float32)
+    near = np.flatnonzero(best >= 0.02)                        # rows elsewhere stay all zero
+    b = best.ravel()[near]
+    wgt = np.clip((b - 0.2) / 0.3, 0.0, 1.0).astype(np.float32)[:, None]
+    prior.reshape(-1, 15)[near] = wgt * M[who.ravel()[near] - 1] + (1.0 - wgt) * M[14]
+    return prior, np.where(inside, who, 0).astype(np.uint8)

@@ -24,7 +24,8 @@
 //     lines (row strides 540, 556, 272, 16 floats from 256-byte aligned bases), so no line is shared with another cluster;
 //   * the counters are zeroed by the prep launch at the start of every step.  A poll that does not complete within
 //     kChainSpinLimit rounds (an XCD that did not receive whole clusters) gives up, poisons the loss of its rows with NaN and lets
-//     the kernel end: wrong placement is loud, never silent.
+//     the kernel end; the row losses are NaN from the prep launch until a cluster writes them, and the host takes this form only
+//     after a probe launch on the device (chain_placement_probe): wrong placement is loud, never silent.
 // The grid (72 x ceil(row blocks / 8) workgroups of 512 threads, at most kChainMaxBatch rows) is co-resident by size.  Tickets are
 // taken in arrival order, so the first nine workgroups of a launch that become resident on an XCD always form a complete
 // cluster, finish and free their CUs: two training processes sharing one GPU (whose launches together may exceed the CUs) still
@@ -524,7 +525,14 @@ __global__ __launch_bounds__(512, 1) void dense_chain_kernel(DenseChainArgs a) {
     __syncthreads();                                            // s_flag is reused by the barriers
     const int cluster = ticket / kChainMembers, j = ticket - cluster * kChainMembers;
     const int block = cluster * kXcds + xcd;
-    if (cluster >= kChainClustersPerXcd || block >= nblocks) return;   // a whole cluster leaves together
+    if (cluster >= kChainClustersPerXcd) {
+        // more workgroups on this XCD than a launch can place there: another XCD is short of them and its row blocks will never
+        // be computed (their row losses keep the NaN the prep launch wrote; this one says so too).  The host only uses this
+        // kernel on devices where a probe launch saw 8 equal shares (scs_train.hip: chain_placement_probe).
+        if (threadIdx.x == 0) a.loss_rows[0] = __builtin_nanf("");
+        return;
+    }
+    if (block >= nblocks) return;                               // the grid is rounded up to whole rounds of 8 row blocks: a whole cluster leaves together
     const int m0 = block * 16;
     unsigned int* ctr = xbase + (size_t)(1 + cluster) * kChainLine;
     ChainStamper ts{a.stamps ? a.stamps + (size_t)(block * kChainMembers + j) * kChainStamps : nullptr, 0};

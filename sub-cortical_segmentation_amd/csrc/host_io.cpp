@@ -10,7 +10,11 @@
 // word copies, the output goes through a 1 MB window that stays in cache and is never written to memory as a whole, and only
 // the requested elements are copied out.  It stops as soon as the last requested element has been produced.
 //
-// The member's ISIZE is checked; its CRC-32 is NOT (that alone costs as much as the system zlib's whole inflate).
+// The member's ISIZE is always checked.  Its CRC-32 is checked whenever a member is inflated to its end with the check on:
+// scs_gz_read (T1 / mask volumes: whole-file reads) and scs_gz_gather calls that ask for the inflated length (whole stream);
+// SCS_GZ_NOCRC=1 switches it off.  A gather that stops at its last requested element (the 755 MB prior: the ROI ends long
+// before the stream does) never sees the trailer and takes no CRC - INTEGRATION.md says so.  The CRC of the produced bytes
+// is slicing-by-8 with zero runs folded by a precomputed operator (the tables of the writer below).
 #include <cerrno>
 #include <cstdarg>
 #include <cstdint>
@@ -126,11 +130,21 @@ struct Gather {
     bool finished() const { return i >= n && (!range_out || copied >= range_hi); }
 };
 
+uint32_t crc_feed(uint32_t reg, const uint8_t* p, size_t n);      // CRC-32 register update (defined with the writer's tables below)
+
 struct Window {
     std::vector<uint8_t> buf;
     size_t w = 0;           // bytes in the window
     int64_t base = 0;       // stream offset of buf[0]
+    // CRC-32 of the current member's output (crc_on): register, and the stream offset up to which it has been taken
+    bool crc_on = false;
+    uint32_t crc_reg = 0xFFFFFFFFu;
+    int64_t crc_pos = 0;
     Window() : buf(kHist + kChunk + kSlack) {}
+    void crc_catch_up() {
+        const int64_t have = base + (int64_t)w;
+        if (crc_on && have > crc_pos) { crc_reg = crc_feed(crc_reg, buf.data() + (crc_pos - base), (size_t)(have - crc_pos)); crc_pos = have; }
+    }
     // hand the produced bytes to the gather, keep the last kHist bytes as match history
     void flush(Gather& g) {
         const int64_t have = base + (int64_t)w;
@@ -143,6 +157,7 @@ struct Window {
             memcpy(g.out + (size_t)g.i * g.elem, buf.data() + (g.off[g.i] - base), (size_t)g.elem);
             ++g.i;
         }
+        crc_catch_up();                                             // before the bytes leave the window
         if (w > kHist) {
             const size_t keep = kHist;
             memmove(buf.data(), buf.data() + (w - keep), keep);
@@ -251,7 +266,7 @@ int inflate_stream(Bits& b, Window& win, Gather& g, bool* done) {
 
 }  // namespace
 
-static int gz_drive(const char* path, Gather& g, int64_t* inflated_bytes) {
+static int gz_drive(const char* path, Gather& g, int64_t* inflated_bytes, bool want_crc) {
     using scs::set_error;
     FILE* f = fopen(path, "rb");
     if (!f) { set_error("%s: %s", path, strerror(errno)); return SCS_ERR_ARG; }
@@ -267,6 +282,7 @@ static int gz_drive(const char* path, Gather& g, int64_t* inflated_bytes) {
         if (got != in.size()) { set_error("%s: short read", path); return SCS_ERR_ARG; }
     }
     Window win;
+    win.crc_on = want_crc && getenv("SCS_GZ_NOCRC") == nullptr;
     const uint8_t* p = in.data();
     const uint8_t* end = p + in.size();
     bool done = g.finished() && inflated_bytes == nullptr;
@@ -283,6 +299,7 @@ static int gz_drive(const char* path, Gather& g, int64_t* inflated_bytes) {
         {
             Bits b{p, end};
             const int64_t before = win.base + (int64_t)win.w;
+            win.crc_reg = 0xFFFFFFFFu; win.crc_pos = before;                 // the CRC is per member
             if (inflate_stream(b, win, g, &done) != 0) { set_error("%s: corrupt or truncated deflate stream", path); return SCS_ERR_ARG; }
             if (done) break;
             // unread whole bytes in the accumulator go back to the input
@@ -292,6 +309,11 @@ static int gz_drive(const char* path, Gather& g, int64_t* inflated_bytes) {
             const uint32_t isize = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
             const int64_t produced = win.base + (int64_t)win.w - before;
             if ((uint32_t)produced != isize) { set_error("%s: gzip member length mismatch", path); return SCS_ERR_ARG; }
+            if (win.crc_on) {
+                win.crc_catch_up();
+                const uint32_t want = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                if (~win.crc_reg != want) { set_error("%s: gzip member CRC-32 mismatch (corrupted file)", path); return SCS_ERR_ARG; }
+            }
             p += 8;
         }
         win.flush(g);
@@ -314,7 +336,7 @@ extern "C" int scs_gz_gather(const char* path, const int64_t* byte_offsets, int6
         if (byte_offsets[k] < byte_offsets[k - 1]) { set_error("bad argument: offsets must ascend"); return SCS_ERR_ARG; }
     if (n && byte_offsets[0] < 0) { set_error("bad argument: negative offset"); return SCS_ERR_ARG; }
     Gather g{byte_offsets, n, 0, elem_bytes, static_cast<uint8_t*>(out)};
-    return gz_drive(path, g, inflated_bytes);
+    return gz_drive(path, g, inflated_bytes, inflated_bytes != nullptr);
 }
 
 extern "C" int scs_gz_read(const char* path, int64_t offset, int64_t nbytes, void* out) {
@@ -323,7 +345,7 @@ extern "C" int scs_gz_read(const char* path, int64_t offset, int64_t nbytes, voi
     Gather g{nullptr, 0, 0, 1, nullptr};
     g.range_out = static_cast<uint8_t*>(out); g.range_lo = offset; g.range_hi = offset + nbytes;
     if (nbytes == 0) return SCS_OK;
-    return gz_drive(path, g, nullptr);
+    return gz_drive(path, g, nullptr, true);
 }
 
 // ===================================================================================== a deflate WRITER for sparse volumes
@@ -413,6 +435,28 @@ struct FixedCodes {
 };
 
 static const CrcTables& crc_tables() { static const CrcTables t; return t; }
+}  // namespace scs
+namespace {
+// register update over n produced bytes: runs of zero words through the zero-run operator, the rest slicing-by-8
+uint32_t crc_feed(uint32_t reg, const uint8_t* p, size_t n) {
+    const scs::CrcTables& C = scs::crc_tables();
+    size_t i = 0, span = 0;
+    while (i + 8 <= n) {
+        uint64_t v;
+        memcpy(&v, p + i, 8);
+        if (v != 0) { i += 8; continue; }
+        size_t q = i + 8;
+        while (q + 8 <= n) { memcpy(&v, p + q, 8); if (v != 0) break; q += 8; }
+        if (q - i >= 64) {                                           // short runs are not worth two operator applications
+            reg = C.zeros(C.bytes(reg, p + span, i - span), q - i);
+            span = q;
+        }
+        i = q;
+    }
+    return C.bytes(reg, p + span, n - span);
+}
+}  // namespace
+namespace scs {
 static const FixedCodes& fixed_codes() { static const FixedCodes t; return t; }
 
 struct BitWriter {

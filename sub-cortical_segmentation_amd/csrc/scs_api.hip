@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -231,40 +232,46 @@ __device__ __forceinline__ size_t file_index(long lin, int dx, int dy, int dz, i
     return (size_t)x + (size_t)dx * ((size_t)y + (size_t)dy * z);
 }
 
-// count, sum and sum of squares of the non-zero voxels: per-block partials in a fixed order (deterministic), in double
+// Statistics of the non-zero voxels in TWO passes (the volume is 25 MB: a pass is a few microseconds), per-block partials in a
+// fixed order (deterministic), in double: PASS 0 count and sum -> mean; PASS 1 the sum of squared deviations about that mean -
+// no E[x^2] - mean^2, whose digits go when the mean is large against the spread.
 constexpr int kStatBlocks = 1024;
-__global__ __launch_bounds__(256) void zscore_stats_kernel(const void* __restrict__ raw, int dtype, long n, double* __restrict__ part /*[kStatBlocks][3]*/) {
-    __shared__ double s_red[4][3];
-    double cnt = 0, sm = 0, sq = 0;
+template <int PASS>
+__global__ __launch_bounds__(256) void zscore_stats_kernel(const void* __restrict__ raw, int dtype, long n, const double* __restrict__ stat,
+                                                          double* __restrict__ part /*[kStatBlocks][2]*/) {
+    __shared__ double s_red[4][2];
+    const double mean = PASS ? stat[0] : 0.0;
+    double a = 0, b = 0;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)kStatBlocks * 256L) {
         const double v = raw_value(raw, dtype, (size_t)e);           // the statistics do not depend on the order
-        if (v != 0.0) { cnt += 1.0; sm += v; sq += v * v; }
+        if (v != 0.0) {
+            if (PASS == 0) { a += 1.0; b += v; } else { const double d = v - mean; a += d * d; }
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o); sm += __shfl_down(sm, o); sq += __shfl_down(sq, o); }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { s_red[wv][0] = cnt; s_red[wv][1] = sm; s_red[wv][2] = sq; }
+    if (lane == 0) { s_red[wv][0] = a; s_red[wv][1] = b; }
     __syncthreads();
-    if (threadIdx.x < 3)
-        part[blockIdx.x * 3 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+    if (threadIdx.x < 2)
+        part[blockIdx.x * 2 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
-// mean and population standard deviation from the partials -> stat[0] = mean, stat[1] = std, stat[2] = count
+// PASS 0: stat[0] = mean, stat[2] = count;  PASS 1: stat[1] = population standard deviation
+template <int PASS>
 __global__ __launch_bounds__(256) void zscore_final_kernel(const double* __restrict__ part, double* __restrict__ stat) {
-    __shared__ double s_red[4][3];
-    double cnt = 0, sm = 0, sq = 0;
-    for (int b = threadIdx.x; b < kStatBlocks; b += 256) { cnt += part[b * 3]; sm += part[b * 3 + 1]; sq += part[b * 3 + 2]; }
+    __shared__ double s_red[4][2];
+    double a = 0, b = 0;
+    for (int k = threadIdx.x; k < kStatBlocks; k += 256) { a += part[k * 2]; b += part[k * 2 + 1]; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_down(cnt, o); sm += __shfl_down(sm, o); sq += __shfl_down(sq, o); }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { s_red[wv][0] = cnt; s_red[wv][1] = sm; s_red[wv][2] = sq; }
+    if (lane == 0) { s_red[wv][0] = a; s_red[wv][1] = b; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        cnt = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
-        sm = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
-        sq = (s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2]);
-        const double mean = cnt > 0 ? sm / cnt : 0.0;
-        const double var = cnt > 0 ? fmax(sq / cnt - mean * mean, 0.0) : 0.0;
-        stat[0] = mean; stat[1] = sqrt(var); stat[2] = cnt;
+        a = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+        b = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+        if (PASS == 0) { stat[0] = a > 0 ? b / a : 0.0; stat[2] = a; }
+        else stat[1] = stat[2] > 0 ? sqrt(a / stat[2]) : 0.0;
     }
 }
 // out[x][y][z] = float((v - mean) / std), in double like the reference's inference path (base.py:358), then one rounding
@@ -593,6 +600,23 @@ int scs_create(int device, scs_handle* out) {
     scs_ctx* h = new (std::nothrow) scs_ctx();
     SCS_ARG(h != nullptr, "out of host memory");
     h->device = device;
+    {   // the behaviour switches of the training step: the environment is read here, once per handle
+        auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        scs_options& o = h->opt;
+        o.fin_max_batch = env_int("SCS_FIN_MAX_BATCH", -1);
+        o.bn1_fused_max_batch = env_int("SCS_BN1_FUSED_MAX_BATCH", -1);
+        o.dense_chain_max_batch = env_int("SCS_DENSE_CHAIN_MAX_BATCH", -1);
+        o.c5_fused_max_batch = env_int("SCS_C5_FUSED_MAX_BATCH", -1);
+        o.train_one_stream = getenv("SCS_TRAIN_ONE_STREAM") != nullptr;
+        o.tail_side = getenv("SCS_TAIL_SIDE") != nullptr;
+        o.tail_fused = env_int("SCS_TAIL_FUSED", -1);
+        o.split_max_batch = env_int("SCS_SPLIT_MAX_BATCH", -1);
+        if (const char* e = getenv("SCS_WG_SLICES")) {
+            int x[4];
+            if (sscanf(e, "%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3]) == 4)
+                for (int i = 0; i < 4; ++i) if (x[i] >= 1 && x[i] <= 256) o.wg_slices[i] = x[i];
+        }
+    }
     int rc = set_kernel_attrs();
     if (rc != SCS_OK) { delete h; return rc; }
     const size_t bytes = (size_t)SCS_N_PARAMS * sizeof(float);
@@ -622,6 +646,8 @@ int scs_destroy(scs_handle h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->dense_ws) (void)hipFree(h->dense_ws);
     if (h->dense_feat) (void)hipFree(h->dense_feat);
+    if (h->box_flag) (void)hipFree(h->box_flag);
+    if (h->box_flag_host) (void)hipHostFree(h->box_flag_host);
     if (h->stage_dev) (void)hipFree(h->stage_dev);
     if (h->last_train_event) (void)hipEventDestroy(h->last_train_event);
     if (h->host_compute) (void)hipStreamDestroy(h->host_compute);
@@ -653,6 +679,36 @@ int scs_get_params(scs_handle h, float* host_arena, size_t n) {
     SCS_HIP(hipSetDevice(h->device));
     SCS_HIP(hipDeviceSynchronize());
     SCS_HIP(hipMemcpy(host_arena, h->params, n * sizeof(float), hipMemcpyDeviceToHost));
+    return SCS_OK;
+}
+
+static int* option_slot(scs_ctx* h, const char* name) {
+    scs_options& o = h->opt;
+    struct { const char* n; int* p; } tab[] = {
+        {"fin_max_batch", &o.fin_max_batch}, {"bn1_fused_max_batch", &o.bn1_fused_max_batch},
+        {"dense_chain_max_batch", &o.dense_chain_max_batch}, {"c5_fused_max_batch", &o.c5_fused_max_batch},
+        {"train_one_stream", &o.train_one_stream}, {"tail_side", &o.tail_side}, {"tail_fused", &o.tail_fused},
+        {"split_max_batch", &o.split_max_batch},
+        {"wg_slices_conv2", &o.wg_slices[0]}, {"wg_slices_conv3", &o.wg_slices[1]}, {"wg_slices_conv4", &o.wg_slices[2]},
+        {"wg_slices_conv5", &o.wg_slices[3]}};
+    for (auto& t : tab) if (strcmp(t.n, name) == 0) return t.p;
+    return nullptr;
+}
+
+int scs_set_option(scs_handle h, const char* name, int64_t value) {
+    SCS_ARG(h && name, "null handle or option name");
+    int* slot = option_slot(h, name);
+    SCS_ARG(slot != nullptr, "unknown option name");
+    SCS_ARG(value >= -1 && value <= (1 << 20), "option value out of range");
+    *slot = (int)value;
+    return SCS_OK;
+}
+
+int scs_get_option(scs_handle h, const char* name, int64_t* value) {
+    SCS_ARG(h && name && value, "null handle, option name or output");
+    int* slot = option_slot(h, name);
+    SCS_ARG(slot != nullptr, "unknown option name");
+    *value = *slot;
     return SCS_OK;
 }
 
@@ -713,6 +769,17 @@ int scs_forward_volume_rows(scs_handle h, const float* vol, int dx, int dy, int 
     return forward_common(h, nullptr, nullptr, nullptr, atlas_rows, vol, dx, dy, dz, centers, nullptr, n, probs, labels, stream);
 }
 
+// centres outside the caller's box (xmin, xmax, ymin, ymax, zmin, zmax): the shared-tower path would skip them
+__global__ void box_check_kernel(const int32_t* __restrict__ centers, long n, int x0, int x1, int y0, int y1, int z0, int z1,
+                                 unsigned int* __restrict__ outside) {
+    unsigned int bad = 0;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        const int x = centers[3 * k], y = centers[3 * k + 1], z = centers[3 * k + 2];
+        bad += (x < x0 || x > x1 || y < y0 || y > y1 || z < z0 || z > z1) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(outside, bad);
+}
+
 int scs_forward_volume_shared(scs_handle h, const float* vol, int dx, int dy, int dz, const int32_t* centers,
                               const float* atlas_rows, int64_t n, const int32_t* box, float* probs, int32_t* labels, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
@@ -731,6 +798,15 @@ int scs_forward_volume_shared(scs_handle h, const float* vol, int dx, int dy, in
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
+    // every centre must lie inside the box (the tile maps cover nothing else): counted on the device in front of the work, read
+    // back behind it - a centre outside makes the call fail with SCS_ERR_ARG instead of leaving a stale row of results
+    if (!h->box_flag) {
+        SCS_HIP(hipMalloc(&h->box_flag, sizeof(unsigned int)));
+        SCS_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->box_flag_host), sizeof(unsigned int), hipHostMallocDefault));
+    }
+    SCS_HIP(hipMemsetAsync(h->box_flag, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(box_check_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, st, centers, (long)n,
+                       box[0], box[1], box[2], box[3], box[4], box[5], h->box_flag);
     rc = dense_towers(h, vol, dx, dy, dz, centers, n, box, st);
     if (rc != SCS_OK) return rc;
     for (int64_t s = 0; s < n; s += step) {
@@ -740,6 +816,12 @@ int scs_forward_volume_shared(scs_handle h, const float* vol, int dx, int dy, in
         rc = forward_head(h, c5, atlas_rows + s * 15, nullptr, 0, 0, 0, nullptr, nullptr, m, probs ? probs + s * 15 : nullptr,
                           labels ? labels + s : nullptr, st, nullptr, m, nullptr);
         if (rc != SCS_OK) return rc;
+    }
+    SCS_HIP(hipMemcpyAsync(h->box_flag_host, h->box_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    SCS_HIP(hipStreamSynchronize(st));
+    if (*h->box_flag_host != 0) {
+        set_error("scs_forward_volume_shared: %u of %lld centres lie outside the box; the results are invalid", *h->box_flag_host, (long long)n);
+        return SCS_ERR_ARG;
     }
     return SCS_OK;
 }
@@ -924,8 +1006,11 @@ int scs_zscore_volume(scs_handle h, const void* raw_dev, int dtype, int dx, int 
     SCS_HIP(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const long n = (long)dx * dy * dz;
-    hipLaunchKernelGGL(zscore_stats_kernel, dim3(kStatBlocks), dim3(256), 0, st, raw_dev, dtype, n, scratch_dev);
-    hipLaunchKernelGGL(zscore_final_kernel, dim3(1), dim3(256), 0, st, scratch_dev, scratch_dev + 3 * kStatBlocks);
+    double* stat = scratch_dev + 3 * kStatBlocks;
+    hipLaunchKernelGGL(zscore_stats_kernel<0>, dim3(kStatBlocks), dim3(256), 0, st, raw_dev, dtype, n, stat, scratch_dev);
+    hipLaunchKernelGGL(zscore_final_kernel<0>, dim3(1), dim3(256), 0, st, scratch_dev, stat);
+    hipLaunchKernelGGL(zscore_stats_kernel<1>, dim3(kStatBlocks), dim3(256), 0, st, raw_dev, dtype, n, stat, scratch_dev);
+    hipLaunchKernelGGL(zscore_final_kernel<1>, dim3(1), dim3(256), 0, st, scratch_dev, stat);
     const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 65535L * 8);
     hipLaunchKernelGGL(zscore_apply_kernel, dim3(blocks), dim3(256), 0, st, raw_dev, dtype, dx, dy, dz, fortran_order,
                        scratch_dev + 3 * kStatBlocks, out_dev);

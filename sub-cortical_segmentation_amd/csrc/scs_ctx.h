@@ -4,8 +4,24 @@
 
 struct TrainWs;
 
+// Behaviour switches of the training step, per handle: read ONCE from the environment when the handle is created (SCS_* below),
+// changed afterwards only through scs_set_option (include/scs.h).  -1 = the library's default bound.
+struct scs_options {
+    int fin_max_batch = -1;          // SCS_FIN_MAX_BATCH: batch-norm finalize inside the producing conv kernel up to this batch
+    int bn1_fused_max_batch = -1;    // SCS_BN1_FUSED_MAX_BATCH: conv1's statistics finalized inside the prep + moments launch
+    int dense_chain_max_batch = -1;  // SCS_DENSE_CHAIN_MAX_BATCH: the dense head as ONE launch up to this batch
+    int c5_fused_max_batch = -1;     // SCS_C5_FUSED_MAX_BATCH: the conv5 block's backward as one launch
+    int train_one_stream = 0;        // SCS_TRAIN_ONE_STREAM: every launch in order on the caller's stream
+    int tail_side = 0;               // SCS_TAIL_SIDE: the round-2 order of the step's tail
+    int wg_slices[4] = {0, 0, 0, 0}; // SCS_WG_SLICES="b,c,d,e": batch slices of the conv2..5 weight-gradient kernels (0 = default)
+    int tail_fused = -1;             // SCS_TAIL_FUSED: bn5 / bn5-backward / bn2 folded into their neighbours (-1 = default on)
+    int split_max_batch = -1;        // SCS_SPLIT_MAX_BATCH: channel-split conv tilings up to this batch (-1 = default)
+};
+
 struct scs_ctx {
     int device = 0;
+    scs_options opt{};
+    int chain_placement = 0;        // dense_chain.h: 0 = not probed yet, 1 = every XCD receives grid / 8 workgroups, -1 = it does not
     bool has_params = false;
     bool packed_dirty = false;     // parameter arena changed since the inference operands were packed
 
@@ -38,6 +54,8 @@ struct scs_ctx {
     // shared-tower evaluation of a whole subject (dense_eval.h): tile buffers of one slice batch, block-5 features of all voxels
     float* dense_ws = nullptr; size_t dense_ws_floats = 0;
     float* dense_feat = nullptr; size_t dense_feat_floats = 0;
+    unsigned int* box_flag = nullptr;          // scs_forward_volume_shared: centres outside the caller's box (device counter ...
+    unsigned int* box_flag_host = nullptr;     // ... and its pinned host copy)
 
     // host staging for the *_host entry points
     float* stage_dev = nullptr;       // [chunk] x (3*1024 + 15 + 15) floats + labels

@@ -96,6 +96,8 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_head = nullptr;              // recorded behind the grouped dense weight-gradient launch: the head's gradients are final
+    bool head_recorded = false;
     // scs_train_step_profiled
     bool prof = false;
     hipEvent_t pev[2 * scs::ST_COUNT]{};
@@ -125,6 +127,7 @@ void train_free(scs_ctx* h) {
     if (w->side) (void)hipStreamDestroy(w->side);
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
     if (w->ev_join) (void)hipEventDestroy(w->ev_join);
+    if (w->ev_head) (void)hipEventDestroy(w->ev_head);
     for (auto& e : w->pev) if (e) (void)hipEventDestroy(e);
     delete w;
     h->tws = nullptr;
@@ -180,6 +183,7 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
+        SCS_HIP(hipEventCreateWithFlags(&w->ev_head, hipEventDisableTiming));
     }
     if (n <= w->cap) return SCS_OK;
     SCS_HIP(hipDeviceSynchronize());           // a previous step may still be using the old buffers
@@ -242,6 +246,7 @@ struct PrepArgs {
     const float* fc2W; float* w2p;                           // fc_2.W [555][270] -> [556][272] zero padded
     unsigned int* chain_counter;                             // cluster barrier counters of the dense chain: zeroed here
     const float* c5W; float* wc5; int c5_tower_stride;       // conv5.W [60][40][9] of tower 0 (towers c5_tower_stride apart) -> Wc [3][60][368]
+    float* loss_rows;                                        // [n] row losses: NaN until the head of the step has written them
 };
 
 // blockIdx.y selects the job:
@@ -301,6 +306,9 @@ __device__ __forceinline__ void prep_body(const PrepArgs& a, int job, int bx) {
             if (c == 0) a.yb[row] = a.y[src];
         }
         for (int e = t0; e < kChainCounterWords; e += stride) a.chain_counter[e] = 0u;
+        // a row block the dense head never reaches (dense_chain.h: an XCD that did not receive its workgroups) leaves NaN in
+        // the step's loss instead of last step's value
+        for (int e = t0; e < a.n; e += stride) a.loss_rows[e] = __builtin_nanf("");
         for (int e = t0; e < kTowers * 60 * 360; e += stride) {           // Wc[t][o][c*9 + tap] = W[t][o][c][8 - tap]
             const int t = e / 21600, f = e - t * 21600, o = f / 360, rem = f - o * 360, c = rem / 9, k = rem - c * 9;
             a.wc5[(size_t)t * kC5WcFloats + o * kC5WS + c * 9 + (8 - k)] = a.c5W[(size_t)t * a.c5_tower_stride + f];
@@ -915,15 +923,11 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(WgFinalArgs a) {
 }
 
 // batch slices of the weight-gradient kernels per conv layer (workgroups = slices x bands x 3 towers; partials to sum =
-// slices x bands x parts).  SCS_WG_SLICES="b,c,d,e" (conv2..conv5) overrides for tuning runs.
+// slices x bands x parts).  The handle's wg_slices options (SCS_WG_SLICES="b,c,d,e" at scs_create: conv2..conv5) override for tuning runs.
 struct WgSlices { int v[kConvs]; };
-static WgSlices wg_slices() {
+static WgSlices wg_slices(const scs_options& o) {
     WgSlices s{{0, 64, 64, 32, 32}};
-    if (const char* e = getenv("SCS_WG_SLICES")) {
-        int x[4];
-        if (sscanf(e, "%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3]) == 4)
-            for (int i = 0; i < 4; ++i) if (x[i] >= 1 && x[i] <= 256) s.v[i + 1] = x[i];
-    }
+    for (int i = 0; i < 4; ++i) if (o.wg_slices[i] >= 1 && o.wg_slices[i] <= 256) s.v[i + 1] = o.wg_slices[i];
     return s;
 }
 
@@ -952,6 +956,35 @@ static int set_train_attrs(TrainWs* w, int device) {
     return SCS_OK;
 }
 
+// The one-launch dense head forms its clusters from per-XCD tickets and assumes that every XCD receives grid / 8 workgroups
+// (dense_chain.h).  That holds for the round-robin dispatch of a whole MI300X / MI355X (SPX mode, 8 XCDs, >= 216 CUs); it does not
+// on a CPX/DPX/QPX partition, a 6-XCD part or under a CU mask.  Checked at run time, once per handle: a probe launch of the chain's
+// largest grid in which every workgroup counts itself on its XCD.  Anything but 8 equal counts -> the per-layer launches.
+__global__ __launch_bounds__(512, 1) void chain_probe_kernel(unsigned int* counts /*[16]*/) {
+    if (threadIdx.x == 0) atomicAdd(counts + (xcc_id() & 15), 1u);
+}
+static int chain_placement_probe(scs_ctx* h, hipStream_t st) {
+    if (h->chain_placement != 0) return SCS_OK;
+    hipDeviceProp_t prop;
+    SCS_HIP(hipGetDeviceProperties(&prop, h->device));
+    const dim3 grid = dense_chain_grid(kChainMaxBatch);
+    h->chain_placement = -1;
+    if (prop.multiProcessorCount < (int)grid.x) return SCS_OK;              // the grid must be co-resident
+    unsigned int* d = nullptr;
+    unsigned int host[16];
+    SCS_HIP(hipMalloc(&d, sizeof(host)));
+    hipError_t e = hipMemsetAsync(d, 0, sizeof(host), st);
+    if (e == hipSuccess) { hipLaunchKernelGGL(chain_probe_kernel, grid, dim3(512), kChainLdsBytes, st, d); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, d, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    SCS_HIP(e);
+    bool ok = true;
+    for (int x = 0; x < 16; ++x) ok = ok && host[x] == (x < kXcds ? grid.x / kXcds : 0u);
+    h->chain_placement = ok ? 1 : -1;
+    return SCS_OK;
+}
+
 // ------------------------------------------------------------------------------------------- the step
 static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, const uint8_t* y, const int32_t* index, int n,
                            uint64_t dropout_seed, const uint8_t* masks_dev, float* loss_host, hipStream_t st, float* stage_ms) {
@@ -962,21 +995,23 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     TrainWs* w = h->tws;
     rc = set_train_attrs(w, h->device);
     if (rc != SCS_OK) return rc;
+    rc = chain_placement_probe(h, st);
+    if (rc != SCS_OK) return rc;
     float* P = h->params;
     float* G = h->grads;
     constexpr HeadOff H = head_off();
     constexpr TowerOff T0 = tower_off(0);
-    const bool one_stream = getenv("SCS_TRAIN_ONE_STREAM") != nullptr;             // tuning runs and the stream-order test: no side stream
+    const scs_options& opt = h->opt;                                               // behaviour switches: per handle (scs_set_option), no getenv per step
+    const bool one_stream = opt.train_one_stream != 0;                             // tuning runs and the stream-order test: no side stream
     // batch-norm finalize inside the producing conv kernel up to kFinMaxBatch, as a launch of its own beyond (train_cfg.h);
-    // SCS_FIN_MAX_BATCH overrides the bound (tests run both forms at one batch size)
-    const char* fin_env = getenv("SCS_FIN_MAX_BATCH");
-    const bool fin_in_kernel = n <= (fin_env ? atoi(fin_env) : kFinMaxBatch);
+    // option fin_max_batch overrides the bound (tests run both forms at one batch size)
+    const bool fin_in_kernel = n <= (opt.fin_max_batch >= 0 ? opt.fin_max_batch : kFinMaxBatch);
     hipStream_t sd = one_stream ? st : w->side;
     // The tail of the step.  The conv2 weight gradient - the last big kernel, which cannot start before the conv2 data gradient ends -
     // follows that kernel on the CALLER's stream (in order: no cross-stream wait on the critical path) with its reduction behind
     // it; the layer-1 launch and the reduction of the conv3..5 partials go to the side stream, behind the conv3 weight gradient,
-    // and run beside it.  SCS_TAIL_SIDE (tuning runs) restores the round-2 order: everything but the layer-1 launch on the side stream.
-    const bool tail_side = getenv("SCS_TAIL_SIDE") != nullptr;
+    // and run beside it.  option tail_side (tuning runs) restores the round-2 order: everything but the layer-1 launch on the side stream.
+    const bool tail_side = opt.tail_side != 0;
     const bool tail_on_main = !one_stream && !tail_side;
 
     w->prof = stage_ms != nullptr;
@@ -1023,16 +1058,15 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         pa.tr[1] = TrProblem{P + H.fc1W, kFC1, wT1, kTld, kFlat, kFC1};
         pa.atlas = atlas; pa.y = y; pa.index = index; pa.cat2 = w->cat2; pa.yb = w->yb; pa.n = n;
         pa.n_rows = index ? x0.n_samples : n;
-        pa.fc2W = P + H.fc2W; pa.w2p = w2p; pa.chain_counter = w->chain_counter;
+        pa.fc2W = P + H.fc2W; pa.w2p = w2p; pa.chain_counter = w->chain_counter; pa.loss_rows = w->loss_rows;
         pa.c5W = P + T0.convW[4]; pa.wc5 = wc5; pa.c5_tower_stride = kTowerFloats;
         pa.masks = masks_dev ? nullptr : w->masks; pa.mask_total = (size_t)n * kFlat * 5; pa.seed = dropout_seed;
         // ---- forward, training mode: the input moments ride in the same launch; up to kBn1FusedMaxBatch the workgroup that
         // completes a tower's moments also finalizes conv1's batch statistics there (beside the prep jobs: no launch of its own on
-        // the step's critical path); SCS_BN1_FUSED_MAX_BATCH overrides the bound (0: always a launch; tests run both forms)
+        // the step's critical path); option bn1_fused_max_batch overrides the bound (0: always a launch; tests run both forms)
         Bn1Args b1{P, T0.convW[0], T0.bn[0], kTowerFloats, w->mom, Ptr3{{w->w1p[0], w->w1p[1], w->w1p[2]}}, Ptr3{{w->l1p[0], w->l1p[1], w->l1p[2]}},
                    Ptr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, nullptr};
-        const char* b1_env = getenv("SCS_BN1_FUSED_MAX_BATCH");
-        const bool bn1_fused = n <= (b1_env ? std::min(atoi(b1_env), w->cap) : kBn1FusedMaxBatch);
+        const bool bn1_fused = n <= (opt.bn1_fused_max_batch >= 0 ? std::min(opt.bn1_fused_max_batch, w->cap) : kBn1FusedMaxBatch);
         if (bn1_fused) { b1.counter = w->fin_counter; b1.rec = w->fin_grp; }
         run(ST_PREP, st, [&] {
             hipLaunchKernelGGL(prep_moments_kernel, prep_moments_grid(units1), dim3(256), 0, st, pa, x0, w->mom_part, n,
@@ -1089,13 +1123,13 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     }
     // Small batches: the whole dense head - these three layers, the out layer with its loss, and the three data-gradient
     // layers below - is ONE launch of 9-workgroup clusters (dense_chain.h; same tiles, same sums, same bits); otherwise one
-    // launch per layer.  SCS_DENSE_CHAIN_MAX_BATCH overrides the bound (0: never; tests run both forms at one batch size);
+    // launch per layer.  option dense_chain_max_batch overrides the bound (0: never; tests run both forms at one batch size);
     // SCS_CHAIN_STAMPS prints the one-launch form's per-tile phase times to stderr (diagnostic, synchronises).
-    const char* chain_env = getenv("SCS_DENSE_CHAIN_MAX_BATCH");
-    const int chain_max = chain_env ? std::min(atoi(chain_env), kChainMaxBatch) : kChainDefaultMaxBatch;
+    const int chain_max = opt.dense_chain_max_batch >= 0 ? std::min(opt.dense_chain_max_batch, kChainMaxBatch) : kChainDefaultMaxBatch;
     DenseChainArgs ch{};
     for (int t = 0; t < kTowers; ++t) ch.d1[t] = g.p[t];
-    const bool chain = n <= chain_max && dense_chain_ok(n, g, kTowers);
+    // ... and only on a device whose dispatcher gives every XCD grid / 8 workgroups (probed once per handle: chain_placement_ok)
+    const bool chain = n <= chain_max && dense_chain_ok(n, g, kTowers) && h->chain_placement > 0;
     if (!chain) run(ST_D1, st, [&] { gemm_launch(g, kTowers, st); });
     g.K4 = kFC1; g.K = kFC1; g.N = kFC1;
     g.p[0] = GemmProblem{w->featd, kFlat, P + H.fc1W, kFC1, P + H.fc1b, w->R1, kFC1, mask2, kFC1, nullptr, 0, w->cat2, kFC1ld};
@@ -1175,6 +1209,10 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             wg.p[3 + t] = WgProblem{w->H5[t], kFlat, w->dfeat + t * kD1, kFlat, G + T.d1W, kD1, G + T.d1b, kFlat, kD1};
         }
         run(ST_WGDENSE, sd, [&] { dense_wgrad_launch(wg, kWgProblems, sd); });
+        // every gradient of FC1 / fc_2 / out (the contiguous tail of the arena) is final behind this launch, ~0.3 ms before the
+        // step ends: a data-parallel caller may start exchanging that bucket now (scs_wait_head_grads)
+        (void)hipEventRecord(w->ev_head, sd);
+        w->head_recorded = true;
     }
     bg.M = n; bg.K4 = kD1; bg.K = kD1; bg.N = kFlat;
     for (int t = 0; t < kTowers; ++t)         // through the dropout in front of d1 (mask5 of the tower) in the epilogue
@@ -1186,14 +1224,13 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // gradient of layer i+1, or computed directly for the 3x3 planes of conv5), then the data-gradient kernel of layer i
     // (d z_i while staging, stored for the weight gradient; epilogue: partial sums of layer i-1), then the weight gradient
     // of layer i on the side stream.
-    const WgSlices slices = wg_slices();
+    const WgSlices slices = wg_slices(opt);
     WgFinalArgs fa{};
     fa.grads = G; fa.tower_stride = kTowerFloats;
     constexpr int kDgBands[kConvs] = {0, DG2::NB, DG3::NB, DG4::NB, DG5::NB};
     // conv5 block: data gradient + weight gradient as one launch of two small GEMMs per workgroup (conv5_bwd.h) up to
-    // kC5MaxBatch; SCS_C5_FUSED_MAX_BATCH overrides the bound (0: the generic kernels; tests run both forms)
-    const char* c5_env = getenv("SCS_C5_FUSED_MAX_BATCH");
-    const bool c5_fused = n <= (c5_env ? std::min(atoi(c5_env), kC5MaxBatch) : kC5MaxBatch);
+    // kC5MaxBatch; option c5_fused_max_batch overrides the bound (0: the generic kernels; tests run both forms)
+    const bool c5_fused = n <= (opt.c5_fused_max_batch >= 0 ? std::min(opt.c5_fused_max_batch, kC5MaxBatch) : kC5MaxBatch);
     const int c5_units = conv5_backward_workgroups(n);
     const bool kDgFin[kConvs + 1] = {false, DG2::FIN != 0, DG3::FIN != 0 && fin_in_kernel, DG4::FIN != 0 && fin_in_kernel,
                                      c5_fused ? fin_in_kernel : (DG5::FIN != 0 && fin_in_kernel), false};
@@ -1446,6 +1483,17 @@ int scs_get_train_buffer(scs_handle h, int which, float* host_out, size_t count)
     SCS_HIP(hipSetDevice(h->device));
     SCS_HIP(hipDeviceSynchronize());
     SCS_HIP(hipMemcpy(host_out, src, count * sizeof(float), hipMemcpyDeviceToHost));
+    return SCS_OK;
+}
+
+int scs_wait_head_grads(scs_handle h, void* stream, size_t* first_float, size_t* n_floats) {
+    SCS_ARG(h != nullptr, "null handle");
+    if (!h->tws || !h->tws->head_recorded) { set_error("scs_wait_head_grads before scs_train_step"); return SCS_ERR_STATE; }
+    SCS_HIP(hipSetDevice(h->device));
+    SCS_HIP(hipStreamWaitEvent((hipStream_t)stream, h->tws->ev_head, 0));
+    constexpr HeadOff H = head_off();
+    if (first_float) *first_float = (size_t)H.fc1W;
+    if (n_floats) *n_floats = (size_t)(H.end - H.fc1W);
     return SCS_OK;
 }
 

@@ -58,6 +58,16 @@ def main():
     p1, g1 = run_steps(flat)
     assert all(np.array_equal(a, b) for a, b in zip(g0, g1)), 'gradient arena differs behind a one-rank RCCL all-reduce'
     assert np.array_equal(p0, p1), 'parameters differ: %g' % float(np.abs(p0 - p1).max())
+    # the two-bucket exchange (SCS_DP_BUCKETS=2): the dense head's bucket is all-reduced on a communication stream that waits
+    # for scs_wait_head_grads' event - issued right behind scs_train_step, while its kernels are still running - the towers'
+    # bucket behind the step; scs_adam_apply is ordered behind both.  Same bits.
+    os.environ['SCS_DP_BUCKETS'] = '2'
+    assert dist.dp_buckets() == 2
+    p2, g2 = run_steps(flat, steps=6)
+    del os.environ['SCS_DP_BUCKETS']
+    assert all(np.array_equal(a, b) for a, b in zip(g0, g2[:3])), 'gradient arena differs with the two-bucket exchange'
+    p3, g3 = run_steps(flat, steps=6)
+    assert all(np.array_equal(a, b) for a, b in zip(g3, g2)) and np.array_equal(p3, p2), 'two buckets: parameters differ after 6 steps'
     assert not np.array_equal(p0, flat)                                # the steps did move the parameters
     # a bare collective on a torch tensor, for the record of what the communicator does
     t = torch.arange(8, dtype=torch.float32, device='cuda:0')

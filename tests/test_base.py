@@ -181,11 +181,18 @@ def test_nifti_big_endian_and_scaled(tmp_path):
     assert np.array_equal(got, a.astype(np.float64) * 0.5 - 3.0)
 
 
-def make_subject(folder, shape=(40, 40, 40), seed=0, with_labels=False):
+def make_subject(folder, shape=(40, 40, 40), seed=0, with_labels=False, steered=False):
+    """steered: the prior file holds synth.steered_atlas (every class wins somewhere at volume level) instead of the
+    probability-like toy prior (classes 0 and 2 only); returns (T1, prior as written, mask as written)."""
     os.makedirs(os.path.join(folder, 'tmp'), exist_ok=True)
     vol = synth.smooth_volume(shape, sigma=3.0, seed=seed, as_int=True)
-    atlas = synth.toy_atlas(shape, seed=seed + 1)
-    mask = (atlas[..., :13].sum(-1) > 0).astype(np.float32)
+    if steered:
+        assert not with_labels
+        atlas, smap = synth.steered_atlas(shape, seed=seed + 1)
+        mask = (smap > 0).astype(np.float32)
+    else:
+        atlas = synth.toy_atlas(shape, seed=seed + 1)
+        mask = (atlas[..., :13].sum(-1) > 0).astype(np.float32)
     nifti.save(vol, os.path.join(folder, 'T1.nii.gz'))
     nifti.save(atlas, os.path.join(folder, 'tmp', 'MNI_sub_probabilities.nii.gz'))
     nifti.save(mask, os.path.join(folder, 'tmp', 'MNI_subcortical_mask.nii.gz'))

@@ -53,8 +53,14 @@ def _worker(rank, world, port, q):
     loss, grads, _, _ = O.train_forward_backward(weights, ax[sl], co[sl], sa[sl], at[sl], y[sl], {k: v[sl] for k, v in masks.items()})
     flat = torch.from_numpy(np.concatenate([np.asarray(g, np.float64).ravel() for n, _ in P.LAYER_SPEC for g in grads[n]]))
     local = flat.clone()
+    two = local.clone()
     scale = dist.allreduce_flat(flat, n_active=2)
     out['avg'] = (flat * scale).numpy()
+    # the two-bucket exchange (dense head's tail of the arena first, then the towers): the same sums element for element
+    assert dist.allreduce_flat(two, n_active=2, first=P.head_first_float()) == scale
+    out['two_buckets_equal'] = bool(torch.equal(two, flat))
+    out['head_first'] = P.head_first_float()
+    out['min'] = dist.min_scalar(float(r + 1))
     out['local'] = local.numpy()
     out['mean_loss'] = dist.mean_scalar(loss, 1)
     out['loss'] = loss
@@ -85,6 +91,7 @@ def test_two_rank_gloo_data_parallel_plumbing():
     assert np.array_equal(a['avg'], b['avg'])                                    # replicas see identical gradients
     assert np.allclose(a['avg'], 0.5 * (a['local'] + b['local']), rtol=0, atol=1e-15)
     assert abs(a['mean_loss'] - 0.5 * (a['loss'] + b['loss'])) < 1e-12 and a['max'] == 2.0
+    assert a['two_buckets_equal'] and b['two_buckets_equal'] and a['head_first'] == 436320 and (a['min'], b['min']) == (1.0, 1.0)
 
 
 def test_single_process_degrades_to_noops():

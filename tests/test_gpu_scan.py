@@ -25,9 +25,14 @@ def options(folder, **kw):
 
 
 def test_test_scan_matches_the_cpu_procedure(tmp_path, weights):
+    """36^3 subject whose prior is synth.steered_atlas: all 15 classes appear at volume level, so the label scatter, the per-class
+    Dice and post_process_segmentation (base.py:425-431, 460-480) run with 14 live structures, not the 2 classes smooth volumes
+    with probability-like priors give."""
     from scipy import ndimage
+    from cnn_cort import synth
     folder = str(tmp_path / 'test')
-    vol, atlas, mask = make_subject(os.path.join(folder, 'subj1'), shape=(36, 36, 36), seed=11)
+    vol, atlas, mask = make_subject(os.path.join(folder, 'subj1'), shape=(36, 36, 36), seed=11, steered=True)
+    smap = synth.steered_atlas((36, 36, 36), seed=12)[1]
     opts = options(folder)
     net = build_model(os.path.join(PKG, 'nets'), opts)           # loads nets/miccai2012_v1/miccai2012_v1.{f32,json}
     t1s, names = base.load_test_names(opts)
@@ -42,13 +47,21 @@ def test_test_scan_matches_the_cpu_procedure(tmp_path, weights):
     opts2 = options(folder, post_process='False', out_probabilities='False')
     base.test_scan(net, t1s[0], opts2)
     rawseg = nifti.load(os.path.join(sub, 'out_subcortical_rawseg.nii.gz')).get_data()
+    live = np.unique(rawseg)
+    assert len(live) >= 13, 'classes at volume level: %s' % live
 
     # the reference's procedure on the CPU (literal load_patch_batch -> oracle), on a fixed subset of the ROI
-    # voxels (the float64 oracle needs ~5 ms per patch; the ROI has tens of thousands)
+    # voxels (the float64 oracle needs ~5 ms per patch; the ROI has tens of thousands): up to 70 voxels of every structure
+    # blob and 700 drawn from the whole ROI
     roi = ndimage.binary_dilation(mask, iterations=10)
     centers_all = R.get_mask_voxels(roi)
     assert (rawseg[~roi] == 0).all() and (prob[~roi] == 0).all()            # nothing written outside the ROI
-    pick = np.random.RandomState(0).choice(len(centers_all), 1500, replace=False)
+    rng = np.random.RandomState(0)
+    where = np.array([smap[c] for c in centers_all])
+    pick = set(rng.choice(len(centers_all), 700, replace=False).tolist())
+    for k in range(1, 15):
+        idx = np.flatnonzero(where == k)
+        pick.update(rng.choice(idx, min(70, len(idx)), replace=False).tolist())
     centers = [centers_all[i] for i in sorted(pick)]
     vn = R.zscore_inference(vol)
     views = [np.stack([np.array(R.get_patches(vn, centers, (32, 32), mode=m)).astype(np.float32)], axis=1)
@@ -59,13 +72,41 @@ def test_test_scan_matches_the_cpu_procedure(tmp_path, weights):
     clear = (srt[:, -1] - srt[:, -2]) > 1e-5
     assert np.abs(prob[x, y, z, :] - p).max() < 1e-4
     assert np.array_equal(rawseg[x, y, z][clear], p.argmax(1)[clear])
-    # per-class Dice between the GPU labels and the CPU oracle labels on those voxels: exactly 1
+    # per-class Dice between the GPU labels and the CPU oracle labels on those voxels: exactly 1, over >= 12 classes
+    seen = 0
     for c in range(15):
         a, b = rawseg[x, y, z][clear] == c, p.argmax(1)[clear] == c
         if a.sum() + b.sum():
+            seen += 1
             assert 2.0 * (a & b).sum() / (a.sum() + b.sum()) == 1.0
-    # post-processing of the GPU labels equals the literal restatement (quirk included)
+    assert seen >= 12, 'only %d classes among the compared voxels' % seen
+    # post-processing of the GPU labels equals the literal restatement (quirk included), with most structures live
     assert np.array_equal(seg, R.post_process_segmentation(rawseg, mask.astype(bool)))
+
+
+def test_cohort_on_a_cold_net_with_many_reader_threads(tmp_path):
+    """test_cohort's reader threads call net.normalize_volume / net.roi_centers, each of which needs the libscs handle: on a Net
+    that has never been used (build_model + load_params_from, then straight into test_cohort) several threads reach the lazy
+    handle creation at once.  It is created once, under a lock, with the parameters set - the files equal those of test_scan
+    on a warm net."""
+    import gzip
+    a, b = str(tmp_path / 'a'), str(tmp_path / 'b')
+    for i in range(6):
+        make_subject(os.path.join(a, 's%d' % i), shape=(30, 28, 26), seed=60 + i, steered=True)
+        make_subject(os.path.join(b, 's%d' % i), shape=(30, 28, 26), seed=60 + i, steered=True)
+    opts = options(a, test_batch_size=100000)
+    warm = build_model(os.path.join(PKG, 'nets'), opts)
+    for i in range(6):
+        base.test_scan(warm, os.path.join(a, 's%d' % i, 'T1.nii.gz'), opts)
+    cold = build_model(os.path.join(PKG, 'nets'), options(b, test_batch_size=100000))
+    assert cold._handle is None
+    res = base.test_cohort(cold, [os.path.join(b, 's%d' % i, 'T1.nii.gz') for i in range(6)], options(b, test_batch_size=100000),
+                           shard=False, readers=6, writers=2)
+    assert len(res) == 6
+    for i in range(6):
+        for f in ('out_subcortical_prob.nii.gz', 'out_subcortical_seg_prec.nii.gz'):
+            with gzip.open(os.path.join(a, 's%d' % i, f)) as fa, gzip.open(os.path.join(b, 's%d' % i, f)) as fb:
+                assert fa.read() == fb.read(), (i, f)
 
 
 def test_predict_api_accepts_numpy_and_device_tensors(weights):
@@ -197,6 +238,27 @@ def test_device_zscore_equals_the_numpy_normalisation(dtype, order):
     g = got.cpu().numpy()
     assert np.abs(g - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
     assert np.mean(g != want) < 1e-3                                   # all but a few roundings identical
+    if dtype == np.float32:
+        # A float32 T1 goes through the reference's formula ENTIRELY in float32 (NumPy's pairwise float32 mean / std, float32
+        # subtraction and division: base.py:358 with a float32 image).  The device computes mean / std in double (two passes)
+        # and rounds once: a stated deviation, bounded here against the unmodified formula -
+        # a few float32 ulps of the largest value.
+        nz = vol[np.nonzero(vol)]
+        ref32 = (vol - nz.mean()) / nz.std()
+        assert ref32.dtype == np.float32
+        assert np.abs(g - ref32).max() <= 4e-6 * max(1.0, np.abs(ref32).max())
+
+
+def test_device_zscore_keeps_its_digits_when_the_mean_dwarfs_the_spread():
+    """mean 30000, spread 3 (a float32 volume whose E[x^2] - mean^2 has no digits left in float64 either way worth trusting at
+    float32 output precision only if formed carefully): the two-pass variance agrees with NumPy's."""
+    from cnn_cort.nets import Net
+    rng = np.random.RandomState(2)
+    vol = (30000.0 + 3.0 * rng.standard_normal((33, 31, 29))).astype(np.float32)
+    vol[:4] = 0
+    got = Net(device=0).normalize_volume(vol).cpu().numpy()
+    want = R.zscore_inference(vol.astype(np.float64)).astype(np.float32)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
 
 
 @pytest.mark.parametrize('shape,iters,order', [((23, 17, 31), 10, 'F'), ((40, 44, 36), 10, 'C'), ((9, 64, 5), 3, 'F'), ((33, 20, 18), 0, 'F')])
@@ -232,7 +294,7 @@ def test_full_size_subject_of_baseline_config_4(tmp_path, weights):
     from conftest import ROOT
     sys.path.insert(0, ROOT)
     import bench
-    scan = bench.make_cohort(str(tmp_path), 1, seed=3)[0]
+    scan = bench.make_cohort(str(tmp_path), 1, seed=3, steered=True)[0]
     sub = os.path.dirname(scan)
     opts = options(str(tmp_path), test_batch_size=100000)
     net = build_model(os.path.join(PKG, 'nets'), opts)
@@ -280,4 +342,16 @@ def test_full_size_subject_of_baseline_config_4(tmp_path, weights):
     base.test_scan(net, scan, options(str(tmp_path), test_batch_size=100000, post_process='False', out_probabilities='False'))
     rawseg = nifti.load(os.path.join(sub, 'out_subcortical_rawseg.nii.gz')).get_data()
     assert np.array_equal(rawseg[c[:, 0], c[:, 1], c[:, 2]], got.argmax(1)) and (rawseg[~roi] == 0).all()
-    assert np.array_equal(seg, R.post_process_segmentation(rawseg, mask.astype(bool)) if False else base.post_process_mask(rawseg, mask))
+    live = np.unique(rawseg)
+    assert len(live) >= 13, 'classes at volume level: %s' % live           # the steered prior: (nearly) every structure is present
+    # post-processing against the LITERAL procedure (base.py:460-480 restated in oracle/patches_ref.py) on the ROI's bounding
+    # box: every labelled voxel lies inside the box, component numbering follows the raster order of first voxels (which a crop
+    # preserves), so the literal result on the crop is the full result restricted to it; outside the box every voxel is
+    # background of every class and takes the value a background voxel of the box takes
+    box = tuple(slice(int(lo), int(hi) + 1) for lo, hi in zip(centers.min(0), centers.max(0)))
+    lit = R.post_process_segmentation(rawseg[box], mask[box].astype(bool))
+    assert np.array_equal(seg[box], lit)
+    bg_in_box = lit[(rawseg[box] == 0)]
+    outside = np.ones(raw.shape, bool)
+    outside[box] = False
+    assert bg_in_box.size and (bg_in_box == bg_in_box.flat[0]).all() and (seg[outside] == bg_in_box.flat[0]).all()

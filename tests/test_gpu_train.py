@@ -148,17 +148,19 @@ def test_fit_with_the_opt_in_augmentation(tmp_path):
     assert hist[True] != hist[False]
 
 
-def test_two_rank_gradient_exchange(tmp_path):
+@pytest.mark.parametrize('buckets', ['1', '2'])
+def test_two_rank_gradient_exchange(tmp_path, buckets):
     """Two ranks (gloo rehearsal, both on cuda:0): each back-propagates its half of the g5 batch, the gradient arenas
     are summed through cnn_cort.dist and Adam applies the 1/world scale: replicas end identical and the exchanged
-    gradient equals the sum of the two local ones."""
+    gradient equals the sum of the two local ones - as one all-reduce of the arena and as the two-bucket exchange
+    (SCS_DP_BUCKETS=2: dense head first, on a communication stream behind scs_wait_head_grads; towers behind the step)."""
     import os
     import socket
     import subprocess
     import sys
     from conftest import ROOT
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, SCS_DIST_BACKEND='gloo')
+    env = dict(os.environ, SCS_DIST_BACKEND='gloo', SCS_DP_BUCKETS=buckets)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'tests', 'dp_worker.py'), str(tmp_path)]
     subprocess.run(cmd, check=True, env=env, timeout=300, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -401,7 +403,7 @@ def test_training_step_on_random_draws(fresh, weights, n):
 def test_training_step_with_the_finalize_as_its_own_launch(fresh, weights, monkeypatch):
     """Beyond kFinMaxBatch (train_cfg.h) the batch-norm finalize steps are launches of their own instead of the last workgroup
     of the conv kernels: the same step through that form (forced at a small batch) against the oracle."""
-    monkeypatch.setenv('SCS_FIN_MAX_BATCH', '0')
+    fresh.set_option('fin_max_batch', 0)                          # per handle (scs_set_option); no environment switch per step
     worst, forced = _step_against_gate_aware_oracle(fresh, weights, 37, 0)
     print('finalize launches: worst relative gradient error %.3g; %r' % (worst, forced))
 
@@ -416,8 +418,8 @@ def test_dense_head_as_one_launch_gives_the_bits_of_the_layer_launches(weights, 
     from cnn_cort import synth, _hip
     out = {}
     for form, bound in (('layers', '0'), ('chain', '384')):
-        monkeypatch.setenv('SCS_DENSE_CHAIN_MAX_BATCH', bound)
         h = _hip.Handle(0)
+        h.set_option('dense_chain_max_batch', int(bound))
         h.set_params(P.params_to_flat(weights))
         st = torch.cuda.current_stream().cuda_stream
         losses = []
@@ -444,8 +446,8 @@ def test_conv1_statistics_finalized_in_the_moments_launch_give_the_bits_of_the_f
     from cnn_cort import synth, _hip
     out = {}
     for form, bound in (('launch', '0'), ('in the moments launch', '512')):
-        monkeypatch.setenv('SCS_BN1_FUSED_MAX_BATCH', bound)
         h = _hip.Handle(0)
+        h.set_option('bn1_fused_max_batch', int(bound))
         h.set_params(P.params_to_flat(weights))
         st = torch.cuda.current_stream().cuda_stream
         losses = []
@@ -466,19 +468,18 @@ def test_conv1_statistics_finalized_in_the_moments_launch_give_the_bits_of_the_f
 def test_stream_order_of_the_last_launches_does_not_change_the_bits(weights, monkeypatch, n):
     """The step's weight-gradient launches run beside the data gradients on a side stream, in two arrangements of the last ones -
     conv2's weight gradient and its reduction on the caller's stream with the layer-1 launch and the conv3..5 reduction beside
-    them (default), or everything but the layer-1 launch on the side stream (SCS_TAIL_SIDE) - or, as the reference, with every
-    launch in order on ONE stream (SCS_TRAIN_ONE_STREAM).  Same kernels, same arithmetic: six steps through each (Adam applied)
+    them (default), or everything but the layer-1 launch on the side stream (option tail_side) - or, as the reference, with every
+    launch in order on ONE stream (option train_one_stream).  Same kernels, same arithmetic: six steps through each (Adam applied)
     must leave the same arenas bit for bit - a missing dependency between the streams would show here."""
     from cnn_cort import synth, _hip
     out = {}
     for form in ('default', 'side', 'one stream'):
-        monkeypatch.delenv('SCS_TAIL_SIDE', raising=False)
-        monkeypatch.delenv('SCS_TRAIN_ONE_STREAM', raising=False)
-        if form == 'side':
-            monkeypatch.setenv('SCS_TAIL_SIDE', '1')
-        elif form == 'one stream':
-            monkeypatch.setenv('SCS_TRAIN_ONE_STREAM', '1')          # every launch in order on the caller's stream: the reference
         h = _hip.Handle(0)
+        assert h.get_option('tail_side') == 0 and h.get_option('train_one_stream') == 0
+        if form == 'side':
+            h.set_option('tail_side', 1)
+        elif form == 'one stream':
+            h.set_option('train_one_stream', 1)                      # every launch in order on the caller's stream: the reference
         h.set_params(P.params_to_flat(weights))
         st = torch.cuda.current_stream().cuda_stream
         losses = []
@@ -505,8 +506,8 @@ def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monke
     from cnn_cort import synth, _hip
     out = {}
     for form, bound in (("generic", "0"), ("fused", "1024"), ("fused again", "1024")):
-        monkeypatch.setenv('SCS_C5_FUSED_MAX_BATCH', bound)
         h = _hip.Handle(0)
+        h.set_option('c5_fused_max_batch', int(bound))
         h.set_params(P.params_to_flat(weights))
         st = torch.cuda.current_stream().cuda_stream
         ax, co, sa, at = synth.patch_batch(n, seed=900 + n)

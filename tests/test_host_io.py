@@ -81,10 +81,42 @@ def test_gather_refuses_bad_input(tmp_path):
         _hip.gz_gather(path, np.array([len(data)], np.int64), 4)          # beyond the end
     with pytest.raises(IOError):
         _hip.gz_gather(path, np.array([8, 4], np.int64), 4)               # not ascending
-    try:                                                                  # a flipped bit is either detected or changes the bytes -
-        got, total = _hip.gz_gather(str(tmp_path / 'flip.gz'), last, 4, total=True)      # the CRC is deliberately not checked
-    except IOError:
-        pass
+    with pytest.raises(IOError):                                          # whole-stream gather: the member's CRC-32 is verified
+        _hip.gz_gather(str(tmp_path / 'flip.gz'), last, 4, total=True)
+
+
+def test_crc32_of_every_member_is_verified_on_whole_reads(tmp_path, monkeypatch):
+    """A payload byte changed in a way that keeps the deflate stream decodable and its length right (a stored block: the bytes
+    are the data) is caught by the CRC-32 of the member - in scs_gz_read (what nifti.load uses for T1 / mask volumes) and in a
+    gather over the whole stream; SCS_GZ_NOCRC=1 skips the check; a gather that stops before the end of the stream cannot see
+    the trailer and returns the (here: untouched) leading bytes."""
+    import zlib
+    rng = np.random.RandomState(5)
+    data = (rng.rand(70000) < 0.02).astype(np.uint8).tobytes() + rng.bytes(3000) + bytes(200000)      # zero runs + noise + a long run
+    for level in (0, 6):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31)
+        blob = bytearray(co.compress(data) + co.flush())
+        good = str(tmp_path / ('ok%d.gz' % level))
+        open(good, 'wb').write(bytes(blob))
+        out = np.empty(len(data), np.uint8)
+        _hip.gz_read(good, 0, out)
+        assert out.tobytes() == data
+        if level == 0:
+            # stored blocks: byte 10 + 5 + k of the file is byte k of the data
+            blob[10 + 5 + 71000] ^= 0x01
+        else:
+            blob[-8] ^= 0x01                                            # the trailer's CRC itself
+        bad = str(tmp_path / ('bad%d.gz' % level))
+        open(bad, 'wb').write(bytes(blob))
+        with pytest.raises(IOError, match='CRC'):
+            _hip.gz_read(bad, 0, np.empty(len(data), np.uint8))
+        with pytest.raises(IOError, match='CRC'):
+            _hip.gz_gather(bad, np.array([0], np.int64), 1, total=True)
+        head = _hip.gz_gather(bad, np.array([0, 100], np.int64), 4)      # stops after offset 104: no trailer, no check
+        assert head.tobytes() == data[0:4] + data[100:104]
+        monkeypatch.setenv('SCS_GZ_NOCRC', '1')
+        _hip.gz_read(bad, 0, out)                                       # unchecked: the (possibly wrong) bytes come back
+        monkeypatch.delenv('SCS_GZ_NOCRC')
 
 
 def test_load_rows_native_and_python_paths_agree(tmp_path, monkeypatch):

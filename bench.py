@@ -231,11 +231,17 @@ def measure_train(torch, dist, h, B, steps, warmup, rank, world, dev, st, profil
     ax, co, sa, at, y = inputs
     ctr = [0]
 
+    # one rank: the step applies the Adam update itself (scs_set_fused_adam - what Net.fit does without a process group: nothing
+    # sits between the gradients and the update); N > 1: scs_train_step, the RCCL all-reduce, scs_adam_apply
+    fused = not dist.is_dist()
+    h.set_fused_adam(fused)
+
     def step():
         ctr[0] += 1
         h.train_step(ax, co, sa, at, y, B, seed=5 + ctr[0], want_loss=False, stream=st)
-        scale = dist.allreduce_grads(h, True, st, n_active=world)
-        h.adam_apply(grad_scale=scale, stream=st)
+        if not fused:
+            scale = dist.allreduce_grads(h, True, st, n_active=world)
+            h.adam_apply(grad_scale=scale, stream=st)
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -256,6 +262,7 @@ def measure_train(torch, dist, h, B, steps, warmup, rank, world, dev, st, profil
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     acc = [0.0, 0.0, 0.0]
     reps = 40
+    h.set_fused_adam(False)                                            # the three parts as separate calls, whatever the timed form was
     for _ in range(reps):
         ctr[0] += 1
         ev[0].record()
@@ -271,6 +278,8 @@ def measure_train(torch, dist, h, B, steps, warmup, rank, world, dev, st, profil
     out['train_step_ms'] = dist.max_scalar(acc[0] / reps)
     out['allreduce_ms'] = dist.max_scalar(acc[1] / reps)
     out['adam_ms'] = dist.max_scalar(acc[2] / reps)
+    h.set_fused_adam(fused)
+    out['update'] = 'fused into the step (one rank: scs_set_fused_adam)' if fused else 'scs_adam_apply behind the all-reduce'
     out['decomposition_note'] = ('%d extra steps with a synchronize after each (event pairs around scs_train_step / dist.allreduce_grads / '
                                  'scs_adam_apply, max over ranks): isolated steps, so train_step_ms exceeds the pipelined ms_per_step' % reps)
     if profile and rank == 0:
@@ -658,7 +667,7 @@ def main():
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
     if args.mode == 'train' and rank == 0:
         for k in ('roofline', 'stages', 'launches_per_step', 'sum_of_launch_ms', 'train_step_ms', 'allreduce_ms', 'adam_ms',
-                  'decomposition_note', 'per_rank_ms_per_step'):
+                  'decomposition_note', 'per_rank_ms_per_step', 'update'):
             out[k] = train_out[k]
     if args.mode == 'forward':
         # the other half of BASELINE.json's metric, in the same driver-run line: the training step at batch 256 (configs[2])

@@ -274,6 +274,14 @@ int scs_train_loss(scs_handle h, float** dev_ptr);
  * sum all-reduce).  Then refreshes the inference operands. */
 int scs_adam_apply(scs_handle h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* Single-rank training: apply that update INSIDE every following scs_train_step* call (enable = 1), layer group by layer group
+ * as the step finishes their gradients - the dense layers' 84 % of the arena beside the conv backward pass, the conv blocks
+ * beside the last weight-gradient kernel, conv2.W inside its reduction - instead of as a launch of its own behind the step.
+ * Same arithmetic per element as scs_adam_apply with grad_scale 1 (bit-identical parameters).  While enabled scs_adam_apply
+ * returns SCS_ERR_STATE (the update must not run twice); a data-parallel caller, whose all-reduce sits between gradients and
+ * update, leaves this off. */
+int scs_set_fused_adam(scs_handle h, int enable, float lr, float beta1, float beta2, float eps);
+
 /* Deterministic forward + summed cross-entropy + number of correct argmax predictions on n labelled
  * samples (nolearn eval_iter_).  Synchronises.  The sums are formed in a fixed order (bit-reproducible). */
 int scs_eval_batch(scs_handle h, const float* ax_dev, const float* co_dev, const float* sa_dev,

@@ -56,6 +56,7 @@ SIGNATURES = {
     'scs_grad_arena': (_c.c_int, [_vp, _c.POINTER(_vp), _c.POINTER(_c.c_size_t)]),
     'scs_wait_head_grads': (_c.c_int, [_vp, _vp, _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
     'scs_adam_apply': (_c.c_int, [_vp, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _vp]),
+    'scs_set_fused_adam': (_c.c_int, [_vp, _c.c_int, _c.c_float, _c.c_float, _c.c_float, _c.c_float]),
     'scs_eval_batch': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c.c_int64, _c.POINTER(_c.c_double),
                                   _c.POINTER(_c.c_int64), _vp]),
 }
@@ -479,6 +480,12 @@ class Handle:
         p = ctypes.c_void_p()
         _check(self.lib.scs_train_loss(self.h, ctypes.byref(p)), 'scs_train_loss')
         return p.value
+
+    def set_fused_adam(self, enable, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+        """Single-rank training: every following train_step applies the Adam update itself (scs_set_fused_adam); adam_apply must
+        not be called while this is on."""
+        _check(self.lib.scs_set_fused_adam(self.h, 1 if enable else 0, lr, b1, b2, eps), 'scs_set_fused_adam')
+        self.fused_adam = bool(enable)
 
     def adam_apply(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0, stream=0):
         _check(self.lib.scs_adam_apply(self.h, lr, b1, b2, eps, grad_scale, stream or None), 'scs_adam_apply')

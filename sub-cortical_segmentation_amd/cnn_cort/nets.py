@@ -742,6 +742,10 @@ class Net:
         if self.verbose:
             print('  epoch    trn loss    val loss    trn/val    valid acc  dur')
             print('-------  ----------  ----------  ---------  -----------  -----')
+        # one rank: nothing sits between a step's gradients and their update, so the step applies lasagne.updates.adam itself,
+        # group by group as the gradients become final (scs_set_fused_adam: same arithmetic, no launch behind the step)
+        fused = not dist.is_dist()
+        h.set_fused_adam(fused, lr=self.update_learning_rate)
         try:
             for ep in range(epochs or self.max_epochs):
                 t0 = time.time()
@@ -760,8 +764,9 @@ class Net:
                             loss_view = dist.wrap_device_floats(h.train_loss_ptr(), 1, self._dev())
                         loss_buf[len(sizes):len(sizes) + 1].copy_(loss_view, non_blocking=True)
                         sizes.append(nb)
-                    scale = dist.allreduce_grads(h, active, stream, n_active=dist.active_ranks(len(starts), step, world))
-                    h.adam_apply(lr=self.update_learning_rate, grad_scale=scale, stream=stream)
+                    if not fused:
+                        scale = dist.allreduce_grads(h, active, stream, n_active=dist.active_ranks(len(starts), step, world))
+                        h.adam_apply(lr=self.update_learning_rate, grad_scale=scale, stream=stream)
                 losses = loss_buf[:len(sizes)].cpu().numpy().astype(np.float64)
                 self._dev_newer = True
                 dist.sync_params(h)            # reconcile per-rank BN running statistics (no-op on one GPU)
@@ -789,6 +794,7 @@ class Net:
         except StopIteration:
             pass
         finally:
+            h.set_fused_adam(False)            # the handle goes back to the two-call form (scs_train_step, scs_adam_apply)
             if not compact:
                 pool.shutdown(wait=False)
         return self

@@ -31,6 +31,10 @@ struct scs_ctx {
     float* adam_m = nullptr;
     float* adam_v = nullptr;
     long adam_t = 0;
+    // scs_set_fused_adam: the update is applied INSIDE every training step (single-rank training: nothing sits between the
+    // gradients and the update), layer group by layer group as the gradients become final
+    bool fused_adam = false;
+    float fa_lr = 1e-3f, fa_b1 = 0.9f, fa_b2 = 0.999f, fa_eps = 1e-8f;
 
     // packed inference operands
     float* packed = nullptr;

@@ -40,7 +40,7 @@ namespace scs {
 // profiling stages of scs_train_step_profiled (one per launch)
 enum Stage { ST_PREP, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
              ST_FC2, ST_HEAD, ST_DCAT, ST_DFEAT, ST_DH5, ST_BN5B, ST_DG5, ST_FINB4, ST_DG4, ST_FINB3, ST_DG3, ST_FINB2, ST_DG2,
-             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_CHAIN, ST_C5B, ST_COUNT };
+             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_CHAIN, ST_C5B, ST_ADAM1, ST_ADAM2, ST_ADAM3, ST_COUNT };
 static const char* const kStageNames[ST_COUNT] = {
     "prep (weight packs, dropout masks, atlas columns) + input moments", "bn1 finalize", "conv1+conv2 fwd", "bn2 finalize",
     "conv3 fwd", "bn3 finalize", "conv4 fwd", "bn4 finalize", "conv5 fwd", "bn5 + dropout", "d1 x3 fwd", "FC1 fwd", "fc_2 fwd",
@@ -48,7 +48,7 @@ static const char* const kStageNames[ST_COUNT] = {
     "bn3 bwd finalize", "conv3 dgrad", "bn2 bwd finalize", "conv2 dgrad + layer-1 sums", "layer-1 gradients", "dense wgrad (grouped)",
     "conv5 wgrad", "conv4 wgrad", "conv3 wgrad", "conv2 wgrad", "conv3..5 wgrad reduce", "conv2 wgrad reduce",
     "dense head, one launch (d1 x3, FC1, fc_2, out + softmax + CE, fc_2 / FC1 / d1 dgrad)",
-    "conv5 backward, one launch (dgrad + wgrad + bn4 bwd sums)"};
+    "conv5 backward, one launch (dgrad + wgrad + bn4 bwd sums)", "adam (dense layers, fused)", "adam (bn2..5 scale / shift, fused)", "adam (conv2..5 weights, fused)"};
 
 }  // namespace scs
 
@@ -332,6 +332,20 @@ __device__ __forceinline__ void prep_body(const PrepArgs& a, int job, int bx) {
 struct Ptr3 { float* p[kTowers]; };
 struct CPtr3 { const float* p[kTowers]; };
 template <class T> __device__ __forceinline__ T sel3(const T (&a)[kTowers], int t) { return t == 0 ? a[0] : (t == 1 ? a[1] : a[2]); }
+
+// lasagne.updates.adam on ONE element, for the kernels that apply the update to the gradients they have just written (the fused
+// form of the step, scs_set_fused_adam): adam_kernel's arithmetic with grad_scale 1
+struct AdamCoef { float a_t, b1, b2, eps; };
+struct AdamFuse { float* p; float* m; float* v; AdamCoef k; };       // p == null: not fused
+// (explicitly rounded operations: every kernel that applies the update - adam_kernel, adam_seg_kernel, the fused reductions -
+// gives the same bits whatever the compiler would contract around the inlined text)
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float gr, const AdamCoef& k) {
+    const float mn = __fmaf_rn(k.b1, m, __fmul_rn(1.f - k.b1, gr));
+    const float vn = __fmaf_rn(k.b2, v, __fmul_rn(__fmul_rn(1.f - k.b2, gr), gr));
+    m = mn; v = vn;
+    p = __fsub_rn(p, __fdiv_rn(__fmul_rn(k.a_t, mn), __fadd_rn(__fsqrt_rn(vn), k.eps)));
+}
+__device__ __forceinline__ void adam_elem(const AdamFuse& a, int at, float g) { adam_update(a.p[at], a.m[at], a.v[at], g, a.k); }
 
 __device__ __forceinline__ double block_sum(double v, double* s_red) {
 #pragma unroll
@@ -702,7 +716,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
 //   d wf[k] = sc (A[c][k] - mb S[k] - mg inv (sum_k' wf[k'] R[k'][k] - mean S[k])),   mb = d beta/M, mg = d gamma/M,
 // and d W = d wf flipped back to Lasagne's true-convolution layout.  One workgroup per (channel, tower).
 __global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, int units, int n, const double* __restrict__ mom, CPtr3 l1p,
-                                                      CPtr3 l1m, float* grads, int w_off0, int bn_off0, int tower_stride) {
+                                                      CPtr3 l1m, float* grads, int w_off0, int bn_off0, int tower_stride, AdamFuse af) {
     __shared__ double s_w[4][10];
     __shared__ double s_A[10];
     const int c = blockIdx.x, t = blockIdx.y;
@@ -749,13 +763,17 @@ __global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__
     const double dg = inv * (wa - mean * db);
     float* gb = grads + bn_off0 + t * tower_stride;
     gb[c] = (float)db; gb[20 + c] = (float)dg;
+    if (af.p) { adam_elem(af, bn_off0 + t * tower_stride + c, (float)db); adam_elem(af, bn_off0 + t * tower_stride + 20 + c, (float)dg); }
     const double mb = db / M, mg = dg / M;
     float* gw = grads + w_off0 + t * tower_stride + c * 9;
     for (int k = 0; k < 9; ++k) {
         double wr = 0;
         for (int k2 = 0; k2 < 9; ++k2) wr += (double)l1[k2] * R[k2 * 10 + k];
         const double xs = inv * (wr - mean * R[k * 10 + 9]);
-        gw[(2 - k / 3) * 3 + (2 - k % 3)] = (float)(sc * (s_A[k] - mb * R[k * 10 + 9] - mg * xs));
+        const float gv = (float)(sc * (s_A[k] - mb * R[k * 10 + 9] - mg * xs));
+        const int kk = (2 - k / 3) * 3 + (2 - k % 3);
+        gw[kk] = gv;
+        if (af.p) adam_elem(af, w_off0 + t * tower_stride + c * 9 + kk, gv);
     }
 }
 
@@ -889,7 +907,8 @@ __global__ __launch_bounds__(256) void head_train_kernel(const float* __restrict
 // sum of the partial weight gradients of ALL conv layers in a fixed order (deterministic): blockIdx.z = layer, 64 elements x
 // 4 groups of partials per block, 8 independent loads in flight per thread
 struct WgFinalJob { const float* part; int nsplit, cin, cout, w_off0; };
-struct WgFinalArgs { WgFinalJob j[4]; float* grads; int tower_stride; int z0; };      // blockIdx.z + z0 selects the job
+struct WgFinalArgs { WgFinalJob j[4]; float* grads; int tower_stride; int z0;          // blockIdx.z + z0 selects the job
+                     AdamFuse af; };                                                   // af.p set: the update of the element, fused
 __global__ __launch_bounds__(256) void wgrad_final_kernel(WgFinalArgs a) {
     __shared__ float s_red[4][64];
     WgFinalJob J = a.j[0];
@@ -918,7 +937,9 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(WgFinalArgs a) {
     if (grp == 0 && e < tot) {
         v = (s_red[0][ex] + s_red[1][ex]) + (s_red[2][ex] + s_red[3][ex]);
         const int o = e % J.cout, j = e / J.cout, c = j / 9, k = j - c * 9;    // partials are [c*9 + tap][o]
-        a.grads[J.w_off0 + t * a.tower_stride + (o * J.cin + c) * 9 + (2 - k / 3) * 3 + (2 - k % 3)] = v;   // flip back to Lasagne's W
+        const int at = J.w_off0 + t * a.tower_stride + (o * J.cin + c) * 9 + (2 - k / 3) * 3 + (2 - k % 3);   // flip back to Lasagne's W
+        a.grads[at] = v;
+        if (a.af.p) adam_elem(a.af, at, v);
     }
 }
 
@@ -934,12 +955,25 @@ static WgSlices wg_slices(const scs_options& o) {
 // lasagne.updates.adam over the arena
 __global__ void adam_kernel(float* p, float* g, float* m, float* v, int n, float a_t, float b1, float b2, float eps, float gscale) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const float gr = g[e] * gscale;
-        const float mn = b1 * m[e] + (1.f - b1) * gr;
-        const float vn = b2 * v[e] + (1.f - b2) * gr * gr;
-        m[e] = mn; v[e] = vn;
-        p[e] -= a_t * mn / (sqrtf(vn) + eps);
+        adam_update(p[e], m[e], v[e], __fmul_rn(g[e], gscale), AdamCoef{a_t, b1, b2, eps});
     }
+}
+
+// the same update over up to kAdamSegs ranges of the arena (blockIdx.y = range): the fused form of the step applies it group by
+// group as the gradients become final (scs_set_fused_adam)
+constexpr int kAdamSegs = 12;
+struct AdamSegs { int off[kAdamSegs]; int len[kAdamSegs]; };
+__global__ void adam_seg_kernel(float* p, const float* g, float* m, float* v, AdamSegs sg, AdamCoef k) {
+    int off = sg.off[0], len = sg.len[0];
+#pragma unroll
+    for (int i = 1; i < kAdamSegs; ++i) if ((int)blockIdx.y == i) { off = sg.off[i]; len = sg.len[i]; }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < len; e += gridDim.x * blockDim.x) {
+        const int i = off + e;
+        adam_update(p[i], m[i], v[i], g[i], k);
+    }
+}
+static AdamCoef adam_coef(double t, float lr, float b1, float b2, float eps) {
+    return AdamCoef{(float)((double)lr * std::sqrt(1.0 - std::pow((double)b2, t)) / (1.0 - std::pow((double)b1, t))), b1, b2, eps};
 }
 
 // dynamic-LDS attributes are per device: set them for the device of every handle that trains (cheap; once per handle)
@@ -1002,6 +1036,11 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     constexpr HeadOff H = head_off();
     constexpr TowerOff T0 = tower_off(0);
     const scs_options& opt = h->opt;                                               // behaviour switches: per handle (scs_set_option), no getenv per step
+    // scs_set_fused_adam: the Lasagne-Adam update of this step's gradients is part of the step
+    const bool fused = h->fused_adam;
+    if (fused) h->adam_t += 1;
+    const AdamCoef ak = adam_coef((double)h->adam_t, h->fa_lr, h->fa_b1, h->fa_b2, h->fa_eps);
+    const AdamFuse af = fused ? AdamFuse{h->params, h->adam_m, h->adam_v, ak} : AdamFuse{nullptr, nullptr, nullptr, ak};
     const bool one_stream = opt.train_one_stream != 0;                             // tuning runs and the stream-order test: no side stream
     // batch-norm finalize inside the producing conv kernel up to kFinMaxBatch, as a launch of its own beyond (train_cfg.h);
     // option fin_max_batch overrides the bound (tests run both forms at one batch size)
@@ -1213,6 +1252,14 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         // step ends: a data-parallel caller may start exchanging that bucket now (scs_wait_head_grads)
         (void)hipEventRecord(w->ev_head, sd);
         w->head_recorded = true;
+        if (fused) {
+            // nothing reads FC1 / fc_2 / out / d1 parameters from the arena any more in this step (the head's forward is done, the
+            // data gradients use the transposed copies of the prep launch): 84 % of the update runs here, beside the conv backward pass
+            AdamSegs sg{};
+            sg.off[0] = H.fc1W; sg.len[0] = H.end - H.fc1W;
+            for (int t = 0; t < kTowers; ++t) { const TowerOff T = tower_off(t * kTowerFloats); sg.off[1 + t] = T.d1W; sg.len[1 + t] = (t + 1) * kTowerFloats - T.d1W; }
+            run(ST_ADAM1, sd, [&] { hipLaunchKernelGGL(adam_seg_kernel, dim3(216, 4), dim3(256), 0, sd, P, G, h->adam_m, h->adam_v, sg, ak); });
+        }
     }
     bg.M = n; bg.K4 = kD1; bg.K = kD1; bg.N = kFlat;
     for (int t = 0; t < kTowers; ++t)         // through the dropout in front of d1 (mask5 of the tower) in the epilogue
@@ -1227,6 +1274,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     const WgSlices slices = wg_slices(opt);
     WgFinalArgs fa{};
     fa.grads = G; fa.tower_stride = kTowerFloats;
+    // (the update inside these reductions was tried: their stores are a transpose - stride Cin * 9 floats between neighbouring lanes -
+    // and three more arrays accessed that way doubled their time; the conv weights are updated by one coalesced launch behind them)
     constexpr int kDgBands[kConvs] = {0, DG2::NB, DG3::NB, DG4::NB, DG5::NB};
     // conv5 block: data gradient + weight gradient as one launch of two small GEMMs per workgroup (conv5_bwd.h) up to
     // kC5MaxBatch; option c5_fused_max_batch overrides the bound (0: the generic kernels; tests run both forms)
@@ -1311,6 +1360,14 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         else run(ST_DG2, st, [&] { conv_launch<DG2>(a, st); });
         // weight gradient of this layer on the side stream (it reads the d z the kernel above stored)
         fork();
+        if (fused && i == 2) {
+            // (d beta, d gamma) of the conv2..conv5 blocks are final (the last of them left by the kernel above, or by its finalize
+            // launch): their update, a tiny launch on the side stream in front of the conv3 weight gradient
+            AdamSegs sb{};
+            for (int t = 0; t < kTowers; ++t)
+                for (int q = 1; q < kConvs; ++q) { sb.off[t * 4 + q - 1] = T0.bn[q] + t * kTowerFloats; sb.len[t * 4 + q - 1] = 2 * kCout[q]; }
+            run(ST_ADAM2, sd, [&] { hipLaunchKernelGGL(adam_seg_kernel, dim3(1, 12), dim3(128), 0, sd, P, G, h->adam_m, h->adam_v, sb, ak); });
+        }
         WgArgs wa{};
         float* part = w->wg_part + (size_t)(i - 1) * kTowers * kWgPartFloats;
         for (int t = 0; t < kTowers; ++t) {
@@ -1336,7 +1393,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     hipStream_t sl = tail_on_main ? sd : st, s2 = tail_on_main ? st : sd;
     run(ST_L1FINAL, sl, [&] {
         hipLaunchKernelGGL(l1_final_kernel, dim3(20, kTowers), dim3(256), 0, sl, w->l1_part, n * kL1Bands, n, w->mom,
-                           CPtr3{{w->l1p[0], w->l1p[1], w->l1p[2]}}, CPtr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, G, T0.convW[0], T0.bn[0], kTowerFloats);
+                           CPtr3{{w->l1p[0], w->l1p[1], w->l1p[2]}}, CPtr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, G, T0.convW[0], T0.bn[0], kTowerFloats, af);
     });
     if (tail_on_main) {
         fa.z0 = 1;
@@ -1345,6 +1402,14 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     fa.z0 = 0;
     run(ST_WGFINAL2, s2, [&] { hipLaunchKernelGGL(wgrad_final_kernel, dim3((20 * 20 * 9 + 63) / 64, kTowers, 1), dim3(256), 0, s2, fa); });
     join();                                   // every gradient is in the arena before the caller's stream goes on
+    if (fused) {
+        // what is left of the update: the conv2..conv5 weights (16 % of the arena), whose gradients the two reductions above
+        // have just finished - one coalesced launch of 12 ranges
+        AdamSegs sc{};
+        for (int t = 0; t < kTowers; ++t)
+            for (int q = 1; q < kConvs; ++q) { sc.off[t * 4 + q - 1] = T0.convW[q] + t * kTowerFloats; sc.len[t * 4 + q - 1] = kCout[q] * kCin[q] * 9; }
+        run(ST_ADAM3, st, [&] { hipLaunchKernelGGL(adam_seg_kernel, dim3(22, 12), dim3(256), 0, st, P, G, h->adam_m, h->adam_v, sc, ak); });
+    }
     if (hipError_t le = hipGetLastError(); le != hipSuccess) {
         w->tickets_dirty = true;
         set_error("a launch of the training step failed: %s", hipGetErrorString(le));
@@ -1504,9 +1569,18 @@ int scs_train_loss(scs_handle h, float** dev_ptr) {
     return SCS_OK;
 }
 
+int scs_set_fused_adam(scs_handle h, int enable, float lr, float beta1, float beta2, float eps) {
+    SCS_ARG(h != nullptr, "null handle");
+    SCS_ARG(!enable || (lr > 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f), "Adam coefficients out of range");
+    h->fused_adam = enable != 0;
+    if (enable) { h->fa_lr = lr; h->fa_b1 = beta1; h->fa_b2 = beta2; h->fa_eps = eps; }
+    return SCS_OK;
+}
+
 int scs_adam_apply(scs_handle h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
     SCS_ARG(h != nullptr, "null handle");
     if (!h->has_params) { set_error("scs_adam_apply before scs_set_params"); return SCS_ERR_STATE; }
+    if (h->fused_adam) { set_error("scs_adam_apply on a handle with the fused update on (scs_set_fused_adam): the step applied it"); return SCS_ERR_STATE; }
     SCS_HIP(hipSetDevice(h->device));
     h->adam_t += 1;
     const double t = (double)h->adam_t;

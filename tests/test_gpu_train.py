@@ -660,3 +660,35 @@ def test_long_run_is_deterministic_under_uneven_load(weights):
         out.append(h.get_params())
         h.close()
     assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize('n', [5, 128, 256])
+def test_fused_adam_gives_the_bits_of_the_two_call_form(weights, n):
+    """scs_set_fused_adam: the step applies lasagne.updates.adam itself - the dense layers' ranges on the side stream as soon as
+    their gradients are final, the conv blocks' behind the layer-1 launch and the conv3..5 reduction, conv2.W inside its
+    reduction.  Element for element the arithmetic of scs_adam_apply(grad_scale 1): five steps through both forms leave the
+    same parameters (BN running statistics included), Adam moments and losses, bit for bit - an update that ran before its
+    gradient was final, or a range updated twice or never, would show here.  scs_adam_apply refuses while the fused form is on."""
+    from cnn_cort import synth, _hip
+    out = {}
+    for form in ('two calls', 'fused'):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        h.set_fused_adam(form == 'fused', lr=2e-3, b1=0.8, b2=0.99, eps=1e-7)
+        st = torch.cuda.current_stream().cuda_stream
+        losses = []
+        for step in range(5):
+            ax, co, sa, at = synth.patch_batch(n, seed=2100 + n + step)
+            y = np.random.RandomState(n + step).randint(0, 15, n).astype(np.uint8)
+            losses.append(h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=61 + step, stream=st))
+            if form == 'fused':
+                with pytest.raises(_hip.ScsError):
+                    h.adam_apply(stream=st)
+            else:
+                h.adam_apply(lr=2e-3, b1=0.8, b2=0.99, eps=1e-7, stream=st)
+        torch.cuda.synchronize()
+        out[form] = (np.array(losses), arena(h, 'grad').copy(), arena(h, 'param').copy())
+        h.close()
+    assert not np.array_equal(out['fused'][2], P.params_to_flat(weights))
+    for got, ref, what in zip(out['fused'], out['two calls'], ('losses', 'gradient arena', 'parameter arena')):
+        assert np.array_equal(got, ref), '%s differ between the fused update and scs_adam_apply at n = %d' % (what, n)

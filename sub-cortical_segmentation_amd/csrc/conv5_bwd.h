@@ -30,6 +30,7 @@ constexpr int kC5RedFloats = kC5G * 40 * 5 * 2;
 constexpr size_t kC5LdsBytes = (size_t)(kC5DzFloats + kC5XPad + kC5WcFloats + kC5RedFloats) * 4;   // (Z4: 16 000 floats, in Wc's space)
 static_assert(kC5Z4Floats <= kC5WcFloats && kC5Threads * 3 * 2 <= kC5WcFloats, "the raw conv4 planes and the finalize scratch reuse the weights' space");
 static_assert(kC5LdsBytes <= 160 * 1024, "LDS budget");
+static_assert(8 * 60 * 2 * 2 <= kC5DzFloats && 64 * 4 <= kC5RedFloats, "part5 scratch: the per-part sums in the d z space, the coefficient table in s_red");
 
 struct C5BArgs {
     const float* Z5[kTowers];     // raw conv5 output [n][60][9]
@@ -43,11 +44,20 @@ struct C5BArgs {
     float* stats;                 // [tower][workgroups][40][2]: (sum dy, sum dy xhat) of the conv4 block, one unit per workgroup
     float* part;                  // [tower][workgroups][360][60]
     unsigned long long* stamps;   // diagnostic (SCS_C5_STAMPS): 8 time stamps (100 MHz) per workgroup, or null
+    // part5 set (tail_fused): the conv5 block's own (d beta, d gamma) arrive as per-(row block, column) sums from the dense head's
+    // last stage (dense_chain.h) instead of as the coefficient table cf5 of a launch in between: every workgroup adds them per
+    // channel (fixed order, double: the same bits everywhere), forms (sc, sh, ca, cb) in LDS, and workgroup 0 of a tower
+    // stores the two gradients
+    const float* part5;           // [tower][blocks5][540] float2, or null
+    int blocks5;
+    const float* low5[kTowers];   // float4 per channel of the conv5 block: sc, sh, mean, inv_std
+    float* gbn5[kTowers];         // (d beta, d gamma) slot of the conv5 block in the gradient arena
     FinArgs fin;                  // fin_on: the last workgroup of a tower turns the sums into the conv4 block's BN-backward coefficients
     int fin_on;                   // (conv_mfma.h: take_ticket / bn_grp_backward / bn_top_backward; sums then leave write-through)
     int n;
 };
 
+template <bool P5>     // P5: the conv5 block's BN-backward coefficients from the dense head's column sums (a.part5)
 __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem5[];
     float* s_dz = smem5;                                  // [48][66]
@@ -70,6 +80,22 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
     stamp(0);
     constexpr int Z_IT = (kC5Z4Floats / 4 + kC5Threads - 1) / kC5Threads;          // 8
     float4 z4v[Z_IT];
+    // ---- part5: the conv5 block's BN-backward coefficients from the dense head's column sums.  Thread (c, p): channel c = tid % 60,
+    // part p = tid / 60 (8 parts) takes row blocks p, p + 8, .. - requested here, ahead of everything else (loads retire in order)
+    constexpr int P5_MAXB = 3;                                 // row blocks per part: 8 x 3 = 24 blocks = batch 384 (the chain's bound)
+    float2 p5v[P5_MAXB][9];
+    float4 lo5 = {0.f, 0.f, 0.f, 0.f};
+    constexpr bool p5 = P5;
+    const int p5c = tid % 60, p5p = tid / 60;
+    if constexpr (p5) {                                        // (straight-line loads from clamped addresses: no branch around the batch)
+        const int cc = min(p5c, 59), pp = min(p5p, 7);
+        const float2* __restrict__ ps = reinterpret_cast<const float2*>(a.part5) + (size_t)tower * a.blocks5 * 540 + cc * 9;
+#pragma unroll
+        for (int i = 0; i < P5_MAXB; ++i)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) p5v[i][k] = ps[(size_t)min(pp + 8 * i, a.blocks5 - 1) * 540 + k];
+        lo5 = reinterpret_cast<const float4*>(pick3(a.low5, tower))[cc];
+    }
 
     // ---- stage: d z (formed here), X5, Wc - every load of a thread in flight before the first LDS write; the raw conv4 planes
     // the epilogue needs are requested right behind and wait in registers (their LDS space is Wc's, free after the col2im step)
@@ -85,12 +111,45 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
             const bool ok = r < ng * 9 && o < 60;
             const int g = r / 9, px = r - g * 9;
             const int at = ok ? g * 540 + o * 9 + px : 0;
-            zv[k] = z5[at]; dv[k] = dh[at]; cv[k] = cf[ok ? o : 0];
+            zv[k] = z5[at]; dv[k] = dh[at]; if constexpr (p5) cv[k] = float4{0.f, 0.f, 0.f, 0.f}; else cv[k] = cf[ok ? o : 0];
         }
 #pragma unroll
         for (int k = 0; k < X_IT; ++k) { const int e = tid + kC5Threads * k; xv[k] = (e < ng * 250) ? x5[e] : float4{0.f, 0.f, 0.f, 0.f}; }
+        // (with part5 the weights - which only the second GEMM needs - are requested behind the coefficient step: held across its
+        // barriers the compiler spilled all 44 registers of them to scratch)
+        if constexpr (!p5) {
 #pragma unroll
-        for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; wv[k] = wc[min(e, kC5WcFloats / 4 - 1)]; }
+            for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; wv[k] = wc[min(e, kC5WcFloats / 4 - 1)]; }
+        }
+        if constexpr (p5) {
+            // sums per (channel, part) -> LDS (the d z space: nothing has been written there yet), the 8 parts in order, then the
+            // coefficient table in the s_red space; bn_bwd_final_kernel's formulas
+            double* s_p5 = reinterpret_cast<double*>(s_dz);                        // [8][60][2]
+            float4* s_cf = reinterpret_cast<float4*>(s_red);                       // [64]
+            {
+                float fb = 0.f, fg = 0.f;                                          // a thread's <= 27 values in float, the parts in double
+#pragma unroll
+                for (int i = 0; i < P5_MAXB; ++i) {
+                    const bool on = p5p + 8 * i < a.blocks5;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { fb += on ? p5v[i][k].x : 0.f; fg += on ? p5v[i][k].y : 0.f; }
+                }
+                if (tid < 480) { s_p5[(p5p * 60 + p5c) * 2] = (double)fb; s_p5[(p5p * 60 + p5c) * 2 + 1] = (double)fg; }
+            }
+            __syncthreads();
+            if (tid < 60) {
+                double sb = 0, sg = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { sb += s_p5[(q * 60 + tid) * 2]; sg += s_p5[(q * 60 + tid) * 2 + 1]; }
+                const double count = (double)a.n * 9.0, mb = sb / count, mg = sg / count, sc = lo5.x, inv = lo5.w, mean = lo5.z;
+                s_cf[tid] = make_float4(lo5.x, lo5.y, (float)(-sc * inv * mg), (float)(sc * (inv * mean * mg - mb)));
+                if (blockIdx.x == 0) { float* gb = pick3(a.gbn5, tower); gb[tid] = (float)sb; gb[60 + tid] = (float)sg; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < DZ_IT; ++k) { const int o = (tid + kC5Threads * k) & 63; cv[k] = s_cf[min(o, 59)]; }
+            __syncthreads();                                                       // s_p5 has been read: d z may be written
+        }
 #pragma unroll
         for (int k = 0; k < DZ_IT; ++k) {
             const int e = tid + kC5Threads * k, r = e >> 6, o = e & 63;
@@ -100,8 +159,16 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
         }
 #pragma unroll
         for (int k = 0; k < X_IT; ++k) { const int e = tid + kC5Threads * k; if (e < kC5XFloats / 4) reinterpret_cast<float4*>(s_x)[e] = xv[k]; }
+        if constexpr (!p5) {
 #pragma unroll
-        for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; if (e < kC5WcFloats / 4) reinterpret_cast<float4*>(s_w)[e] = wv[k]; }
+            for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; if (e < kC5WcFloats / 4) reinterpret_cast<float4*>(s_w)[e] = wv[k]; }
+        } else {
+            float4 w2[W_IT];                                                       // (its own registers: see above)
+#pragma unroll
+            for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; w2[k] = wc[min(e, kC5WcFloats / 4 - 1)]; }
+#pragma unroll
+            for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; if (e < kC5WcFloats / 4) reinterpret_cast<float4*>(s_w)[e] = w2[k]; }
+        }
     }
     // (requested behind the staging loads: memory operations retire in order, so in front of them they would hold up the first LDS write)
 #pragma unroll
@@ -271,11 +338,14 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
 inline int conv5_backward_workgroups(int n) { return (n + kC5G - 1) / kC5G; }
 
 inline hipError_t conv5_backward_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC5LdsBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_backward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC5LdsBytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_backward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC5LdsBytes);
 }
 
 inline void conv5_backward_launch(const C5BArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(conv5_backward_kernel, dim3(conv5_backward_workgroups(a.n), kTowers), dim3(kC5Threads), kC5LdsBytes, st, a);
+    if (a.part5) hipLaunchKernelGGL(conv5_backward_kernel<true>, dim3(conv5_backward_workgroups(a.n), kTowers), dim3(kC5Threads), kC5LdsBytes, st, a);
+    else hipLaunchKernelGGL(conv5_backward_kernel<false>, dim3(conv5_backward_workgroups(a.n), kTowers), dim3(kC5Threads), kC5LdsBytes, st, a);
 }
 
 }  // namespace scs

@@ -102,7 +102,10 @@ struct ConvCfg {
     static constexpr bool LAST_RAGGED = (NW - 1 + NW * (TPW - 1)) >= TILES;   // some waves lack their last tile
     // TILES = NW * q + 1 (9 or 13 tiles on 4 waves): instead of one wave owning the odd tile - and every other wave waiting
     // for it - its channel blocks are dealt to the waves: 16-block b to wave b, the 4-blocks to wave NT16 (training kernels)
-    static constexpr bool SHARED = (EPI_ >= EPI_RAW) && !NSPLIT_ && !POOL && TILES > NW && TILES % NW == 1 &&
+#ifndef SCS_SHARED_INFER
+#define SCS_SHARED_INFER 0
+#endif
+    static constexpr bool SHARED = ((EPI_ >= EPI_RAW && !POOL) || SCS_SHARED_INFER) && !NSPLIT_ && TILES > NW && TILES % NW == 1 &&
                                    (nt16(COUT_) + (nt4(COUT_) > 0 ? 1 : 0)) <= NW;
     static constexpr int WCHUNK = conv_chunk_floats(COUT_);   // floats per weight chunk
     static constexpr int WCHUNK4 = WCHUNK / 4;
@@ -365,6 +368,8 @@ struct ConvArgs {
     X0Src x0;                     // SRC_X0 / EPI_L1: the input patches
     int tower0;                   // first tower of this launch (grid.y towers from here; per-tower streams launch one each)
     FinArgs fin;                  // FIN configurations
+    float* wgstats;               // EPI_RAW_STATS with G > 1 (conv5 block), or null: [tower][workgroup][COUT] (mean, M2) of the workgroup's
+                                  // G * OUTB values per channel - the units the one-launch dense head finalizes (dense_chain.h)
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -1228,6 +1233,7 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
         constexpr int RPI = C::NTH / LPR;                    // rows per iteration
         float* __restrict__ sp = a.stats + ((size_t)tower * a.n * C::NB) * C::COUT * 2;
         const int sub = tid % LPR;
+        float2 unit_val = make_float2(0.f, 0.f);              // this thread's row of the last pass (G > 1: the only pass)
 #pragma unroll
         for (int row0 = 0; row0 < ROWS; row0 += RPI) {
             const int row = row0 + tid / LPR;
@@ -1304,6 +1310,26 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                     val = make_float2(sm, sq);
                 }
                 if constexpr (C::FIN) st_sc1(dst, val); else *dst = val;
+                unit_val = val;
+            }
+        }
+        if constexpr (C::EPI == EPI_RAW_STATS && C::G > 1) {
+            // the same statistics once more as ONE unit per (workgroup, channel): the G patches' units combined in patch order
+            // by the parallel-variance formula, in double (a.wgstats; the per-patch units above stay what the finalize launch reads)
+            static_assert(LPR == 1 && ROWS <= C::NTH && C::NB == 1, "one thread per (patch, channel) row, one pass");
+            if (a.wgstats) {
+                __syncthreads();                                           // s_o has been read: the LDS is free
+                float2* s_u = reinterpret_cast<float2*>(smem);
+                if (tid < ROWS) s_u[tid] = unit_val;
+                __syncthreads();
+                if (tid < C::COUT) {
+                    const double m0 = (double)s_u[tid].x;
+                    double sd = 0, sd2 = 0, q = 0;
+                    for (int g = 0; g < ng; ++g) { const float2 u = s_u[g * C::COUT + tid]; const double d = (double)u.x - m0; sd += d; sd2 += d * d; q += (double)u.y; }
+                    const double dm = sd / ng;
+                    reinterpret_cast<float2*>(a.wgstats)[((size_t)tower * gridDim.x + blockIdx.x) * C::COUT + tid] =
+                        make_float2((float)(m0 + dm), (float)(q + (double)C::OUTB * fmax(sd2 - sd * dm, 0.0)));
+                }
             }
         }
         if constexpr (C::FIN) {

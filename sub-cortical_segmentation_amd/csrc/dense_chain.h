@@ -68,6 +68,27 @@ struct DenseChainArgs {
     const uint8_t* y;                            // batch labels
     float* probs; float* dlog; float* loss_rows; // [n][16], [n][16], [n]
     float* R2; float* dR2;                       // [n][kFC2ld]
+    // conv5 block's batch norm folded into the chain (tail_fused; units[0] == null: H5 comes from the launch before, as round 3):
+    // every workgroup finalizes the statistics of ITS tower from the per-workgroup units conv5's forward kernel left (<= 96 units
+    // of 36 values: one round of loads, double arithmetic in a fixed order - every workgroup gets the same bits), then
+    // applies BN + ReLU + the dropout in front of d1 to the raw conv5 rows while they are its d1 A operand; the member that
+    // owns column block 0 of a tower also stores those rows as H5 (the d1 weight gradient reads them) and, in row block 0,
+    // the (scale, shift) / (sc, sh, mean, inv_std) tables and the running averages (nets.py:177-178)
+    struct Bn5 {
+        const float* units[kTowers];             // [nwg][60] (mean, M2) float2
+        float* bn[kTowers];                      // beta, gamma, mean, inv_std of the conv5 block in the parameter arena
+        float* ss[kTowers];                      // float2 [60] out
+        float* low4[kTowers];                    // float4 [60] out
+        const uint8_t* mask[kTowers];            // dropout keep-flags [n][540]
+        float* H5[kTowers];                      // [n][540] out
+        int nwg;
+    } bn5;
+    // conv5 block's batch-norm BACKWARD sums folded into the last stage (part5 == null: bn_bwd_final_kernel<true> as round 3):
+    // per (tower, row block, column) the sums over the block's 16 rows of dy and dy * xhat (dy = dH5 through the ReLU, from the raw
+    // conv5 output Z5); conv5_backward_kernel's prologue adds them per channel
+    float* part5;                                // [tower][row blocks][540] float2
+    const float* Z5[kTowers];                    // raw conv5 output [n][540]
+    float* clow;                                 // [row blocks][3][60] float4: the towers' (sc, sh, mean, inv_std) handed round inside a cluster
     unsigned int* counters;                      // kChainCounterWords, zero at launch
     unsigned long long* stamps;                  // diagnostic (SCS_CHAIN_STAMPS): kChainStamps 100 MHz time stamps per workgroup, or null
     int n;
@@ -121,9 +142,19 @@ __device__ __forceinline__ bool chain_barrier(unsigned int* ctr, unsigned int ro
 // One 16 x 64 output tile of C = epilogue(A W + b): gemm_splitk4_kernel's arithmetic (same K split over the 8 matrix waves, same
 // order of sums).  Straight-line loads from clamped (always valid) addresses; what lies outside the problem becomes zero by
 // select.  s_r: 8 * 4 * 64 f32x4 of LDS.
-template <int ROLE>
+// what the BN5 form of the first tile needs beside its GemmProblem (A = the raw conv5 rows)
+struct ChainBn5Tile {
+    const float2* units; float* bn; float* ss; float* low4; const uint8_t* mask; float* H5; float* clow;   // clow: this cluster's [60] float4 of the tower
+    int nwg, n; bool store_h5, store_tables;
+    double* s_part;        // LDS [8][64][3]
+    float2* s_sc;          // LDS [64]
+    float2* s_bn;          // LDS [544]: (scale, shift) per k = (channel, pixel)
+};
+constexpr int kBn5MaxUnits = 12;                 // units per thread: 8 parts x 12 = 96 workgroups of 4 patches = batch 384
+
+template <int ROLE, bool BN5 = false>
 __device__ __forceinline__ void chain_tile(const GemmProblem& P, int M, int K4, int K, int N, int relu, int m0, int n0,
-                                           f32x4* s_r, ChainStamper& ts) {
+                                           f32x4* s_r, ChainStamper& ts, const ChainBn5Tile* bx = nullptr) {
     ts.hit();                                                   // [0] tile start
     using T = GemmSplitK4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -133,6 +164,17 @@ __device__ __forceinline__ void chain_tile(const GemmProblem& P, int M, int K4, 
     f32x4 acc[4];
     float e_bias_raw = 0.f, e_gate[4] = {1.f, 1.f, 1.f, 1.f};
     unsigned char e_mask[4] = {1, 1, 1, 1};
+    // BN5: the statistics units of this tower, requested FIRST (loads retire in order: they are back before the operands)
+    float2 bu[BN5 ? kBn5MaxUnits : 1];
+    float2 bu0 = make_float2(0.f, 0.f);
+    float b_beta = 0.f, b_gamma = 0.f, b_mean = 0.f, b_inv = 0.f;
+    if constexpr (BN5) {
+        const int c = min(tid & 63, 59), p = tid >> 6;
+        bu0 = bx->units[c];
+#pragma unroll
+        for (int i = 0; i < kBn5MaxUnits; ++i) bu[i] = bx->units[(size_t)min(p + 8 * i, bx->nwg - 1) * 60 + c];
+        if (tid < 60) { b_beta = bx->bn[tid]; b_gamma = bx->bn[60 + tid]; b_mean = bx->bn[120 + tid]; b_inv = bx->bn[180 + tid]; }
+    }
     {
         const int kmax = K ? K : K4;
         const int groups = (K4 + 15) / 16, per = (groups + T::NW - 1) / T::NW;  // per <= GMAX: K4 <= 640 (checked on the host)
@@ -143,11 +185,13 @@ __device__ __forceinline__ void chain_tile(const GemmProblem& P, int M, int K4, 
         const bool col_ok = n0 + 4 * lr < P.NS;
         const float* __restrict__ wcol = P.W + min(n0 + 4 * lr, P.NS - 4);
         float4 av[T::GMAX], wv[T::GMAX][4];
+        unsigned int am[BN5 ? T::GMAX : 1];                     // BN5: four dropout keep-flags beside every four raw values
 #pragma unroll
         for (int u = 0; u < T::GMAX; ++u) {
             const bool on = (g_beg + u) < g_end;
             const int k = on ? 16 * (g_beg + u) + 4 * kq : 0;   // a group this wave does not own: rows 0..3 (cached)
             av[u] = *reinterpret_cast<const float4*>(arow + (k < K4 ? k : 0));
+            if constexpr (BN5) am[u] = *reinterpret_cast<const unsigned int*>(bx->mask + (size_t)(row_ok ? row : 0) * kFlat + (k < K4 ? k : 0));
 #pragma unroll
             for (int i = 0; i < 4; ++i) wv[u][i] = *reinterpret_cast<const float4*>(wcol + (size_t)min(k + i, kmax - 1) * P.NS);
         }
@@ -165,6 +209,64 @@ __device__ __forceinline__ void chain_tile(const GemmProblem& P, int M, int K4, 
                 const int orow = min(m0 + kq * 4 + r, M - 1);
                 e_mask[r] = mp[(size_t)orow * ldm];
                 e_gate[r] = gp[(size_t)orow * ldg];
+            }
+        }
+        if constexpr (BN5) {
+            // ---- finalize the tower's batch statistics (every workgroup of the tower does, in the same order: the same bits):
+            // weighted parallel-variance combine of the units about unit 0's mean, eight strided sub-sums per channel added in order
+            {
+                const int c = tid & 63, p = tid >> 6;
+                const double m0 = (double)bu0.x;
+                double sw = 0, sw2 = 0, q = 0;
+#pragma unroll
+                for (int i = 0; i < kBn5MaxUnits; ++i) {
+                    const int uu = p + 8 * i;
+                    if (uu < bx->nwg) {
+                        const double wgt = 9.0 * (double)min(4, bx->n - 4 * uu), d = (double)bu[i].x - m0;
+                        sw += wgt * d; sw2 += wgt * d * d; q += (double)bu[i].y;
+                    }
+                }
+                double* sp = bx->s_part + (p * 64 + c) * 3;
+                sp[0] = sw; sp[1] = sw2; sp[2] = q;
+            }
+            __syncthreads();
+            if (tid < 60) {
+                double sw = 0, sw2 = 0, q = 0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) { const double* sp = bx->s_part + (p * 64 + tid) * 3; sw += sp[0]; sw2 += sp[1]; q += sp[2]; }
+                const double cnt = 9.0 * (double)bx->n, dm = sw / cnt, mean = (double)bu0.x + dm;
+                const double var = (q + fmax(sw2 - sw * dm, 0.0)) / cnt;
+                const double inv = 1.0 / sqrt(var + (double)kBnEps);
+                const float sc = b_gamma * (float)inv, sh = b_beta - (float)mean * sc;
+                bx->s_sc[tid] = make_float2(sc, sh);
+                if (bx->clow) reinterpret_cast<float4*>(bx->clow)[tid] = make_float4(sc, sh, (float)mean, (float)inv);   // for this cluster's last stage
+                if (bx->store_tables) {
+                    reinterpret_cast<float2*>(bx->ss)[tid] = make_float2(sc, sh);
+                    reinterpret_cast<float4*>(bx->low4)[tid] = make_float4(sc, sh, (float)mean, (float)inv);
+                    bx->bn[120 + tid] = (1.f - kBnAlpha) * b_mean + kBnAlpha * (float)mean;
+                    bx->bn[180 + tid] = (1.f - kBnAlpha) * b_inv + kBnAlpha * (float)inv;
+                }
+            }
+            __syncthreads();
+            // ---- the A operand: raw conv5 values -> BN + ReLU + dropout (bn_fwd_final_kernel<true>'s expression); H5 as a by-product.
+            // Four consecutive k = (channel, pixel) indices touch at most two channels: c0 = k / 9 and, from element 9 (c0 + 1) - k on, c0 + 1
+#pragma unroll
+            for (int u = 0; u < T::GMAX; ++u) {
+                const bool on = (g_beg + u) < g_end;
+                const int k = 16 * (g_beg + u) + 4 * kq;
+                if (on && k < K4) {
+                    const int c0 = (k * 7282) >> 16;                          // k / 9 for k < 16384
+                    const int nb = 9 * (c0 + 1) - k;                          // elements 0 .. nb - 1 belong to channel c0
+                    const float2 ca = bx->s_sc[c0], cb = bx->s_sc[min(c0 + 1, 59)];
+                    const unsigned int mk = am[u];
+                    float4 h;
+                    h.x = (mk & 0xFFu) ? 2.f * fmaxf(fmaf(av[u].x, ca.x, ca.y), 0.f) : 0.f;
+                    h.y = (mk & 0xFF00u) ? 2.f * fmaxf(nb > 1 ? fmaf(av[u].y, ca.x, ca.y) : fmaf(av[u].y, cb.x, cb.y), 0.f) : 0.f;
+                    h.z = (mk & 0xFF0000u) ? 2.f * fmaxf(nb > 2 ? fmaf(av[u].z, ca.x, ca.y) : fmaf(av[u].z, cb.x, cb.y), 0.f) : 0.f;
+                    h.w = (mk & 0xFF000000u) ? 2.f * fmaxf(nb > 3 ? fmaf(av[u].w, ca.x, ca.y) : fmaf(av[u].w, cb.x, cb.y), 0.f) : 0.f;
+                    av[u] = h;
+                    if (bx->store_h5 && row_ok) *reinterpret_cast<float4*>(bx->H5 + (size_t)row * kFlat + k) = h;
+                }
             }
         }
         ts.drained();                                           // [1] operands have arrived (diagnostic runs only)
@@ -398,6 +500,8 @@ __device__ __forceinline__ void chain_d1_dgrad(const DenseChainArgs& a, int M, i
     constexpr int JW = 3;                                       // jobs per wave (the third only in waves 0, 1)
     float4 av[JW][2], wv[JW][2][4];
     unsigned char e_mask[2][4];
+    float e_z[2][4];                                            // part5: the raw conv5 values of the outputs this wave finishes ...
+    float4 e_lo[2];                                             // ... and their channel's (sc, sh, mean, inv_std)
     // the two (tower, column set) pairs this wave finishes: e = wave, wave + 8 of the 12
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -406,6 +510,16 @@ __device__ __forceinline__ void chain_d1_dgrad(const DenseChainArgs& a, int M, i
         const int ecl = min(n0 + 4 * lr + jc, kFlat - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) e_mask[f][r] = P.mask[(size_t)min(m0 + kq * 4 + r, M - 1) * P.ldm + ecl];
+        e_lo[f] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e_z[f][r] = 0.f;
+        if (a.part5) {
+            const float* z5 = t == 0 ? a.Z5[0] : (t == 1 ? a.Z5[1] : a.Z5[2]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e_z[f][r] = z5[(size_t)min(m0 + kq * 4 + r, M - 1) * kFlat + ecl];
+            // the tower's coefficients as its member of THIS cluster left them in front of barrier 1 (same XCD: L2)
+            e_lo[f] = reinterpret_cast<const float4*>(a.clow + ((size_t)(m0 / 16) * kTowers + t) * 240)[ecl / 9];
+        }
     }
 #pragma unroll
     for (int q = 0; q < JW; ++q) {
@@ -469,6 +583,22 @@ __device__ __forceinline__ void chain_d1_dgrad(const DenseChainArgs& a, int M, i
                 if (orow < M) P.C[(size_t)orow * P.ldc + ecol] = e_mask[f][r] ? 2.f * v[r] : 0.f;
             }
         }
+        if (a.part5) {
+            // (d beta, d gamma) of the conv5 block, this column's share of the row block: dy = dH5 where the block's ReLU let the
+            // value through; the four lane groups hold four rows each (fixed order: rows, then lane groups 0+1, 2+3)
+            float pb = 0.f, pg = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int orow = m0 + kq * 4 + r;
+                const float dh = e_mask[f][r] ? 2.f * v[r] : 0.f;
+                const float dy = (orow < M && fmaf(e_z[f][r], e_lo[f].x, e_lo[f].y) > 0.f) ? dh : 0.f;
+                pb += dy; pg = fmaf(dy, (e_z[f][r] - e_lo[f].z) * e_lo[f].w, pg);
+            }
+            pb += __shfl_xor(pb, 16); pg += __shfl_xor(pg, 16);
+            pb += __shfl_xor(pb, 32); pg += __shfl_xor(pg, 32);
+            if (kq == 0 && ecol < kFlat)
+                reinterpret_cast<float2*>(a.part5)[((size_t)t * ((M + 15) / 16) + m0 / 16) * kFlat + ecol] = make_float2(pb, pg);
+        }
     }
     ts.hit();
 }
@@ -482,7 +612,27 @@ __device__ __forceinline__ void chain_body(const DenseChainArgs& a, int j, int m
     // d1 x3: member j = (tower j / 3, column block j % 3); H5 comes from the launch before
     const int t1 = j / 3, n1 = (j - 3 * t1) * GemmSplitK4::BN;
     const GemmProblem P1 = t1 == 0 ? a.d1[0] : (t1 == 1 ? a.d1[1] : a.d1[2]);
-    chain_tile<ROLE>(P1, n, kFlat, kFlat, kD1, 1, m0, n1, s_r, ts);
+    if (a.bn5.units[0]) {
+        // the conv5 block's batch norm + ReLU + dropout happen here, on the way into the matrix cores (P1.A = the raw conv5 rows)
+        float* lds = reinterpret_cast<float*>(s_r);
+        ChainBn5Tile bx;
+        bx.units = reinterpret_cast<const float2*>(t1 == 0 ? a.bn5.units[0] : (t1 == 1 ? a.bn5.units[1] : a.bn5.units[2]));
+        bx.bn = t1 == 0 ? a.bn5.bn[0] : (t1 == 1 ? a.bn5.bn[1] : a.bn5.bn[2]);
+        bx.ss = t1 == 0 ? a.bn5.ss[0] : (t1 == 1 ? a.bn5.ss[1] : a.bn5.ss[2]);
+        bx.low4 = t1 == 0 ? a.bn5.low4[0] : (t1 == 1 ? a.bn5.low4[1] : a.bn5.low4[2]);
+        bx.mask = t1 == 0 ? a.bn5.mask[0] : (t1 == 1 ? a.bn5.mask[1] : a.bn5.mask[2]);
+        bx.H5 = t1 == 0 ? a.bn5.H5[0] : (t1 == 1 ? a.bn5.H5[1] : a.bn5.H5[2]);
+        bx.nwg = a.bn5.nwg; bx.n = n;
+        bx.store_h5 = n1 == 0;                                  // one of the tower's three members stores the rows
+        bx.store_tables = n1 == 0 && m0 == 0;                   // ... and in row block 0 the tables / running averages
+        bx.clow = (n1 == 0 && a.clow) ? a.clow + ((size_t)(m0 / 16) * kTowers + t1) * 240 : nullptr;
+        bx.s_part = reinterpret_cast<double*>(lds + 8192);      // behind the 8 x 4 partial tiles (32 KB): 12 KB
+        bx.s_sc = reinterpret_cast<float2*>(lds + 8192 + 3072);
+        bx.s_bn = reinterpret_cast<float2*>(lds + 8192 + 3072 + 128);
+        chain_tile<ROLE, true>(P1, n, kFlat, kFlat, kD1, 1, m0, n1, s_r, ts, &bx);
+    } else {
+        chain_tile<ROLE>(P1, n, kFlat, kFlat, kD1, 1, m0, n1, s_r, ts);
+    }
     ok = chain_barrier<ROLE>(ctr, 1, s_flag, ts);
     ts.seek(8);
     if (ok) {                                                   // FC1 (K = 540 features of the three towers)
@@ -543,6 +693,7 @@ __global__ __launch_bounds__(512, 1) void dense_chain_kernel(DenseChainArgs a) {
 }
 
 constexpr size_t kChainLdsBytes = (size_t)kChainS7Floats * 4;
+static_assert(kChainS7Floats >= 8192 + 3072 + 128 + 2 * 544, "the BN5 tables of the first tile sit behind the partial tiles");
 static_assert(kChainS7Floats >= GemmSplitK4::NW * 4 * 64 * 4 + 16 * kFC2ld, "the last stage's partials are the larger set; dR2 [16][272] sits behind the 8 x 4 partial tiles");
 inline hipError_t dense_chain_set_attr() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kChainLdsBytes);

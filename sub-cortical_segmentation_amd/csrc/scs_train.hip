@@ -92,6 +92,10 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     unsigned int* chain_counter = nullptr;     // cluster barriers of dense_chain_kernel (inside `base`; zeroed by the prep launch)
     unsigned int* fin_counter = nullptr;       // arrival tickets of the in-kernel finalize steps (inside `base`; zero between launches)
     float* wg_part = nullptr;                  // [4 layers][3][kWgPartFloats] partial weight gradients
+    // tail_fused (the one-launch dense head takes the conv5 block's batch norm on both sides):
+    float* c5_units = nullptr;                 // [3][ceil(cap / 4)][60] float2: per-workgroup statistics units of conv5's forward kernel (inside `base`)
+    float* part5 = nullptr;                    // [3][24][540] float2: (d beta, d gamma) column sums left by the head's last stage
+    float* clow = nullptr;                     // [24][3][60] float4: the conv5 block's coefficients handed round inside a cluster
     // the weight-gradient kernels of a layer do not feed the data path: they run on a second stream beside the
     // data-gradient kernels (fork / join with events; the caller still sees one stream)
     hipStream_t side = nullptr;
@@ -122,6 +126,7 @@ void train_free(scs_ctx* h) {
     if (w->eval_rows) (void)hipFree(w->eval_rows);
     if (w->wT) (void)hipFree(w->wT);
     if (w->wg_part) (void)hipFree(w->wg_part);
+    if (w->part5) (void)hipFree(w->part5);
     if (w->small) (void)hipFree(w->small);
     if (w->mom) (void)hipFree(w->mom);
     if (w->side) (void)hipStreamDestroy(w->side);
@@ -161,6 +166,12 @@ static int train_ensure(scs_ctx* h, int n) {
         SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats + kTowers * kC5WcFloats) * sizeof(float)));
         SCS_HIP(hipMemset(w->wT, 0, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats + kTowers * kC5WcFloats) * sizeof(float)));   // pad columns stay zero
         SCS_HIP(hipMalloc(&w->wg_part, (size_t)4 * kTowers * kWgPartFloats * sizeof(float)));
+        {
+            const size_t f5 = (size_t)kTowers * (kChainMaxBatch / 16) * kFlat * 2, fc = (size_t)(kChainMaxBatch / 16) * kTowers * 240;
+            SCS_HIP(hipMalloc(&w->part5, (f5 + fc) * sizeof(float)));
+            SCS_HIP(hipMemset(w->part5, 0, (f5 + fc) * sizeof(float)));
+            w->clow = w->part5 + f5;
+        }
         SCS_HIP(hipMalloc(&w->mom, (size_t)kTowers * 100 * sizeof(double)));
         // coefficient tables: per tower and conv layer 64 x (float2 + float4 + float4), then the conv1 tables
         size_t so = 0;
@@ -211,7 +222,8 @@ static int train_ensure(scs_ctx* h, int n) {
                  o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * std::max<size_t>(256, (c + kMomentPpb - 1) / kMomentPpb) * 128),
                  o_fc = take(kTowers * fin_counter_words(c)),                 // one workgroup per patch in the FIN configurations
                  o_fg = take(kTowers * fin_groups(c) * kFinRec * 2 * 2),      // group records (doubles)
-                 o_cc = take((size_t)kChainCounterWords);
+                 o_cc = take((size_t)kChainCounterWords),
+                 o_c5u = take((size_t)kTowers * ((c + 3) / 4) * 120);
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
     SCS_HIP(hipMemset(w->base, 0, off * sizeof(float)));
     for (int t = 0; t < kTowers; ++t) {
@@ -228,6 +240,7 @@ static int train_ensure(scs_ctx* h, int n) {
     w->fin_counter = reinterpret_cast<unsigned int*>(w->base + o_fc);
     w->fin_grp = reinterpret_cast<double*>(w->base + o_fg);
     w->chain_counter = reinterpret_cast<unsigned int*>(w->base + o_cc);
+    w->c5_units = w->base + o_c5u;
     SCS_HIP(hipMalloc(&w->masks, c * kFlat * 5 + c));
     w->yb = w->masks + c * kFlat * 5;
     w->cap = (int)c;
@@ -1078,9 +1091,6 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         w->tickets_dirty = false;
     }
     const uint8_t* masks = masks_dev ? masks_dev : w->masks;
-    const uint8_t* mask5 = masks;                                  // [3][n][540]
-    const uint8_t* mask1 = masks + (size_t)3 * n * kFlat;          // f1_drop [n][540]
-    const uint8_t* mask2 = mask1 + (size_t)n * kFlat;              // f2_drop [n][540]
     float* wT2 = w->wT;                       // [270][544]  = fc_2.W[:540]^T
     float* wT1 = wT2 + 270 * kTld;            // [540][544]  = FC1.W^T
     float* wTd = wT1 + 540 * kTld;            // [3][180][544] = d1.W^T
@@ -1113,11 +1123,38 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         });
         if (!bn1_fused) run(ST_FIN1, st, [&] { hipLaunchKernelGGL(bn1_final_kernel, dim3(kTowers), dim3(1024), 0, st, w->mom_part, units1, n, b1); });
     }
+    // dense head (weights straight from the arena: [K][N] row-major).  Decided HERE, ahead of the conv blocks: with the one-launch
+    // head the conv5 block's batch norm is the head's business on both sides (tail_fused) and the launches around it go away
+    GemmArgs g{};
+    g.M = n; g.K4 = kFlat; g.K = kFlat; g.N = kD1; g.relu = 1;
+    const uint8_t* const mask5 = masks;                            // [3][n][540]
+    const uint8_t* const mask1 = masks + (size_t)3 * n * kFlat;    // f1_drop [n][540]
+    const uint8_t* const mask2 = mask1 + (size_t)n * kFlat;        // f2_drop [n][540]
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        // feat = relu(H5 W + b) (kept: it gates the backward pass), featd = f1_drop(feat), both from the GEMM epilogue
+        g.p[t] = GemmProblem{w->H5[t], kFlat, P + T.d1W, kD1, P + T.d1b, w->feat + t * kD1, kFlat,
+                             mask1 + t * kD1, kFlat, nullptr, 0, w->featd + t * kD1, kFlat};
+    }
+    // Small batches: the whole dense head - these three layers, the out layer with its loss, and the three data-gradient
+    // layers below - is ONE launch of 9-workgroup clusters (dense_chain.h; same tiles, same sums, same bits); otherwise one
+    // launch per layer.  option dense_chain_max_batch overrides the bound (0: never; tests run both forms at one batch size);
+    // SCS_CHAIN_STAMPS prints the one-launch form's per-tile phase times to stderr (diagnostic, synchronises).
+    // ... and only on a device whose dispatcher gives every XCD grid / 8 workgroups (probed once per handle: chain_placement_ok)
+    const int chain_max = opt.dense_chain_max_batch >= 0 ? std::min(opt.dense_chain_max_batch, kChainMaxBatch) : kChainDefaultMaxBatch;
+    const bool chain = n <= chain_max && dense_chain_ok(n, g, kTowers) && h->chain_placement > 0;
+    const bool c5_fused = n <= (opt.c5_fused_max_batch >= 0 ? std::min(opt.c5_fused_max_batch, kC5MaxBatch) : kC5MaxBatch);
+    // tail_fused: bn5 + dropout and bn5 backward are no launches of their own - the head finalizes the conv5 block's statistics and
+    // applies them while it stages its first A operand, its last stage leaves the (d beta, d gamma) column sums and the conv5
+    // backward launch turns them into its coefficients.  Needs both one-launch forms; option tail_fused = 0 restores the launches.
+    const bool tail = chain && c5_fused && opt.tail_fused != 0;
+
     constexpr int kStatBands[kConvs] = {1, TF12::NB, TF3::NB, TF4::NB, TF5::NB};
     for (int i = 1; i < kConvs; ++i) {
         ConvArgs a{};
         a.n = n;
         a.stats = w->stat_part;
+        a.wgstats = (tail && i == kConvs - 1) ? w->c5_units : nullptr;
         for (int t = 0; t < kTowers; ++t) {
             a.w[t] = w->wpk[t][i]; a.out[t] = w->Z[t][i];
             if (i == 1) { a.w1[t] = w->w1p[t]; }
@@ -1144,31 +1181,30 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
                 hipLaunchKernelGGL(bn_fwd_final_kernel<false>, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, units, count, C, P, T0.bn[i],
                                    kTowerFloats, p3(w->ss, i), p3(w->low4, i), CPtr3{}, Ptr3{}, (const uint8_t*)nullptr, n);
             });
-        } else {
+        } else if (!tail) {
             run(ST_BN5, st, [&] {
                 hipLaunchKernelGGL(bn_fwd_final_kernel<true>, dim3(C, kTowers), dim3(256), 0, st, w->stat_part, units, count, C, P, T0.bn[i],
                                    kTowerFloats, p3(w->ss, i), p3(w->low4, i), c3(w->Z, i), Ptr3{{w->H5[0], w->H5[1], w->H5[2]}}, mask5, n);
             });
         }
     }
-    // dense head (weights straight from the arena: [K][N] row-major)
-    GemmArgs g{};
-    g.M = n; g.K4 = kFlat; g.K = kFlat; g.N = kD1; g.relu = 1;
-    for (int t = 0; t < kTowers; ++t) {
-        const TowerOff T = tower_off(t * kTowerFloats);
-        // feat = relu(H5 W + b) (kept: it gates the backward pass), featd = f1_drop(feat), both from the GEMM epilogue
-        g.p[t] = GemmProblem{w->H5[t], kFlat, P + T.d1W, kD1, P + T.d1b, w->feat + t * kD1, kFlat,
-                             mask1 + t * kD1, kFlat, nullptr, 0, w->featd + t * kD1, kFlat};
-    }
-    // Small batches: the whole dense head - these three layers, the out layer with its loss, and the three data-gradient
-    // layers below - is ONE launch of 9-workgroup clusters (dense_chain.h; same tiles, same sums, same bits); otherwise one
-    // launch per layer.  option dense_chain_max_batch overrides the bound (0: never; tests run both forms at one batch size);
-    // SCS_CHAIN_STAMPS prints the one-launch form's per-tile phase times to stderr (diagnostic, synchronises).
-    const int chain_max = opt.dense_chain_max_batch >= 0 ? std::min(opt.dense_chain_max_batch, kChainMaxBatch) : kChainDefaultMaxBatch;
     DenseChainArgs ch{};
     for (int t = 0; t < kTowers; ++t) ch.d1[t] = g.p[t];
-    // ... and only on a device whose dispatcher gives every XCD grid / 8 workgroups (probed once per handle: chain_placement_ok)
-    const bool chain = n <= chain_max && dense_chain_ok(n, g, kTowers) && h->chain_placement > 0;
+    if (tail) {
+        const int nwg5 = (n + TF5::G - 1) / TF5::G;
+        for (int t = 0; t < kTowers; ++t) {
+            ch.d1[t].A = w->Z[t][kConvs - 1];                      // the raw conv5 rows: BN + ReLU + dropout on the way in
+            ch.bn5.units[t] = w->c5_units + (size_t)t * nwg5 * 120;
+            ch.bn5.bn[t] = P + T0.bn[kConvs - 1] + t * kTowerFloats;
+            ch.bn5.ss[t] = reinterpret_cast<float*>(w->ss[t][kConvs - 1]);
+            ch.bn5.low4[t] = reinterpret_cast<float*>(w->low4[t][kConvs - 1]);
+            ch.bn5.mask[t] = mask5 + (size_t)t * n * kFlat;
+            ch.bn5.H5[t] = w->H5[t];
+            ch.Z5[t] = w->Z[t][kConvs - 1];
+        }
+        ch.bn5.nwg = nwg5;
+        ch.part5 = w->part5; ch.clow = w->clow;
+    }
     if (!chain) run(ST_D1, st, [&] { gemm_launch(g, kTowers, st); });
     g.K4 = kFC1; g.K = kFC1; g.N = kFC1;
     g.p[0] = GemmProblem{w->featd, kFlat, P + H.fc1W, kFC1, P + H.fc1b, w->R1, kFC1, mask2, kFC1, nullptr, 0, w->cat2, kFC1ld};
@@ -1278,8 +1314,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // and three more arrays accessed that way doubled their time; the conv weights are updated by one coalesced launch behind them)
     constexpr int kDgBands[kConvs] = {0, DG2::NB, DG3::NB, DG4::NB, DG5::NB};
     // conv5 block: data gradient + weight gradient as one launch of two small GEMMs per workgroup (conv5_bwd.h) up to
-    // kC5MaxBatch; option c5_fused_max_batch overrides the bound (0: the generic kernels; tests run both forms)
-    const bool c5_fused = n <= (opt.c5_fused_max_batch >= 0 ? std::min(opt.c5_fused_max_batch, kC5MaxBatch) : kC5MaxBatch);
+    // kC5MaxBatch (c5_fused, decided above); option c5_fused_max_batch overrides the bound (0: the generic kernels; tests run both forms)
     const int c5_units = conv5_backward_workgroups(n);
     const bool kDgFin[kConvs + 1] = {false, DG2::FIN != 0, DG3::FIN != 0 && fin_in_kernel, DG4::FIN != 0 && fin_in_kernel,
                                      c5_fused ? fin_in_kernel : (DG5::FIN != 0 && fin_in_kernel), false};
@@ -1288,7 +1323,9 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         const double count = (double)n * Hh * Hh;
         CPtr3 dUp;
         for (int t = 0; t < kTowers; ++t) dUp.p[t] = (i == kConvs - 1) ? w->dH5[t] : w->dX[t][i + 1];
-        if (i == kConvs - 1) {
+        if (i == kConvs - 1 && tail) {
+            // the head's last stage left the conv5 block's (d beta, d gamma) column sums; the launch below adds them itself
+        } else if (i == kConvs - 1) {
             run(ST_BN5B, st, [&] {
                 hipLaunchKernelGGL(bn_bwd_final_kernel<true>, dim3(C, kTowers), dim3(256), 0, st, (const float*)nullptr, 0, count, C, c3(w->low4, i),
                                    p3(w->cf4, i), G, T0.bn[i], kTowerFloats, c3(w->Z, i), dUp, n);
@@ -1311,6 +1348,10 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
                 b.Z4[t] = w->Z[t][i - 1]; b.low4[t] = reinterpret_cast<const float*>(w->low4[t][i - 1]);
             }
             b.stats = w->stat_part; b.part = part; b.n = n;
+            if (tail) {
+                b.part5 = w->part5; b.blocks5 = (n + 15) / 16;
+                for (int t = 0; t < kTowers; ++t) { b.low5[t] = reinterpret_cast<const float*>(w->low4[t][i]); b.gbn5[t] = G + T0.bn[i] + t * kTowerFloats; }
+            }
             b.fin_on = fin_in_kernel ? 1 : 0;
             b.fin.counter = w->fin_counter; b.fin.grp = w->fin_grp; b.fin.count = (double)n * kHout[i - 1] * kHout[i - 1];
             for (int t = 0; t < kTowers; ++t) { b.fin.bn[t] = G + T0.bn[i - 1] + t * kTowerFloats; b.fin.coef[t] = reinterpret_cast<float*>(w->cf4[t][i - 1]); }

@@ -420,6 +420,7 @@ def test_dense_head_as_one_launch_gives_the_bits_of_the_layer_launches(weights, 
     for form, bound in (('layers', '0'), ('chain', '384')):
         h = _hip.Handle(0)
         h.set_option('dense_chain_max_batch', int(bound))
+        h.set_option('tail_fused', 0)          # the head alone: the conv5 block's batch norm stays in its own launches on both sides
         h.set_params(P.params_to_flat(weights))
         st = torch.cuda.current_stream().cuda_stream
         losses = []
@@ -508,6 +509,7 @@ def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monke
     for form, bound in (("generic", "0"), ("fused", "1024"), ("fused again", "1024")):
         h = _hip.Handle(0)
         h.set_option('c5_fused_max_batch', int(bound))
+        h.set_option('tail_fused', 0)           # (the conv5 backward kernels alone: with tail_fused the forward differs in the order of two sums)
         h.set_params(P.params_to_flat(weights))
         st = torch.cuda.current_stream().cuda_stream
         ax, co, sa, at = synth.patch_batch(n, seed=900 + n)
@@ -692,3 +694,49 @@ def test_fused_adam_gives_the_bits_of_the_two_call_form(weights, n):
     assert not np.array_equal(out['fused'][2], P.params_to_flat(weights))
     for got, ref, what in zip(out['fused'], out['two calls'], ('losses', 'gradient arena', 'parameter arena')):
         assert np.array_equal(got, ref), '%s differ between the fused update and scs_adam_apply at n = %d' % (what, n)
+
+
+@pytest.mark.parametrize('n', [1, 5, 37, 128, 256, 257, 384])
+def test_conv5_batch_norm_inside_the_dense_head_against_its_own_launches(weights, n):
+    """tail_fused (default up to batch 384): no bn5 + dropout launch and no bn5-backward launch - the one-launch dense head finalizes the
+    conv5 block's batch statistics from per-workgroup units (every workgroup of a tower, same order, same bits), applies BN + ReLU +
+    dropout to the raw conv5 rows while they are its first A operand (one member stores them as H5 for the weight gradient), its
+    last stage leaves the (d beta, d gamma) column sums and the conv5 backward launch turns them into its coefficients.  Against
+    the launches (option tail_fused = 0), same draws and dropout seeds, three steps with Adam: losses to 1e-5, every gradient
+    array to 1e-5 of its scale (the statistics and the two sums are added in a different order, nothing else differs), parameters
+    and BN running statistics to 1e-4; and the fused form is deterministic."""
+    from cnn_cort import synth, _hip
+    out = {}
+    for form in ('launches', 'fused', 'fused again'):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        h.set_option('tail_fused', 0 if form == 'launches' else 1)
+        st = torch.cuda.current_stream().cuda_stream
+        losses, grads = [], None
+        for step in range(3):
+            ax, co, sa, at = synth.patch_batch(n, seed=3100 + n + step)
+            y = np.random.RandomState(n + step).randint(0, 15, n).astype(np.uint8)
+            losses.append(h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=71 + step, stream=st))
+            if step == 0:
+                grads = P.flat_to_params(arena(h, 'grad'))
+            h.adam_apply(stream=st)
+        torch.cuda.synchronize()
+        out[form] = (np.array(losses), grads, P.flat_to_params(arena(h, 'param')))
+        h.close()
+    assert np.isfinite(out['fused'][0]).all()
+    assert np.array_equal(out['fused'][0], out['fused again'][0])
+    worst = 0.0
+    for name, shapes in P.LAYER_SPEC:
+        for i, _ in enumerate(shapes):
+            assert np.array_equal(out['fused'][1][name][i], out['fused again'][1][name][i]), name
+            assert np.array_equal(out['fused'][2][name][i], out['fused again'][2][name][i]), name
+            # (n = 1: nine values per channel in the conv5 block's batch norm - inv_std up to 100 amplifies float32 rounding; parameters
+            # after three Adam steps: a noise-level gradient may change sign)
+            for which, tol in ((1, 1e-5 if n > 1 else 1e-3), (2, 1e-4 if n > 1 else 1e-2)):
+                ref, got = out['launches'][which][name][i], out['fused'][which][name][i]
+                err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
+                if which == 1:
+                    worst = max(worst, err)
+                assert err <= tol, '%s[%d] (%s): %g of scale' % (name, i, 'gradient' if which == 1 else 'parameters', err)
+    assert np.abs(out['fused'][0] - out['launches'][0]).max() <= 1e-5 * max(1.0, np.abs(out['launches'][0]).max())
+    print('n = %d: conv5 batch norm inside the head vs its own launches, worst relative gradient difference %.3g' % (n, worst))

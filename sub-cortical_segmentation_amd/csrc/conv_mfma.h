@@ -70,7 +70,7 @@ template <int CIN_, int COUT_, int HIN_, int G_, int EPI_, int SRC_, int PLANE_,
 struct ConvCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, G = G_, EPI = EPI_, SRC = SRC_, NB = NB_, WPS = WPS_, STAMP = STAMP_, FIN = FIN_;
     static_assert(!FIN_ || (NW_ >= 4 && (EPI_ == EPI_RAW_STATS || EPI_ == EPI_RAW_BNB || EPI_ == EPI_RAW_BNB_POOL)), "in-kernel finalize: statistics kernels of at least 256 threads");
-    static_assert(!FIN_ || (NB_ == 1 && G_ == 1), "in-kernel finalize: one statistics unit per workgroup");
+    static_assert(!FIN_ || G_ == 1, "in-kernel finalize: one statistics unit per workgroup (a patch, or one band of it)");
     static constexpr int NW = NW_, NTH = 64 * NW_;          // waves / threads per workgroup
     static constexpr bool NSPLIT = NSPLIT_ != 0;            // K split over waves of (channel pair, K part) (see above)
     static constexpr int KS = NSPLIT_ > 0 ? NSPLIT_ : 1;
@@ -137,8 +137,8 @@ struct ConvCfg {
     static_assert(PLANE_ >= HINB * HIN_, "plane stride too small");
     static_assert(LDS_BYTES * WPS_ <= 160 * 1024, "LDS budget (WPS workgroups per CU)");
     static_assert(NTH >= 8 * XROWS || !FUSED1, "raw patch rows are staged in one pass");
-    static_assert((SRC_ != SRC_BN && SRC_ != SRC_BN_POOL) || NB_ == 1, "BN-fused staging takes whole planes");
-    static_assert(SRC_ != SRC_BN || ((HIN_ * HIN_) % 4 == 0 && PLANE_ % 4 == 0), "SRC_BN stages 16-byte pieces");
+    static_assert(SRC_ != SRC_BN || ((HIN_ * HIN_) % 4 == 0 && PLANE_ % 4 == 0 && (HOB * HIN_) % 4 == 0 && (HINB * HIN_) % 4 == 0),
+                  "SRC_BN stages 16-byte pieces (of a band: its first row and its row count must keep them aligned)");
     static_assert(SRC_ != SRC_DZ_POOL_PAD2 || (HINB % 2 == 0 && HIN_ % 2 == 0 && PLANE_ % 2 == 0 && (NB_ == 1 || HOB % 2 == 0)),
                   "pooled d z staging walks 2x2 windows");
     static_assert(EPI_ != EPI_L1 || (COUT_ == 20 && HO == 30 && G_ == 1 && NW_ == 4), "EPI_L1 is the conv2 data gradient");
@@ -707,50 +707,54 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             [&](int e, float v) { const int pl = e / BW, r = e - pl * BW; s_in[pl * C::PLANE + r] = v; });
     } else if constexpr (C::SRC == SRC_BN) {
         // training forward: x = relu(sc * z + sh) while staging; x is also stored (the weight-gradient kernel reads it)
-        constexpr int HW = C::HIN * C::HIN, HW4 = HW / 4;
-        const float4* __restrict__ src4 = reinterpret_cast<const float4*>(insrc + (size_t)g0 * C::CIN * HW);
+        // (NB > 1: rows [band * HOB, band * HOB + HINB) of every plane; a band stores the rows it owns - the last one its halo too)
+        constexpr int HW = C::HIN * C::HIN, HW4 = HW / 4, BW4 = C::HINB * C::HIN / 4, B04 = C::HOB * C::HIN / 4;
+        const float4* __restrict__ src4 = reinterpret_cast<const float4*>(insrc + (size_t)g0 * C::CIN * HW) + band * B04;
         const float2* __restrict__ bn2 = reinterpret_cast<const float2*>(pick3(a.bn, tower));
         float* __restrict__ xo = pick3(a.xout, tower);
-        float4* __restrict__ xo4 = xo ? reinterpret_cast<float4*>(xo + (size_t)g0 * C::CIN * HW) : nullptr;
+        float4* __restrict__ xo4 = xo ? reinterpret_cast<float4*>(xo + (size_t)g0 * C::CIN * HW) + band * B04 : nullptr;
         float4* dst4 = reinterpret_cast<float4*>(s_in);
         const int planes = ng * C::CIN;
+        const int own4 = (C::NB == 1 || band == C::NB - 1) ? BW4 : B04;
         struct V { float4 v; float2 ss; };
-        staged_copy<C::G * C::CIN * HW4, V, C::NTH, 0>(
+        staged_copy<C::G * C::CIN * BW4, V, C::NTH, 0>(
             tid,
-            [&](int e) { const int pl = e / HW4; V r; r.ss = bn2[pl % C::CIN];
-                         r.v = (pl < planes) ? src4[e] : float4{0.f, 0.f, 0.f, 0.f}; return r; },
+            [&](int e) { const int pl = e / BW4, q = e - pl * BW4; V r; r.ss = bn2[pl % C::CIN];
+                         r.v = (pl < planes) ? src4[(size_t)pl * HW4 + q] : float4{0.f, 0.f, 0.f, 0.f}; return r; },
             [&](int e, V r) {
-                const int pl = e / HW4, q = e - pl * HW4;
+                const int pl = e / BW4, q = e - pl * BW4;
                 const float4 y{fmaxf(fmaf(r.v.x, r.ss.x, r.ss.y), 0.f), fmaxf(fmaf(r.v.y, r.ss.x, r.ss.y), 0.f),
                                fmaxf(fmaf(r.v.z, r.ss.x, r.ss.y), 0.f), fmaxf(fmaf(r.v.w, r.ss.x, r.ss.y), 0.f)};
                 dst4[pl * (C::PLANE / 4) + q] = y;
-                if (xo4 && pl < planes) xo4[e] = y;
+                if (xo4 && pl < planes && q < own4) xo4[(size_t)pl * HW4 + q] = y;
             });
     } else if constexpr (C::SRC == SRC_BN_POOL) {
         // training forward: x = maxpool2x2(relu(sc * z + sh)) while staging (one thread per window), x also stored
-        constexpr int HZ = 2 * C::HIN, HWZ = HZ * HZ, W = C::HIN * C::HIN;
-        const float* __restrict__ src = insrc + (size_t)g0 * C::CIN * HWZ;
+        // (NB > 1: pooled rows [band * HOB, band * HOB + HINB) of every plane; a band stores the rows it owns - the last one its halo too)
+        constexpr int HZ = 2 * C::HIN, HWZ = HZ * HZ, W = C::HIN * C::HIN, BW = C::HINB * C::HIN, B0 = C::HOB * C::HIN;
+        const float* __restrict__ src = insrc + (size_t)g0 * C::CIN * HWZ + (size_t)(2 * band * C::HOB) * HZ;
         const float2* __restrict__ bn2 = reinterpret_cast<const float2*>(pick3(a.bn, tower));
         float* __restrict__ xo = pick3(a.xout, tower);
-        if (xo) xo += (size_t)g0 * C::CIN * W;
+        if (xo) xo += (size_t)g0 * C::CIN * W + band * B0;
         const int planes = ng * C::CIN;
+        const int own = (C::NB == 1 || band == C::NB - 1) ? BW : B0;
         struct V { float2 r0, r1, ss; };
-        staged_copy<C::G * C::CIN * W, V, C::NTH, 0>(
+        staged_copy<C::G * C::CIN * BW, V, C::NTH, 0>(
             tid,
             [&](int e) {
-                const int pl = e / W, wdx = e - pl * W, wy = wdx / C::HIN, wx = wdx - wy * C::HIN;
+                const int pl = e / BW, wdx = e - pl * BW, wy = wdx / C::HIN, wx = wdx - wy * C::HIN;
                 V r; r.ss = bn2[pl % C::CIN];
                 const float* zp = src + (size_t)min(pl, planes - 1) * HWZ + (2 * wy) * HZ + 2 * wx;
                 r.r0 = *reinterpret_cast<const float2*>(zp); r.r1 = *reinterpret_cast<const float2*>(zp + HZ);
                 return r;
             },
             [&](int e, V r) {
-                const int pl = e / W, wdx = e - pl * W;
+                const int pl = e / BW, wdx = e - pl * BW;
                 const float m = fmaxf(fmaxf(fmaf(r.r0.x, r.ss.x, r.ss.y), fmaf(r.r0.y, r.ss.x, r.ss.y)),
                                       fmaxf(fmaf(r.r1.x, r.ss.x, r.ss.y), fmaf(r.r1.y, r.ss.x, r.ss.y)));
                 const float y = (pl < planes) ? fmaxf(m, 0.f) : 0.f;
                 s_in[pl * C::PLANE + wdx] = y;
-                if (xo && pl < planes) xo[(size_t)pl * W + wdx] = y;
+                if (xo && pl < planes && wdx < own) xo[(size_t)pl * W + wdx] = y;
             });
     } else if constexpr (C::SRC == SRC_DZ_PAD2 && C::NB == 1 && C::HSRC % 4 == 0) {
         // training backward, whole planes whose rows are float4 multiples: d z = [sc z + sh > 0] sc dUp + ca z + cb from 16-byte
@@ -1313,10 +1317,10 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                 unit_val = val;
             }
         }
-        if constexpr (C::EPI == EPI_RAW_STATS && C::G > 1) {
+        if constexpr (C::EPI == EPI_RAW_STATS && C::G > 1 && LPR == 1 && ROWS <= C::NTH && C::NB == 1) {
             // the same statistics once more as ONE unit per (workgroup, channel): the G patches' units combined in patch order
             // by the parallel-variance formula, in double (a.wgstats; the per-patch units above stay what the finalize launch reads)
-            static_assert(LPR == 1 && ROWS <= C::NTH && C::NB == 1, "one thread per (patch, channel) row, one pass");
+            // (tilings with one thread per (patch, channel) row and one pass: the conv5 forward kernel of train_cfg.h)
             if (a.wgstats) {
                 __syncthreads();                                           // s_o has been read: the LDS is free
                 float2* s_u = reinterpret_cast<float2*>(smem);
@@ -1341,12 +1345,12 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
             if (take_ticket(cnt + (size_t)kFinLine * (1 + grp), min((unsigned int)kFinGroup, nwg - grp * kFinGroup), s_flag)) {
                 // this workgroup completed its group: the group's units (G per workgroup) -> one record per channel
                 const float2* part = reinterpret_cast<const float2*>(sp);
-                const int units = a.n * C::NB, upw = C::G * C::NB;         // units per workgroup
-                const int u0 = (int)grp * kFinGroup * upw;
+                const int units = a.n * C::NB;                             // one unit per workgroup: unit index = blockIdx.x
+                const int u0 = (int)grp * kFinGroup;
                 double* grec = a.fin.grp + ((size_t)tower * groups + grp) * kFinRec * 2;
                 const double per_unit = a.fin.count / units;
                 // (a group of kFinGroup workgroups holds kFinGroup * upw units: reduced in slices of kFinGroup units when upw > 1)
-                static_assert(C::G * C::NB == 1, "in-kernel finalize: one unit per workgroup");
+                static_assert(C::G == 1, "in-kernel finalize: one unit per workgroup");
                 if constexpr (C::EPI == EPI_RAW_STATS) bn_grp_forward<C::COUT>(part, u0, min(kFinGroup, units - u0), per_unit, grec);
                 else bn_grp_backward<C::COUT>(part, u0, min(kFinGroup, units - u0), grec);
                 if (take_ticket(cnt, groups, s_flag)) {

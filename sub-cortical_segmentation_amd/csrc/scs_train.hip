@@ -220,8 +220,8 @@ static int train_ensure(scs_ctx* h, int n) {
                  o_dcat = take(c * kFC1), o_dfeat = take(c * kFlat), o_lr = take(c), o_ld = take(64),
                  o_sp = take((size_t)kTowers * c * 8 * 64 * 2),     // up to 8 bands x 64 channels x 2 sums
                  o_l1 = take((size_t)kTowers * c * kL1Bands * 200), o_mp = take((size_t)kTowers * std::max<size_t>(256, (c + kMomentPpb - 1) / kMomentPpb) * 128),
-                 o_fc = take(kTowers * fin_counter_words(c)),                 // one workgroup per patch in the FIN configurations
-                 o_fg = take(kTowers * fin_groups(c) * kFinRec * 2 * 2),      // group records (doubles)
+                 o_fc = take(kTowers * fin_counter_words(2 * c)),             // up to two workgroups per patch in the FIN configurations (banded tilings)
+                 o_fg = take(kTowers * fin_groups(2 * c) * kFinRec * 2 * 2),  // group records (doubles)
                  o_cc = take((size_t)kChainCounterWords),
                  o_c5u = take((size_t)kTowers * ((c + 3) / 4) * 120);
     SCS_HIP(hipMalloc(&w->base, off * sizeof(float)));
@@ -996,6 +996,7 @@ static int set_train_attrs(TrainWs* w, int device) {
     SCS_HIP(conv_set_attr<DG5>()); SCS_HIP(conv_set_attr<DG4>()); SCS_HIP(conv_set_attr<DG3>()); SCS_HIP(conv_set_attr<DG2>());
     SCS_HIP(conv_set_attr<TF3N>()); SCS_HIP(conv_set_attr<TF4N>()); SCS_HIP(conv_set_attr<DG5N>()); SCS_HIP(conv_set_attr<DG4N>());
     SCS_HIP(conv_set_attr<DG3N>());
+    SCS_HIP(conv_set_attr<TF3B>()); SCS_HIP(conv_set_attr<TF4B>()); SCS_HIP(conv_set_attr<DG4B>()); SCS_HIP(conv_set_attr<DG3B>());
     SCS_HIP(wgrad_set_attr<WG2>()); SCS_HIP(wgrad_set_attr<WG3>()); SCS_HIP(wgrad_set_attr<WG4>()); SCS_HIP(wgrad_set_attr<WG5>());
     SCS_HIP(conv5_backward_set_attr());
     SCS_HIP(dense_chain_set_attr());
@@ -1058,6 +1059,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // batch-norm finalize inside the producing conv kernel up to kFinMaxBatch, as a launch of its own beyond (train_cfg.h);
     // option fin_max_batch overrides the bound (tests run both forms at one batch size)
     const bool fin_in_kernel = n <= (opt.fin_max_batch >= 0 ? opt.fin_max_batch : kFinMaxBatch);
+    // banded tilings of the middle layers (train_cfg.h: two workgroups per patch-tower) at small batches; they carry the in-kernel finalize
+    const bool split = fin_in_kernel && n <= (opt.split_max_batch >= 0 ? opt.split_max_batch : kSplitMaxBatch);
     hipStream_t sd = one_stream ? st : w->side;
     // The tail of the step.  The conv2 weight gradient - the last big kernel, which cannot start before the conv2 data gradient ends -
     // follows that kernel on the CALLER's stream (in order: no cross-stream wait on the critical path) with its reduction behind
@@ -1087,7 +1090,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // ---- prep: operand packs (unfolded), transposed dense weights, atlas columns + batch labels, dropout masks
     const int units1 = moment_units(n), ppb = moment_ppb(n);
     if (w->tickets_dirty) {                     // a launch of the previous step failed in mid-flight: re-arm the arrival tickets
-        SCS_HIP(hipMemsetAsync(w->fin_counter, 0, kTowers * fin_counter_words((size_t)w->cap) * sizeof(unsigned int), st));
+        SCS_HIP(hipMemsetAsync(w->fin_counter, 0, kTowers * fin_counter_words((size_t)2 * w->cap) * sizeof(unsigned int), st));
         w->tickets_dirty = false;
     }
     const uint8_t* masks = masks_dev ? masks_dev : w->masks;
@@ -1148,6 +1151,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // applies them while it stages its first A operand, its last stage leaves the (d beta, d gamma) column sums and the conv5
     // backward launch turns them into its coefficients.  Needs both one-launch forms; option tail_fused = 0 restores the launches.
     const bool tail = chain && c5_fused && opt.tail_fused != 0;
+    static_assert(TF5::G > 1 && TF5::G * TF5::COUT <= TF5::NTH && TF5::G * TF5::COUT * 2 > TF5::NTH && TF5::NB == 1,
+                  "tail_fused reads the per-workgroup statistics units of the conv5 forward kernel (conv_mfma.h: a.wgstats)");
 
     constexpr int kStatBands[kConvs] = {1, TF12::NB, TF3::NB, TF4::NB, TF5::NB};
     for (int i = 1; i < kConvs; ++i) {
@@ -1170,8 +1175,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         }
         const bool kFwdFin[kConvs] = {false, TF12::FIN != 0, TF3::FIN != 0 && fin_in_kernel, TF4::FIN != 0 && fin_in_kernel, TF5::FIN != 0};
         if (i == 1) run(ST_CONV12, st, [&] { conv_launch<TF12>(a, st); });
-        else if (i == 2) run(ST_CONV3, st, [&] { if (fin_in_kernel) conv_launch<TF3>(a, st); else conv_launch<TF3N>(a, st); });
-        else if (i == 3) run(ST_CONV4, st, [&] { if (fin_in_kernel) conv_launch<TF4>(a, st); else conv_launch<TF4N>(a, st); });
+        else if (i == 2) run(ST_CONV3, st, [&] { if (split) conv_launch<TF3B>(a, st); else if (fin_in_kernel) conv_launch<TF3>(a, st); else conv_launch<TF3N>(a, st); });
+        else if (i == 3) run(ST_CONV4, st, [&] { if (split) conv_launch<TF4B>(a, st); else if (fin_in_kernel) conv_launch<TF4>(a, st); else conv_launch<TF4N>(a, st); });
         else run(ST_CONV5, st, [&] { conv_launch<TF5>(a, st); });
         const int units = n * kStatBands[i];
         if (kFwdFin[i]) {
@@ -1396,8 +1401,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             }
         }
         if (i == 4) run(ST_DG5, st, [&] { if (fin_in_kernel) conv_launch<DG5>(a, st); else conv_launch<DG5N>(a, st); });
-        else if (i == 3) run(ST_DG4, st, [&] { if (fin_in_kernel) conv_launch<DG4>(a, st); else conv_launch<DG4N>(a, st); });
-        else if (i == 2) run(ST_DG3, st, [&] { if (fin_in_kernel) conv_launch<DG3>(a, st); else conv_launch<DG3N>(a, st); });
+        else if (i == 3) run(ST_DG4, st, [&] { if (split) conv_launch<DG4B>(a, st); else if (fin_in_kernel) conv_launch<DG4>(a, st); else conv_launch<DG4N>(a, st); });
+        else if (i == 2) run(ST_DG3, st, [&] { if (split) conv_launch<DG3B>(a, st); else if (fin_in_kernel) conv_launch<DG3>(a, st); else conv_launch<DG3N>(a, st); });
         else run(ST_DG2, st, [&] { conv_launch<DG2>(a, st); });
         // weight gradient of this layer on the side stream (it reads the d z the kernel above stored)
         fork();

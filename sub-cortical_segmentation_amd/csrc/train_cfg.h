@@ -29,6 +29,16 @@ using TF4N = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 144, 1, 4, 0, 4, 0>;
 using DG5N = ConvCfg<60, 40, 7, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 49, 1, 4, 0, 4, 0>;
 using DG4N = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 208, 1, 3, 0, 4, 0>;
 using DG3N = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 256, 1, 3, 0, 4, 0>;
+// Two workgroups per patch-tower (row bands) for the four one-generation kernels of the middle layers at SMALL batches: at batch
+// 128 the unbanded tilings launch 384 workgroups on 256 CUs - half the machine runs a full-length latency chain twice, the other
+// half once - the banded ones 768 of half the work (tools/tbench.hip "band", same GPU, batch 128: conv3 fwd 27.6 -> 25.1 us, conv4
+// fwd 30.6 -> 26.1, conv4 dgrad 40.0 -> 34.6, conv3 dgrad 34.6 -> 31.0; no gain at 160, 20 % SLOWER at 256: two generations).
+// Taken up to kSplitMaxBatch (option split_max_batch) together with the in-kernel finalize.
+using TF3B = ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 112, 2, 3, 0, 4, 1>;
+using TF4B = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 100, 2, 4, 0, 4, 1>;
+using DG4B = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 112, 2, 3, 0, 4, 1>;
+using DG3B = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 144, 2, 3, 0, 4, 1>;
+constexpr int kSplitMaxBatch = 128;
 constexpr int kFinMaxBatch = 512;
 // conv1's statistics (from the input moments) finalized inside the prep + moments launch up to this batch, by bn1_final_kernel beyond
 constexpr int kBn1FusedMaxBatch = 512;

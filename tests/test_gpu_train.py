@@ -380,7 +380,7 @@ def _step_against_gate_aware_oracle(handle, weights, n, draw, stale_rows=True):
     return worst, {k: v for k, v in dbg['forced'].items() if v[0]}
 
 
-@pytest.mark.parametrize('n', [1, 5, 37, 255, 256, 257])
+@pytest.mark.parametrize('n', [1, 5, 37, 128, 129, 255, 256, 257])
 def test_training_step_at_ragged_batch_sizes(fresh, weights, n):
     """scs_train_step against the oracle at batch sizes that are not multiples of anything the kernels tile by (n = 256 is
     BASELINE configs[2]): slice partition of the weight-gradient kernels, patch groups of the moment / data-gradient
@@ -704,7 +704,7 @@ def test_conv5_batch_norm_inside_the_dense_head_against_its_own_launches(weights
     last stage leaves the (d beta, d gamma) column sums and the conv5 backward launch turns them into its coefficients.  Against
     the launches (option tail_fused = 0), same draws and dropout seeds, three steps with Adam: losses to 1e-5, every gradient
     array to 1e-5 of its scale (the statistics and the two sums are added in a different order, nothing else differs), parameters
-    and BN running statistics to 1e-4; and the fused form is deterministic."""
+    and BN running statistics to what three Adam steps can move them apart by; and the fused form is deterministic."""
     from cnn_cort import synth, _hip
     out = {}
     for form in ('launches', 'fused', 'fused again'):
@@ -732,7 +732,9 @@ def test_conv5_batch_norm_inside_the_dense_head_against_its_own_launches(weights
             assert np.array_equal(out['fused'][2][name][i], out['fused again'][2][name][i]), name
             # (n = 1: nine values per channel in the conv5 block's batch norm - inv_std up to 100 amplifies float32 rounding; parameters
             # after three Adam steps: a noise-level gradient may change sign)
-            for which, tol in ((1, 1e-5 if n > 1 else 1e-3), (2, 1e-4 if n > 1 else 1e-2)):
+            # (an Adam step moves an entry by ~lr whatever the size of its gradient: an entry whose gradient is at rounding level may go
+            # the other way - the parameters are only held to what three steps can move them apart by)
+            for which, tol in ((1, 1e-5 if n > 1 else 1e-3), (2, 1e-2)):
                 ref, got = out['launches'][which][name][i], out['fused'][which][name][i]
                 err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
                 if which == 1:
@@ -740,3 +742,41 @@ def test_conv5_batch_norm_inside_the_dense_head_against_its_own_launches(weights
                 assert err <= tol, '%s[%d] (%s): %g of scale' % (name, i, 'gradient' if which == 1 else 'parameters', err)
     assert np.abs(out['fused'][0] - out['launches'][0]).max() <= 1e-5 * max(1.0, np.abs(out['launches'][0]).max())
     print('n = %d: conv5 batch norm inside the head vs its own launches, worst relative gradient difference %.3g' % (n, worst))
+
+
+@pytest.mark.parametrize('n', [1, 5, 37, 127, 128])
+def test_banded_tilings_of_the_middle_layers_against_the_whole_patch_tilings(weights, n):
+    """Up to batch 128 conv3 / conv4 forward and their data gradients run as TWO workgroups per patch-tower (row bands: csrc/train_cfg.h
+    TF3B / TF4B / DG4B / DG3B), beyond as one.  Same arithmetic per output; the batch statistics and BN-backward sums are
+    formed from twice as many units: three steps through both (option split_max_batch = 0: whole patches) agree to 1e-5 of each
+    gradient's scale, block outputs and d z planes are complete (a band that forgot its halo rows would leave stale values
+    that the weight gradients read), and the banded form is deterministic."""
+    from cnn_cort import synth, _hip
+    out = {}
+    for form in ('whole', 'bands', 'bands again'):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        h.set_option('split_max_batch', 0 if form == 'whole' else 128)
+        st = torch.cuda.current_stream().cuda_stream
+        losses, grads = [], None
+        for step in range(3):
+            ax, co, sa, at = synth.patch_batch(n, seed=4100 + n + step)
+            y = np.random.RandomState(n + step).randint(0, 15, n).astype(np.uint8)
+            losses.append(h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=81 + step, stream=st))
+            if step == 2:
+                grads = P.flat_to_params(arena(h, 'grad'))
+            h.adam_apply(stream=st)
+        torch.cuda.synchronize()
+        out[form] = (np.array(losses), grads)
+        h.close()
+    assert np.array_equal(out['bands'][0], out['bands again'][0])
+    worst = 0.0
+    for name, shapes in P.LAYER_SPEC:
+        for i, _ in enumerate(shapes):
+            assert np.array_equal(out['bands'][1][name][i], out['bands again'][1][name][i]), name
+            ref, got = out['whole'][1][name][i], out['bands'][1][name][i]
+            err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
+            worst = max(worst, err)
+            assert err <= (2e-5 if n > 1 else 1e-2), '%s[%d]: %g of scale' % (name, i, err)
+    assert np.abs(out['bands'][0] - out['whole'][0]).max() <= 1e-5 * max(1.0, np.abs(out['whole'][0]).max())
+    print('n = %d: banded vs whole-patch tilings, worst relative gradient difference after three steps %.3g' % (n, worst))

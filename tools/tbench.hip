@@ -291,6 +291,23 @@ int main(int argc, char** argv) {
         run_conv<TF4>("TF4 (shipped)", n, rounds, c4);
         run_conv<TF5>("TF5 (shipped)", n, rounds, c5);
     }
+    if (!strcmp(what, "band")) {
+        // two workgroups per patch-tower (row bands) against one: data-gradient kernels whose staging already takes bands
+        run_conv<DG4>("DG4 (shipped)", n, rounds, c4);
+        run_conv<ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 112, 2, 4, 0, 4, 1>>("DG4 2 bands, fin, WPS4", n, rounds, c4);
+        run_conv<ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 112, 2, 3, 0, 4, 1>>("DG4 2 bands, fin, WPS3", n, rounds, c4);
+        run_conv<TF3>("TF3 (shipped)", n, rounds, c3);
+        run_conv<ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 112, 2, 4, 0, 4, 1>>("TF3 2 bands, fin, WPS4", n, rounds, c3);
+        run_conv<ConvCfg<20, 40, 14, 1, EPI_RAW_STATS, SRC_BN_POOL, 112, 2, 3, 0, 4, 1>>("TF3 2 bands, fin, WPS3", n, rounds, c3);
+        run_conv<TF4>("TF4 (shipped)", n, rounds, c4);
+        run_conv<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 84, 2, 4, 0, 4, 1>>("TF4 2 bands, fin, WPS4", n, rounds, c4);
+        run_conv<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 84, 2, 3, 0, 4, 1>>("TF4 2 bands, fin, WPS3", n, rounds, c4);
+        run_conv<ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 100, 2, 4, 0, 4, 1>>("TF4 2 bands, PLANE 100", n, rounds, c4);
+        run_conv<DG3>("DG3 (shipped)", n, rounds, c3);
+        run_conv<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 144, 2, 4, 0, 4, 1>>("DG3 2 bands, fin, WPS4", n, rounds, c3);
+        run_conv<ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 144, 2, 3, 0, 4, 1>>("DG3 2 bands, fin, WPS3", n, rounds, c3);
+        return 0;
+    }
     if (all || !strcmp(what, "dg")) {
         run_conv<DG5>("DG5 (shipped)", n, rounds, c5);
         run_conv<DG4>("DG4 (shipped)", n, rounds, c4);

@@ -740,7 +740,7 @@ def test_conv5_batch_norm_inside_the_dense_head_against_its_own_launches(weights
                 if which == 1:
                     worst = max(worst, err)
                 assert err <= tol, '%s[%d] (%s): %g of scale' % (name, i, 'gradient' if which == 1 else 'parameters', err)
-    assert np.abs(out['fused'][0] - out['launches'][0]).max() <= 1e-5 * max(1.0, np.abs(out['launches'][0]).max())
+    assert np.abs(out['fused'][0] - out['launches'][0]).max() <= (1e-5 if n > 1 else 1e-4) * max(1.0, np.abs(out['launches'][0]).max())
     print('n = %d: conv5 batch norm inside the head vs its own launches, worst relative gradient difference %.3g' % (n, worst))
 
 
@@ -778,5 +778,6 @@ def test_banded_tilings_of_the_middle_layers_against_the_whole_patch_tilings(wei
             err = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-6))
             worst = max(worst, err)
             assert err <= (2e-5 if n > 1 else 1e-2), '%s[%d]: %g of scale' % (name, i, err)
-    assert np.abs(out['bands'][0] - out['whole'][0]).max() <= 1e-5 * max(1.0, np.abs(out['whole'][0]).max())
+    # (n = 1: a batch norm over 9 .. 144 values per channel - losses of ~30 after a step or two; held to 1e-4 there)
+    assert np.abs(out['bands'][0] - out['whole'][0]).max() <= (1e-5 if n > 1 else 1e-4) * max(1.0, np.abs(out['whole'][0]).max())
     print('n = %d: banded vs whole-patch tilings, worst relative gradient difference after three steps %.3g' % (n, worst))

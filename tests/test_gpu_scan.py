@@ -202,6 +202,31 @@ def test_shared_tower_evaluation_gives_the_bits_of_the_patch_path(weights, case)
         net.predict_volume(vol, centers, atlas4d=np.zeros(vol.shape + (15,), np.float32), towers='shared')
 
 
+def test_shared_tower_entry_refuses_a_centre_outside_its_box(handle):
+    """scs_forward_volume_shared through the C ABI with a box that does not contain every centre: the tile maps cover the box only,
+    so the call counts such centres on the device and fails with SCS_ERR_ARG instead of returning stale rows (include/scs.h);
+    the same call with the right box succeeds."""
+    import torch
+    from cnn_cort import _hip
+    vol, centers, atlas = _roi_case('blob')
+    n = len(centers)
+    d_vol = torch.from_numpy(vol).cuda()
+    d_cen = torch.from_numpy(np.ascontiguousarray(centers, dtype=np.int32)).cuda()
+    d_atl = torch.from_numpy(atlas).cuda()
+    d_lab = torch.full((n,), -7, dtype=torch.int32, device='cuda:0')
+    lo, hi = centers.min(0), centers.max(0)
+    box = (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+    st = torch.cuda.current_stream().cuda_stream
+    handle.forward_volume_shared(d_vol, vol.shape, d_cen, d_atl, n, box, None, d_lab, st)
+    good = d_lab.cpu().numpy().copy()
+    assert (good >= 0).all()
+    for short in ((lo[0] + 1, hi[0], lo[1], hi[1], lo[2], hi[2]), (lo[0], hi[0], lo[1], hi[1] - 2, lo[2], hi[2]), (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2] - 1)):
+        with pytest.raises(_hip.ScsError, match='outside the box'):
+            handle.forward_volume_shared(d_vol, vol.shape, d_cen, d_atl, n, short, None, d_lab, st)
+    handle.forward_volume_shared(d_vol, vol.shape, d_cen, d_atl, n, box, None, d_lab, st)      # the handle is fine afterwards
+    assert np.array_equal(d_lab.cpu().numpy(), good)
+
+
 @pytest.mark.parametrize('shape,iters', [((23, 17, 31), 1), ((40, 44, 36), 10), ((9, 64, 5), 3), ((33, 20, 18), 0)])
 def test_gpu_dilation_equals_scipy(shape, iters):
     """Net.dilate_mask == scipy.ndimage.binary_dilation(mask, iterations) bit for bit (6-neighbour cross, border 0), on

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Everything profiles/ of a round is made from, in ONE gpurun call on one MI355X:  bash tools/profile_round.sh r03
+# Everything profiles/ of a round is made from, in ONE gpurun call on one MI355X:  bash tools/profile_round.sh r04
 #   bench lines (default = forward + train_step block, train, volume, cohort in three forms), test_scan per stage, rocprofv3 kernel traces of the forward and of the
 #   training run (per-kernel statistics, a one-step launch timeline), and the HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in
 #   separate runs, no trace domains beside them).  Results land in gpurun_out/; tools/pmc_traffic.py then writes
 #   profiles/traffic.json against gpurun_out/csrc_sha16.txt.
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -23,18 +23,18 @@ echo "== test_scan, one subject, per stage"
 timeout -k 10 300 python3 tools/scan_cpu_profile.py 2>&1 | grep -v amdgpu.ids > $OUT/${R}_scan_cpu_profile.txt || exit 1
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel trace forward"
-timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/prof_fwd -- python3 $ROOT/bench.py --no-cpu --no-train-block --steps 10 --warmup 2 > $OUT/prof_fwd.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/prof_fwd -- python3 $ROOT/bench.py --no-cpu --no-train-block --no-sustained --no-dice --steps 10 --warmup 2 > $OUT/prof_fwd.log 2>&1 || exit 1
 python3 $ROOT/tools/rocpd_stats.py $(find $OUT/prof_fwd -name "*.db" | head -1) > $OUT/${R}_forward_kernel_stats.csv || exit 1
 echo "== kernel trace train"
-timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/prof_trn -- python3 $ROOT/bench.py --mode train --no-cpu --steps 60 --warmup 10 > $OUT/prof_trn.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace -d $OUT/prof_trn -- python3 $ROOT/bench.py --mode train --no-cpu --no-sustained --steps 60 --warmup 10 > $OUT/prof_trn.log 2>&1 || exit 1
 DB=$(find $OUT/prof_trn -name "*.db" | head -1)
 python3 $ROOT/tools/rocpd_stats.py $DB > $OUT/${R}_train_kernel_stats.csv || exit 1
 python3 $ROOT/tools/rocpd_timeline.py $DB > $OUT/${R}_train_timeline.txt || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $c forward"
-  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_fwd_$c -- python3 $ROOT/bench.py --no-cpu --no-train-block --steps 3 --warmup 1 > $OUT/pmc_fwd_$c.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_fwd_$c -- python3 $ROOT/bench.py --no-cpu --no-train-block --no-sustained --no-dice --steps 3 --warmup 1 > $OUT/pmc_fwd_$c.log 2>&1 || exit 1
   echo "== pmc $c train"
-  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_trn_$c -- python3 $ROOT/bench.py --mode train --no-cpu --steps 20 --warmup 5 > $OUT/pmc_trn_$c.log 2>&1 || exit 1
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_trn_$c -- python3 $ROOT/bench.py --mode train --no-cpu --no-sustained --steps 20 --warmup 5 > $OUT/pmc_trn_$c.log 2>&1 || exit 1
 done
 mkdir -p $OUT/pmc_fwd_csv $OUT/pmc_trn_csv
 i=0; for f in $(find $OUT/pmc_fwd_FETCH_SIZE $OUT/pmc_fwd_WRITE_SIZE -name "*counter_collection.csv"); do cp $f $OUT/pmc_fwd_csv/$i.csv; i=$((i+1)); done

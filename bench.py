@@ -651,19 +651,25 @@ def main():
         ms, launches = h.forward_profiled(ax, co, sa, at, B, probs, labels, st)
         ms2, _ = h.forward_profiled(ax, co, sa, at, B, probs, labels, st)
         ms = 0.5 * (ms + ms2)                                             # average launch duration over both passes
+        names, macs = list(STAGE_NAMES), list(STAGE_MACS)
+        if ms[2] < 0.1 * ms[1] and ms[3] < 0.1 * ms[1]:
+            # conv3 -> conv4 + pool2 -> conv5 ran as ONE kernel per patch-tower (csrc/conv_fused.h: the profiled forward books it
+            # under the first of the three stages): one stage with the three layers' work
+            names[1], macs[1] = 'conv3+conv4+pool2+conv5 (one kernel)', STAGE_MACS[1] + STAGE_MACS[2] + STAGE_MACS[3]
+            macs[2] = macs[3] = 0
         dom = int(np.argmax(ms))
         per_launch_patches = B / launches
-        flop_launch = 2.0 * STAGE_MACS[dom] * per_launch_patches
+        flop_launch = 2.0 * macs[dom] * per_launch_patches
         ms = ms.astype(np.float64)
         dur = float(ms[dom]) / launches * 1e-3
         achieved = flop_launch / dur / 1e12
-        traffic, note = measured_traffic(STAGE_NAMES[dom]) if B == 100000 else (None, 'measured at the default batch only')
-        out['roofline'] = {'bound': 'mfma', 'kernel': STAGE_NAMES[dom], 'achieved': achieved, 'peak': PEAK_F32_TFLOPS,
+        traffic, note = measured_traffic(names[dom]) if B == 100000 else (None, 'measured at the default batch only')
+        out['roofline'] = {'bound': 'mfma', 'kernel': names[dom], 'achieved': achieved, 'peak': PEAK_F32_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_source': note,
                            'launch_ms': dur * 1e3, 'patches_per_launch': per_launch_patches}
-        out['stages'] = {STAGE_NAMES[i]: {'ms_per_step': float(ms[i]),
-                                          'tflops': float(2.0 * STAGE_MACS[i] * B / (ms[i] * 1e-3) / 1e12) if ms[i] > 0 else None}
-                         for i in range(8)}
+        out['stages'] = {names[i]: {'ms_per_step': float(ms[i]),
+                                    'tflops': float(2.0 * macs[i] * B / (ms[i] * 1e-3) / 1e12) if ms[i] > 1e-3 else None}
+                         for i in range(8) if macs[i] > 0}
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
     if args.mode == 'train' and rank == 0:
         for k in ('roofline', 'stages', 'launches_per_step', 'sum_of_launch_ms', 'train_step_ms', 'allreduce_ms', 'adam_ms',

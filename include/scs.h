@@ -83,6 +83,9 @@ int scs_set_chunk(scs_handle h, int patches_per_chunk);
  *   "c5_fused_max_batch"     SCS_C5_FUSED_MAX_BATCH     the conv5 block's backward as one launch up to this batch
  *   "tail_fused"             SCS_TAIL_FUSED             0: bn5 / bn5-backward as launches of their own (the round-3 step)
  *   "split_max_batch"        SCS_SPLIT_MAX_BATCH        channel-split conv tilings (two workgroups per patch-tower) up to this batch
+ *   "fwd_fused"              SCS_FWD_FUSED              inference: 1 = conv3 -> conv4 + pool2 -> conv5 as ONE kernel per patch-tower (the activations
+ *                                                       between them stay in LDS: 113 instead of 280 KB of HBM traffic per patch, same bits, 20 %
+ *                                                       slower), 2 = that kernel also storing them (scs_get_activation); default 0: three launches
  *   "train_one_stream"       SCS_TRAIN_ONE_STREAM       1: every launch in order on the caller's stream
  *   "tail_side"              SCS_TAIL_SIDE              1: the round-2 stream order of the step's last launches
  *   "wg_slices_conv2".."wg_slices_conv5"  SCS_WG_SLICES="b,c,d,e"  batch slices of the weight-gradient kernels (0 = default)

@@ -23,7 +23,7 @@
 #include "gemm_mfma.h"
 #include "scs_ctx.h"
 #include "dense_eval.h"
-#include "dense_eval.h"
+#include "conv_fused.h"
 
 namespace scs {
 
@@ -452,6 +452,24 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
         conv_launch<CfgConv12>(a, st);
     }
     mark(1);
+    if (h->opt.fwd_fused > 0) {
+        // conv3 -> conv4 + pool2 -> conv5 as ONE kernel per patch-tower (conv_fused.h): the two activations in between stay in LDS;
+        // same bits as the three launches below.  An OPTION (fwd_fused = 1), not the default: it cuts the net's HBM traffic from
+        // ~280 to ~113 KB per patch but streams every layer's weights through LDS once per patch-tower and runs 20 % slower than
+        // the three launches (profiles/NOTES_r04.md).  The profiled forward books the whole kernel under conv3.
+        FusedArgs f{};
+        f.n = n;
+        for (int t = 0; t < kTowers; ++t) {
+            f.in[t] = h->a_pool1[t]; f.out[t] = h->a_conv5[t];
+            for (int l = 0; l < 3; ++l) { f.w[t][l] = pk.convw[t][2 + l]; f.bias[t][l] = pk.convb[t][2 + l]; }
+            f.dbg3[t] = h->opt.fwd_fused == 2 ? h->a_conv3[t] : nullptr;
+            f.dbg4[t] = h->opt.fwd_fused == 2 ? h->a_pool2[t] : nullptr;
+        }
+        conv345_fused_launch(f, st);
+        mark(2); mark(3); mark(4);
+        const float* c5f[kTowers] = {h->a_conv5[0], h->a_conv5[1], h->a_conv5[2]};
+        return forward_head(h, c5f, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, x0 ? x0->n_samples : n, atlas_index);
+    }
     // conv3
     for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_pool1[t]; a.w[t] = pk.convw[t][2]; a.bias[t] = pk.convb[t][2]; a.out[t] = h->a_conv3[t]; }
     conv_launch<CfgConv3>(a, st);
@@ -574,6 +592,7 @@ static int set_kernel_attrs() {
     SCS_HIP(conv_set_attr<CfgConv3>());
     SCS_HIP(conv_set_attr<CfgConv4>());
     SCS_HIP(conv_set_attr<CfgConv5>());
+    SCS_HIP(conv345_fused_set_attr());
     SCS_HIP(conv_set_attr<CfgConv4NP>());
     SCS_HIP(gemm_set_attrs());
     return SCS_OK;
@@ -611,6 +630,7 @@ int scs_create(int device, scs_handle* out) {
         o.tail_side = getenv("SCS_TAIL_SIDE") != nullptr;
         o.tail_fused = env_int("SCS_TAIL_FUSED", -1);
         o.split_max_batch = env_int("SCS_SPLIT_MAX_BATCH", -1);
+        o.fwd_fused = env_int("SCS_FWD_FUSED", -1);
         if (const char* e = getenv("SCS_WG_SLICES")) {
             int x[4];
             if (sscanf(e, "%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3]) == 4)
@@ -689,6 +709,7 @@ static int* option_slot(scs_ctx* h, const char* name) {
         {"dense_chain_max_batch", &o.dense_chain_max_batch}, {"c5_fused_max_batch", &o.c5_fused_max_batch},
         {"train_one_stream", &o.train_one_stream}, {"tail_side", &o.tail_side}, {"tail_fused", &o.tail_fused},
         {"split_max_batch", &o.split_max_batch},
+        {"fwd_fused", &o.fwd_fused},
         {"wg_slices_conv2", &o.wg_slices[0]}, {"wg_slices_conv3", &o.wg_slices[1]}, {"wg_slices_conv4", &o.wg_slices[2]},
         {"wg_slices_conv5", &o.wg_slices[3]}};
     for (auto& t : tab) if (strcmp(t.n, name) == 0) return t.p;
@@ -955,9 +976,13 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
     size_t per = 0;
     float* const* tow = nullptr;
     const float* single = nullptr;
+    if ((which == 1 || which == 2) && h->opt.fwd_fused == 1) {
+        set_error("activations 1 / 2 stay in LDS in the fused forward: set option fwd_fused to 0 or 2 before the forward call");
+        return SCS_ERR_STATE;
+    }
     switch (which) {
         case 0: per = 20 * 196; tow = h->a_pool1; break;
-        case 1: per = 40 * 144; tow = h->a_conv3; break;
+        case 1: per = 40 * 144; tow = h->a_conv3; break;     // (1, 2: written only by the three-launch path or with option fwd_fused = 2)
         case 2: per = 40 * 25; tow = h->a_pool2; break;
         case 3: per = kFlat; tow = h->a_conv5; break;
         case 4: per = kFlat; single = h->a_feat; break;

@@ -92,6 +92,33 @@ def test_per_layer_activations(handle, weights):
     close(logits[:, :15], tr['logits'], 'logits')
 
 
+@pytest.mark.parametrize('name', ['g1_random.npz', 'g2_volume.npz', 'g3_classes.npz', 'g4_ties.npz'])
+def test_fused_conv3_to_conv5_kernel_gives_the_bits_of_the_three_launches(handle, name):
+    """conv3 -> conv4 + pool2 -> conv5 as one kernel per patch-tower (csrc/conv_fused.h, option fwd_fused = 1: the two
+    activations in between never leave LDS) against the three launches (the default): the same MFMA sequences per output, so
+    probabilities, labels, logits and the block-5 activations are equal bit for bit - and the debug form (fwd_fused = 2) stores
+    the same conv3 / pool2 activations the three launches leave in memory."""
+    g = gold(name)
+    n = g['ax'].shape[0]
+    got = {}
+    for form in (0, 1, 2):
+        handle.set_option('fwd_fused', form)
+        try:
+            probs, labels = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+            acts = {w: handle.get_activation(w, 3 * n * per) for w, per in ((3, 540),) + (((1, 5760), (2, 1000)) if form != 1 else ())}
+            logits = handle.get_activation(7, n * 16)
+            if form == 1:
+                with pytest.raises(Exception):
+                    handle.get_activation(1, 3 * n * 5760)
+        finally:
+            handle.set_option('fwd_fused', -1)
+        got[form] = (probs, labels, logits, acts)
+    for form in (1, 2):
+        assert np.array_equal(got[form][0], got[0][0]) and np.array_equal(got[form][1], got[0][1]) and np.array_equal(got[form][2], got[0][2])
+        assert np.array_equal(got[form][3][3], got[0][3][3])
+    assert np.array_equal(got[2][3][1], got[0][3][1]) and np.array_equal(got[2][3][2], got[0][3][2])
+
+
 @pytest.mark.parametrize('n', [1, 3, 4, 5, 15, 16, 17, 63, 130])
 def test_ragged_batch_sizes(handle, n):
     """Partial patch groups (conv3/4: 4 per workgroup, conv5: 16, GEMM: 128 rows) must not leak or drop rows."""

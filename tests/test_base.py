@@ -462,3 +462,32 @@ def test_unchanged_call_sequence_stays_lazy_and_materialises_to_the_reference_ar
     cs2 = base.compact_from_views({'in1': lazy[0], 'in2': lazy[1], 'in3': lazy[2], 'in4': lazy[3]}, y_edit)
     assert np.array_equal(cs2.y[cs2.index], y_edit)
     assert base.compact_from_views({'in1': ref[0], 'in2': lazy[1], 'in3': lazy[2], 'in4': lazy[3]}, lazy[4]) is None
+
+
+def test_steered_atlas_is_a_deterministic_fifteen_class_prior():
+    """synth.steered_atlas (the prior of the 15-class synthetic subject of the GPU tests and of bench.py's `dice` block): 14 blobs
+    whose rows are the steering vectors of cnn_cort/steer15.json (tools/make_steer.py), the background vector between them, all-zero
+    rows far away (the zero-row -> background rule), a structure map that names the blobs - and the same bytes on every call."""
+    import json
+    from conftest import PKG
+    d = json.load(open(os.path.join(PKG, 'cnn_cort', 'steer15.json')))
+    v = np.asarray(d['vectors'], np.float32)
+    assert v.shape == (15, 15) and np.isfinite(v).all() and min(d['held_out_hit_rate']) > 0.9
+    M = synth.steer_matrix()
+    assert np.array_equal(M[14], v[0]) and np.array_equal(M[:14], v[1:])          # prior channel k steers to class k + 1, channel 14 to background
+    shape = (36, 34, 30)
+    p1, m1 = synth.steered_atlas(shape, seed=5)
+    p2, m2 = synth.steered_atlas(shape, seed=5)
+    assert p1.dtype == np.float32 and p1.shape == shape + (15,) and m1.dtype == np.uint8
+    assert np.array_equal(p1, p2) and np.array_equal(m1, m2)
+    assert set(np.unique(m1)) <= set(range(15)) and len(np.unique(m1)) >= 10        # most blobs own voxels
+    zero = np.abs(p1).sum(-1) == 0
+    assert zero.any() and (m1[zero] == 0).all()                                     # rows far from every blob stay all zero
+    core = m1 > 0
+    k = m1[core].astype(int) - 1
+    # deep inside a blob the row is that blob's vector (the blend weight saturates at 1 well before the centre)
+    rows = p1[core]
+    exact = np.all(rows == M[k], axis=1)
+    assert exact.any()
+    between = (~zero) & (~core)
+    assert between.any() and np.allclose(p1[between][np.abs(p1[between] - M[14]).sum(-1) < 1e-6], M[14])

@@ -102,3 +102,18 @@ def test_single_process_degrades_to_noops():
     t = torch.ones(4)
     assert dist.allreduce_flat(t, 1) == 1.0 and dist.mean_scalar(3.0, 2) == 3.0
     dist.barrier()
+
+
+def test_bucket_switch_and_head_bucket_layout(monkeypatch):
+    """SCS_DP_BUCKETS is read at every exchange (1 unless it says 2), and the dense head's bucket a rank WITHOUT a step of its own
+    exchanges (dist.handle_head_bucket) is the arena's tail from FC1.W on - what scs_wait_head_grads reports to the active ranks."""
+    from cnn_cort import dist, params as P
+    monkeypatch.delenv('SCS_DP_BUCKETS', raising=False)
+    assert dist.dp_buckets() == 1
+    for val, want in (('2', 2), ('1', 1), ('3', 1), ('x', 1)):
+        monkeypatch.setenv('SCS_DP_BUCKETS', val)
+        assert dist.dp_buckets() == want
+    first, count = dist.handle_head_bucket(P.N_STORED)
+    assert first == P.flat_offsets()[('FC1', 0)][0] == 436320 and first + count == P.N_STORED
+    names = [n for n, _ in P.LAYER_SPEC]
+    assert names.index('FC1') > max(names.index('%s_prelu_d1' % t) for t in P.TOWERS)       # everything of the towers lies in front of it

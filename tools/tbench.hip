@@ -291,6 +291,16 @@ int main(int argc, char** argv) {
         run_conv<TF4>("TF4 (shipped)", n, rounds, c4);
         run_conv<TF5>("TF5 (shipped)", n, rounds, c5);
     }
+    if (!strcmp(what, "dg2")) {
+        // the dominant kernel of the step (conv2 data gradient + layer-1 sums): three bands of 10 rows against the shipped five of 6
+        run_conv<DG2>("DG2 (shipped: 5 bands, WPS4)", n, rounds, c2);
+        run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 384, 3, 3>>("DG2 3 bands, PLANE 384, WPS3", n, rounds, c2);
+        run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 400, 3, 3>>("DG2 3 bands, PLANE 400, WPS3", n, rounds, c2);
+        run_conv<DG2>("DG2 (shipped: 5 bands, WPS4)", n, rounds, c2);
+        run_conv<ConvCfg<20, 20, 32, 1, EPI_L1, SRC_DZ_POOL_PAD2, 384, 3, 3>>("DG2 3 bands, PLANE 384, WPS3", n, rounds, c2);
+        run_conv<TF12>("TF12 (shipped: 7 bands, WPS4)", n, rounds, c1 + c2);
+        return 0;
+    }
     if (!strcmp(what, "band")) {
         // two workgroups per patch-tower (row bands) against one: data-gradient kernels whose staging already takes bands
         run_conv<DG4>("DG4 (shipped)", n, rounds, c4);

@@ -936,6 +936,18 @@ __global__ __launch_bounds__(256) void wgrad_final_kernel(WgFinalArgs a) {
     if (e < tot) {
         const float* __restrict__ base = J.part + (size_t)t * J.nsplit * tot + e;
         int sp = sp0;
+#ifndef SCS_WGFIN_BATCH
+#define SCS_WGFIN_BATCH 32
+#endif
+        // (the partials of a thread in flight SCS_WGFIN_BATCH at a time - the launch is a chain of dependent round trips and the last
+        // one of the step; added in the same order whatever the batch: same bits)
+        for (; sp + SCS_WGFIN_BATCH <= sp1; sp += SCS_WGFIN_BATCH) {
+            float r[SCS_WGFIN_BATCH];
+#pragma unroll
+            for (int u = 0; u < SCS_WGFIN_BATCH; ++u) r[u] = base[(size_t)(sp + u) * tot];
+#pragma unroll
+            for (int u = 0; u < SCS_WGFIN_BATCH; ++u) v += r[u];
+        }
         for (; sp + 8 <= sp1; sp += 8) {
             float r[8];
 #pragma unroll

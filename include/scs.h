@@ -86,6 +86,8 @@ int scs_set_chunk(scs_handle h, int patches_per_chunk);
  *   "fwd_fused"              SCS_FWD_FUSED              inference: 1 = conv3 -> conv4 + pool2 -> conv5 as ONE kernel per patch-tower (the activations
  *                                                       between them stay in LDS: 113 instead of 280 KB of HBM traffic per patch, same bits, 20 %
  *                                                       slower), 2 = that kernel also storing them (scs_get_activation); default 0: three launches
+ *   "c5_split"               SCS_C5_SPLIT               largest batch at which the conv5 block's backward is two launches (data path on the caller's
+ *                                                       stream, weight-gradient partial on the side stream); default 128, 0 = always one launch
  *   "wgfin_early"            SCS_WGFIN_EARLY            0: the conv3..5 partial-sum reduction at the end of the side stream (the round-3 order)
  *   "train_one_stream"       SCS_TRAIN_ONE_STREAM       1: every launch in order on the caller's stream
  *   "tail_side"              SCS_TAIL_SIDE              1: the round-2 stream order of the step's last launches

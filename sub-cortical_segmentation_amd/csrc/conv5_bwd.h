@@ -57,7 +57,10 @@ struct C5BArgs {
     int n;
 };
 
-template <bool P5>     // P5: the conv5 block's BN-backward coefficients from the dense head's column sums (a.part5)
+// MODE 0: everything in one launch (round 3).  MODE 1: the data path only (d z, data gradient, col2im, the conv4 block's sums) - what the
+// caller's stream has to wait for; MODE 2: d z and the weight-gradient partial only, launched on the side stream beside the data
+// gradients (the partial store and its GEMM are 6 us of the one-launch form's 27; the side stream is idle at that point).
+template <bool P5, int MODE = 0>     // P5: the conv5 block's BN-backward coefficients from the dense head's column sums (a.part5)
 __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem5[];
     float* s_dz = smem5;                                  // [48][66]
@@ -114,10 +117,10 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
             zv[k] = z5[at]; dv[k] = dh[at]; if constexpr (p5) cv[k] = float4{0.f, 0.f, 0.f, 0.f}; else cv[k] = cf[ok ? o : 0];
         }
 #pragma unroll
-        for (int k = 0; k < X_IT; ++k) { const int e = tid + kC5Threads * k; xv[k] = (e < ng * 250) ? x5[e] : float4{0.f, 0.f, 0.f, 0.f}; }
+        for (int k = 0; k < X_IT; ++k) { const int e = tid + kC5Threads * k; xv[k] = (MODE != 1 && e < ng * 250) ? x5[e] : float4{0.f, 0.f, 0.f, 0.f}; }
         // (with part5 the weights - which only the second GEMM needs - are requested behind the coefficient step: held across its
         // barriers the compiler spilled all 44 registers of them to scratch)
-        if constexpr (!p5) {
+        if constexpr (!p5 && MODE != 2) {
 #pragma unroll
             for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; wv[k] = wc[min(e, kC5WcFloats / 4 - 1)]; }
         }
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
                 for (int q = 0; q < 8; ++q) { sb += s_p5[(q * 60 + tid) * 2]; sg += s_p5[(q * 60 + tid) * 2 + 1]; }
                 const double count = (double)a.n * 9.0, mb = sb / count, mg = sg / count, sc = lo5.x, inv = lo5.w, mean = lo5.z;
                 s_cf[tid] = make_float4(lo5.x, lo5.y, (float)(-sc * inv * mg), (float)(sc * (inv * mean * mg - mb)));
-                if (blockIdx.x == 0) { float* gb = pick3(a.gbn5, tower); gb[tid] = (float)sb; gb[60 + tid] = (float)sg; }
+                if (MODE != 2 && blockIdx.x == 0) { float* gb = pick3(a.gbn5, tower); gb[tid] = (float)sb; gb[60 + tid] = (float)sg; }
             }
             __syncthreads();
 #pragma unroll
@@ -159,7 +162,9 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
         }
 #pragma unroll
         for (int k = 0; k < X_IT; ++k) { const int e = tid + kC5Threads * k; if (e < kC5XFloats / 4) reinterpret_cast<float4*>(s_x)[e] = xv[k]; }
-        if constexpr (!p5) {
+        if constexpr (MODE == 2) {
+            // (the weight-gradient part does not touch the weights)
+        } else if constexpr (!p5) {
 #pragma unroll
             for (int k = 0; k < W_IT; ++k) { const int e = tid + kC5Threads * k; if (e < kC5WcFloats / 4) reinterpret_cast<float4*>(s_w)[e] = wv[k]; }
         } else {
@@ -172,12 +177,12 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
     }
     // (requested behind the staging loads: memory operations retire in order, so in front of them they would hold up the first LDS write)
 #pragma unroll
-    for (int k = 0; k < Z_IT; ++k) { const int e = tid + kC5Threads * k; z4v[k] = (e < ng * 1000) ? z4g[e] : float4{0.f, 0.f, 0.f, 0.f}; }
+    for (int k = 0; k < Z_IT; ++k) { const int e = tid + kC5Threads * k; z4v[k] = (MODE != 2 && e < ng * 1000) ? z4g[e] : float4{0.f, 0.f, 0.f, 0.f}; }
     __syncthreads();
     stamp(1);
 
     // ---- weight-gradient partial: D[j][o] = sum_r Xcol[r][j] dz[r][o]; wave w owns row tiles w, w + 8, w + 16 of the 23
-    {
+    if constexpr (MODE != 1) {
         constexpr int MTW = 3;
         f32x4 acc[MTW][4];
         int offj[MTW];
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
     }
 
     stamp(2);
+    if constexpr (MODE == 2) return;
     // ---- data gradient: Y[r][j] = sum_o dz[r][o] Wc[o][j]; wave w owns column tiles w, w + 8, w + 16 and all row tiles
     {
         constexpr int NTW = 3, MT = kC5Rows / 16;
@@ -337,15 +343,25 @@ __global__ __launch_bounds__(kC5Threads, 1) void conv5_backward_kernel(C5BArgs a
 
 inline int conv5_backward_workgroups(int n) { return (n + kC5G - 1) / kC5G; }
 
+template <bool P5, int MODE>
+inline hipError_t conv5_backward_set_attr_one() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_backward_kernel<P5, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC5LdsBytes);
+}
 inline hipError_t conv5_backward_set_attr() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_backward_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC5LdsBytes);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_backward_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC5LdsBytes);
+    hipError_t e = conv5_backward_set_attr_one<false, 0>();
+    if (e == hipSuccess) e = conv5_backward_set_attr_one<true, 0>();
+    if (e == hipSuccess) e = conv5_backward_set_attr_one<true, 1>();
+    if (e == hipSuccess) e = conv5_backward_set_attr_one<true, 2>();
+    return e;
 }
 
-inline void conv5_backward_launch(const C5BArgs& a, hipStream_t st) {
-    if (a.part5) hipLaunchKernelGGL(conv5_backward_kernel<true>, dim3(conv5_backward_workgroups(a.n), kTowers), dim3(kC5Threads), kC5LdsBytes, st, a);
-    else hipLaunchKernelGGL(conv5_backward_kernel<false>, dim3(conv5_backward_workgroups(a.n), kTowers), dim3(kC5Threads), kC5LdsBytes, st, a);
+// mode 0: one launch; 1 / 2: the data path / the weight-gradient partial as launches of their own (part5 form only)
+inline void conv5_backward_launch(const C5BArgs& a, hipStream_t st, int mode = 0) {
+    const dim3 grid(conv5_backward_workgroups(a.n), kTowers), block(kC5Threads);
+    if (!a.part5) hipLaunchKernelGGL((conv5_backward_kernel<false, 0>), grid, block, kC5LdsBytes, st, a);
+    else if (mode == 1) hipLaunchKernelGGL((conv5_backward_kernel<true, 1>), grid, block, kC5LdsBytes, st, a);
+    else if (mode == 2) hipLaunchKernelGGL((conv5_backward_kernel<true, 2>), grid, block, kC5LdsBytes, st, a);
+    else hipLaunchKernelGGL((conv5_backward_kernel<true, 0>), grid, block, kC5LdsBytes, st, a);
 }
 
 }  // namespace scs

@@ -632,6 +632,7 @@ int scs_create(int device, scs_handle* out) {
         o.split_max_batch = env_int("SCS_SPLIT_MAX_BATCH", -1);
         o.fwd_fused = env_int("SCS_FWD_FUSED", -1);
         o.wgfin_early = env_int("SCS_WGFIN_EARLY", 1);
+        o.c5_split = env_int("SCS_C5_SPLIT", -1);
         if (const char* e = getenv("SCS_WG_SLICES")) {
             int x[4];
             if (sscanf(e, "%d,%d,%d,%d", &x[0], &x[1], &x[2], &x[3]) == 4)
@@ -712,6 +713,7 @@ static int* option_slot(scs_ctx* h, const char* name) {
         {"split_max_batch", &o.split_max_batch},
         {"fwd_fused", &o.fwd_fused},
         {"wgfin_early", &o.wgfin_early},
+        {"c5_split", &o.c5_split},
         {"wg_slices_conv2", &o.wg_slices[0]}, {"wg_slices_conv3", &o.wg_slices[1]}, {"wg_slices_conv4", &o.wg_slices[2]},
         {"wg_slices_conv5", &o.wg_slices[3]}};
     for (auto& t : tab) if (strcmp(t.n, name) == 0) return t.p;

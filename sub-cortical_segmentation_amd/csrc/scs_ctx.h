@@ -16,6 +16,8 @@ struct scs_options {
     int wg_slices[4] = {0, 0, 0, 0}; // SCS_WG_SLICES="b,c,d,e": batch slices of the conv2..5 weight-gradient kernels (0 = default)
     int tail_fused = -1;             // SCS_TAIL_FUSED: bn5 / bn5-backward / bn2 folded into their neighbours (-1 = default on)
     int split_max_batch = -1;        // SCS_SPLIT_MAX_BATCH: channel-split conv tilings up to this batch (-1 = default)
+    int c5_split = -1;               // SCS_C5_SPLIT: largest batch at which the conv5 block's backward is two launches (data path / weight-
+                                     // gradient partial on the side stream); -1 = default (128), 0 = always one launch
     int wgfin_early = 1;             // SCS_WGFIN_EARLY: 0 = the conv3..5 partial-sum reduction at the END of the side stream (the round-3 order)
     int fwd_fused = -1;              // SCS_FWD_FUSED: 1 = inference conv3 -> conv4 + pool2 -> conv5 as one kernel per patch-tower, 2 = that kernel
                                      // storing the two intermediates too (scs_get_activation); default (-1, 0): three launches - they are faster

@@ -40,7 +40,7 @@ namespace scs {
 // profiling stages of scs_train_step_profiled (one per launch)
 enum Stage { ST_PREP, ST_FIN1, ST_CONV12, ST_FIN2, ST_CONV3, ST_FIN3, ST_CONV4, ST_FIN4, ST_CONV5, ST_BN5, ST_D1, ST_FC1,
              ST_FC2, ST_HEAD, ST_DCAT, ST_DFEAT, ST_DH5, ST_BN5B, ST_DG5, ST_FINB4, ST_DG4, ST_FINB3, ST_DG3, ST_FINB2, ST_DG2,
-             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_CHAIN, ST_C5B, ST_ADAM1, ST_ADAM2, ST_ADAM3, ST_COUNT };
+             ST_L1FINAL, ST_WGDENSE, ST_WG5, ST_WG4, ST_WG3, ST_WG2, ST_WGFINAL, ST_WGFINAL2, ST_CHAIN, ST_C5B, ST_ADAM1, ST_ADAM2, ST_ADAM3, ST_C5W, ST_COUNT };
 static const char* const kStageNames[ST_COUNT] = {
     "prep (weight packs, dropout masks, atlas columns) + input moments", "bn1 finalize", "conv1+conv2 fwd", "bn2 finalize",
     "conv3 fwd", "bn3 finalize", "conv4 fwd", "bn4 finalize", "conv5 fwd", "bn5 + dropout", "d1 x3 fwd", "FC1 fwd", "fc_2 fwd",
@@ -48,7 +48,7 @@ static const char* const kStageNames[ST_COUNT] = {
     "bn3 bwd finalize", "conv3 dgrad", "bn2 bwd finalize", "conv2 dgrad + layer-1 sums", "layer-1 gradients", "dense wgrad (grouped)",
     "conv5 wgrad", "conv4 wgrad", "conv3 wgrad", "conv2 wgrad", "conv3..5 wgrad reduce", "conv2 wgrad reduce",
     "dense head, one launch (d1 x3, FC1, fc_2, out + softmax + CE, fc_2 / FC1 / d1 dgrad)",
-    "conv5 backward, one launch (dgrad + wgrad + bn4 bwd sums)", "adam (dense layers, fused)", "adam (bn2..5 scale / shift, fused)", "adam (conv2..5 weights, fused)"};
+    "conv5 backward, one launch (dgrad + wgrad + bn4 bwd sums)", "adam (dense layers, fused)", "adam (bn2..5 scale / shift, fused)", "adam (conv2..5 weights, fused)", "conv5 wgrad partial (side stream)"};
 
 }  // namespace scs
 
@@ -1381,7 +1381,14 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             if (c5_stamps && !w->chain_stamps)
                 SCS_HIP(hipMalloc(&w->chain_stamps, (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps * sizeof(unsigned long long)));
             b.stamps = c5_stamps ? w->chain_stamps : nullptr;
-            run(ST_C5B, st, [&] { conv5_backward_launch(b, st); });
+            // With the head's column sums (tail) the launch splits: the data path on the caller's stream, the weight-gradient partial
+            // - which feeds nothing before the partial-sum reduction - on the side stream behind the dense weight gradients
+            // up to batch kC5SplitMaxBatch (option c5_split: the bound, 0 = never).  Same GPU, two rounds: batch 128 0.3974 / 0.3994 ->
+            // 0.3898 / 0.3907 ms; batch 256 0.5349 / 0.5365 -> 0.5424 / 0.5438 (there the side stream is busy with the dense weight
+            // gradients and the early Adam launch at that point, and the partial launch only takes the data path's CUs)
+            const bool c5_split = tail && n <= (opt.c5_split >= 0 ? opt.c5_split : kC5SplitMaxBatch);
+            run(ST_C5B, st, [&] { conv5_backward_launch(b, st, c5_split ? 1 : 0); });
+            if (c5_split) run(ST_C5W, sd, [&] { conv5_backward_launch(b, sd, 2); });
             if (c5_stamps && (size_t)kTowers * c5_units * 8 <= (size_t)(kChainMaxBatch / 16) * kChainMembers * kChainStamps) {
                 SCS_HIP(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hs((size_t)kTowers * c5_units * 8);

@@ -39,6 +39,7 @@ using TF4B = ConvCfg<40, 40, 12, 1, EPI_RAW_STATS, SRC_BN, 100, 2, 4, 0, 4, 1>;
 using DG4B = ConvCfg<40, 40, 14, 1, EPI_RAW_BNB, SRC_DZ_POOL_PAD2, 112, 2, 3, 0, 4, 1>;
 using DG3B = ConvCfg<40, 20, 16, 1, EPI_RAW_BNB_POOL, SRC_DZ_PAD2, 144, 2, 3, 0, 4, 1>;
 constexpr int kSplitMaxBatch = 128;
+constexpr int kC5SplitMaxBatch = 128;     // conv5 block's backward as two launches (data path / weight-gradient partial on the side stream) up to here
 constexpr int kFinMaxBatch = 512;
 // conv1's statistics (from the input moments) finalized inside the prep + moments launch up to this batch, by bn1_final_kernel beyond
 constexpr int kBn1FusedMaxBatch = 512;

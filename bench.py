@@ -224,7 +224,9 @@ def train_stage_profile(h, inputs, B, st, reps=5):
     traffic, note = measured_traffic('train: ' + dom) if B == 256 else (None, 'measured at batch 256 only')
     roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_F32_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_source': note, 'launch_ms': acc[dom], 'patches_per_launch': B}
-    stages = {k: {'ms': v, 'tflops': (2.0 * macs[k] * B / (v * 1e-3) / 1e12) if k in macs and v > 0 else None}
+    split = acc.get(C5W_STAGE, 0.0) > 0
+    shown = lambda k: 'conv5 backward, data path (dgrad + bn4 bwd sums)' if split and k == C5B_STAGE else k
+    stages = {shown(k): {'ms': v, 'tflops': (2.0 * macs[k] * B / (v * 1e-3) / 1e12) if k in macs and v > 0 else None}
               for k, v in acc.items() if v > 0}
     return roofline, stages, len(stages), float(sum(acc.values()))
 

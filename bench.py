@@ -674,6 +674,15 @@ def main():
         out['roofline'] = {'bound': 'mfma', 'kernel': names[dom], 'achieved': achieved, 'peak': PEAK_F32_TFLOPS,
                            'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS, 'traffic': traffic, 'traffic_source': note,
                            'launch_ms': dur * 1e3, 'patches_per_launch': per_launch_patches}
+        # beside the nominal peak: what this device issues when it does nothing but the MFMA the kernels are built on (live probe)
+        try:
+            issue = h.probe_f32_mfma()
+            out['roofline']['device_mfma_issue_rate'] = {
+                'tflops': issue, 'achieved_frac_of_it': achieved / issue,
+                'what': 'back-to-back v_mfma_f32_16x16x4_f32, independent accumulators, operands in registers, four waves per SIMD on '
+                        'every CU (scs_probe_f32_mfma, three launches of ~4 ms, the last one timed, this process): the nominal peak prices the instruction at 32 cycles of 2.4 GHz'}
+        except Exception as e:                                            # informational: never fails the bench line
+            out['roofline']['device_mfma_issue_rate'] = {'error': str(e)}
         out['stages'] = {names[i]: {'ms_per_step': float(ms[i]),
                                     'tflops': float(2.0 * macs[i] * B / (ms[i] * 1e-3) / 1e12) if ms[i] > 1e-3 else None}
                          for i in range(8) if macs[i] > 0}

@@ -96,6 +96,12 @@ int scs_set_chunk(scs_handle h, int patches_per_chunk);
 int scs_set_option(scs_handle h, const char* name, int64_t value);
 int scs_get_option(scs_handle h, const char* name, int64_t* value);
 
+/* Measurement aid (bench.py): the rate at which THIS device issues back-to-back v_mfma_f32_16x16x4_f32 with independent accumulators
+ * and register operands - four waves per SIMD on every CU, three launches of ~4 ms, the last one timed - as TFLOP/s.  The roofline's 157.3 TFLOP/s prices the instruction
+ * at 32 cycles of a 2.4 GHz clock; what the part sustains under an f32-MFMA load is lower, and this is that figure, measured in the
+ * same process as the kernels it is set beside.  No reference counterpart.  Synchronises the device. */
+int scs_probe_f32_mfma(scs_handle h, double* tflops);
+
 /* Deterministic forward on n patches (device pointers).  probs and/or labels may be NULL.
  * labels[i] = argmax_c probs[i][c] (first maximum), i.e. nolearn's predict = argmax(predict_proba).
  * Replaces: net.predict / net.predict_proba (base.py:425-428, 435-438) - one pass yields both. */

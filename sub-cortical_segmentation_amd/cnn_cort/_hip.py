@@ -31,6 +31,7 @@ SIGNATURES = {
     'scs_set_chunk': (_c.c_int, [_vp, _c.c_int]),
     'scs_set_option': (_c.c_int, [_vp, _c.c_char_p, _c.c_int64]),
     'scs_get_option': (_c.c_int, [_vp, _c.c_char_p, _c.POINTER(_c.c_int64)]),
+    'scs_probe_f32_mfma': (_c.c_int, [_vp, _c.POINTER(_c.c_double)]),
     'scs_forward': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
     'scs_forward_host': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
     'scs_forward_volume': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
@@ -271,6 +272,12 @@ class Handle:
         v = ctypes.c_int64(0)
         _check(self.lib.scs_get_option(self.h, name.encode(), ctypes.byref(v)), 'scs_get_option(%s)' % name)
         return int(v.value)
+
+    def probe_f32_mfma(self):
+        """TFLOP/s at which this device issues back-to-back v_mfma_f32_16x16x4_f32 (include/scs.h: scs_probe_f32_mfma)."""
+        v = ctypes.c_double(0.0)
+        _check(self.lib.scs_probe_f32_mfma(self.h, ctypes.byref(v)), 'scs_probe_f32_mfma')
+        return float(v.value)
 
     # ---- inference
     def _check_inputs(self, ax, co, sa, atlas, n, y=None, probs=None, labels=None):

@@ -316,3 +316,16 @@ def test_large_n_is_chunked_consistently(handle):
         srt = torch.sort(p2, dim=1).values
         clear = (srt[:, -1] - srt[:, -2]) > 1e-4
         assert bool((l2 == lb[lo:lo + m])[clear].all())
+
+
+@pytest.mark.gpu
+def test_mfma_issue_rate_probe_is_a_plausible_fraction_of_the_nominal_peak():
+    """scs_probe_f32_mfma (the figure bench.py sets beside the nominal 157.3 TFLOP/s): back-to-back f32 MFMAs on every SIMD cannot
+    exceed the nominal peak and on an MI355X do not fall below half of it."""
+    from cnn_cort import _hip
+    h = _hip.Handle(0)
+    try:
+        rate = h.probe_f32_mfma()
+    finally:
+        h.close()
+    assert 0.5 * 157.3 < rate <= 157.3 * 1.02, rate

@@ -699,6 +699,9 @@ def main():
             for tb in (128, 256):
                 r, stp = measure_train(torch, dist, h, tb, args.train_steps, 20, rank, world, dev, st, profile=True)
                 r['frac_of_f32_peak'] = r['net_frac_of_f32_peak']
+                issue = (out.get('roofline') or {}).get('device_mfma_issue_rate', {}).get('tflops')
+                if issue:                                                 # beside the nominal peak, as in the forward's roofline block
+                    r['net_frac_of_device_mfma_issue_rate'] = r['net_tflops'] / (issue * world)
                 blk['batch%d' % tb] = r
                 tstep, tms = stp, r['ms_per_step']
             if rank == 0:

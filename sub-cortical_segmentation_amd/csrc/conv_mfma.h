@@ -368,6 +368,11 @@ struct ConvArgs {
     X0Src x0;                     // SRC_X0 / EPI_L1: the input patches
     int tower0;                   // first tower of this launch (grid.y towers from here; per-tower streams launch one each)
     FinArgs fin;                  // FIN configurations
+    float* pout[kTowers];         // fused conv1 + conv2 in training (EPI_RAW_STATS), or null: [n][COUT][HP][HP], per 2x2 window of the raw output the
+                                  // value the block's batch norm + ReLU + max-pool will keep - the window's maximum where the layer's gamma
+                                  // (bias[]: [COUT]) is >= 0, its minimum otherwise (z -> sc z + sh and the ReLU are monotone, sign(sc) = sign(gamma):
+                                  // pool(relu(bn(z))) = relu(bn(that value)) exactly).  The next conv stages this quarter-size array (SRC_BN)
+                                  // instead of pooling the full-size one (SRC_BN_POOL); the backward pass still reads the full-size output.
     float* wgstats;               // EPI_RAW_STATS with G > 1 (conv5 block), or null: [tower][workgroup][COUT] (mean, M2) of the workgroup's
                                   // G * OUTB values per channel - the units the one-launch dense head finalizes (dense_chain.h)
 };
@@ -1226,6 +1231,29 @@ __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma
                 if (e < total) {
                     const int gc = e / C::OUTB, r = e - gc * C::OUTB;
                     outp[(size_t)gc * C::OUTPIX + r] = s_o[gc * C::OSTR + r];
+                }
+            }
+        }
+    }
+    if constexpr (C::EPI == EPI_RAW_STATS && C::FUSED1 && C::HOB % 2 == 0 && C::HO % 2 == 0) {
+        // the pooled-by-sign copy of the band's raw outputs (ConvArgs::pout): rows of s_o are [cout][HOB x HO]
+        float* __restrict__ po = pick3(a.pout, tower);
+        if (po) {
+            constexpr int WB2 = (C::HOB / 2) * C::HP, PR = C::HP / 2, ITEMS = C::COUT * (C::HOB / 2) * PR;   // windows per channel and band; window pairs per row
+            static_assert(C::HP % 2 == 0 && C::OSTR % 4 == 0 && C::HO % 4 == 0, "two windows = one 16-byte piece of each of their two rows");
+            po += (size_t)g0 * C::COUT * (C::HP * C::HP) + band * WB2;
+            const float* __restrict__ gm = pick3(a.bias, tower);
+#pragma unroll
+            for (int e0 = 0; e0 < ITEMS; e0 += C::NTH) {
+                const int e = e0 + tid;
+                if (e < ITEMS) {
+                    const int row = e / PR, wp = e - row * PR, co = row / (C::HOB / 2), wy = row - co * (C::HOB / 2);
+                    const float* __restrict__ q = s_o + co * C::OSTR + (2 * wy) * C::HO + 4 * wp;
+                    const float4 r0 = *reinterpret_cast<const float4*>(q), r1 = *reinterpret_cast<const float4*>(q + C::HO);
+                    const bool up = gm[co] >= 0.f;
+                    const float a0 = up ? fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y)) : fminf(fminf(r0.x, r0.y), fminf(r1.x, r1.y));
+                    const float a1 = up ? fmaxf(fmaxf(r0.z, r0.w), fmaxf(r1.z, r1.w)) : fminf(fminf(r0.z, r0.w), fminf(r1.z, r1.w));
+                    *reinterpret_cast<float2*>(po + (size_t)co * (C::HP * C::HP) + wy * C::HP + 2 * wp) = float2{a0, a1};
                 }
             }
         }

@@ -58,6 +58,7 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     int attr_device = -1;                      // device whose kernels carry the dynamic-LDS attributes
     float* base = nullptr;
     float* Z[kTowers][kConvs]{};               // raw conv outputs of conv2..conv5 (index 1..4)
+    float* ZP[kTowers]{};                      // conv2's raw output pooled by the sign of gamma ([n][20][14][14]: what conv3's forward stages; conv_mfma.h ConvArgs::pout)
     float* X[kTowers][kConvs]{};               // block outputs = conv inputs of conv3..conv5 (index 2..4)
     float* H5[kTowers]{};                      // block-5 output after dropout [n][540]
     float* dZ[kTowers][kConvs]{};              // d z of conv2..conv5 (index 1..4), left by the data-gradient kernels
@@ -204,7 +205,7 @@ static int train_ensure(scs_ctx* h, int n) {
     const size_t c = (size_t)((n + 63) / 64 * 64);
     size_t off = 0;
     auto take = [&](size_t f) { size_t o = off; off += al64(f); return o; };
-    size_t oZ[kTowers][kConvs], oX[kTowers][kConvs], odZ[kTowers][kConvs], odX[kTowers][kConvs], oH[kTowers], odH[kTowers];
+    size_t oZ[kTowers][kConvs], oX[kTowers][kConvs], odZ[kTowers][kConvs], odX[kTowers][kConvs], oH[kTowers], odH[kTowers], oZP[kTowers];
     for (int t = 0; t < kTowers; ++t) {
         for (int i = 1; i < kConvs; ++i) {
             oZ[t][i] = take(c * kCout[i] * kHout[i] * kHout[i]);
@@ -214,6 +215,7 @@ static int train_ensure(scs_ctx* h, int n) {
         }
         oH[t] = take(c * kFlat);
         odH[t] = take(c * kFlat);
+        oZP[t] = take(c * kCout[1] * kHin[2] * kHin[2]);
     }
     const size_t o_feat = take(c * kFlat), o_featd = take(c * kFlat), o_R1 = take(c * kFC1), o_cat2 = take(c * kFC1ld),
                  o_R2 = take(c * kFC2ld), o_probs = take(c * 16), o_dlog = take(c * 16), o_dR2 = take(c * kFC2ld),
@@ -231,7 +233,7 @@ static int train_ensure(scs_ctx* h, int n) {
             w->Z[t][i] = w->base + oZ[t][i]; w->dZ[t][i] = w->base + odZ[t][i];
             w->X[t][i] = (i >= 2) ? w->base + oX[t][i] : nullptr; w->dX[t][i] = (i >= 2) ? w->base + odX[t][i] : nullptr;
         }
-        w->H5[t] = w->base + oH[t]; w->dH5[t] = w->base + odH[t];
+        w->H5[t] = w->base + oH[t]; w->dH5[t] = w->base + odH[t]; w->ZP[t] = w->base + oZP[t];
     }
     w->feat = w->base + o_feat; w->featd = w->base + o_featd; w->R1 = w->base + o_R1; w->cat2 = w->base + o_cat2;
     w->R2 = w->base + o_R2; w->probs = w->base + o_probs; w->dlog = w->base + o_dlog; w->dR2 = w->base + o_dR2;
@@ -1179,8 +1181,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         a.wgstats = (tail && i == kConvs - 1) ? w->c5_units : nullptr;
         for (int t = 0; t < kTowers; ++t) {
             a.w[t] = w->wpk[t][i]; a.out[t] = w->Z[t][i];
-            if (i == 1) { a.w1[t] = w->w1p[t]; }
-            else { a.in[t] = w->Z[t][i - 1]; a.bn[t] = reinterpret_cast<const float*>(w->ss[t][i - 1]); a.xout[t] = w->X[t][i]; }
+            if (i == 1) { a.w1[t] = w->w1p[t]; a.pout[t] = w->ZP[t]; a.bias[t] = P + T0.bn[1] + t * kTowerFloats + kCout[1]; }   // gamma2: which extremum pool1 keeps
+            else { a.in[t] = (i == 2) ? w->ZP[t] : w->Z[t][i - 1]; a.bn[t] = reinterpret_cast<const float*>(w->ss[t][i - 1]); a.xout[t] = w->X[t][i]; }
         }
         a.x0 = x0;
         const int C = kCout[i], Hh = kHout[i];

@@ -781,3 +781,23 @@ def test_banded_tilings_of_the_middle_layers_against_the_whole_patch_tilings(wei
     # (n = 1: a batch norm over 9 .. 144 values per channel - losses of ~30 after a step or two; held to 1e-4 there)
     assert np.abs(out['bands'][0] - out['whole'][0]).max() <= (1e-5 if n > 1 else 1e-4) * max(1.0, np.abs(out['whole'][0]).max())
     print('n = %d: banded vs whole-patch tilings, worst relative gradient difference after three steps %.3g' % (n, worst))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [5, 37, 128])
+def test_pool1_taken_before_batch_norm_follows_the_sign_of_gamma(fresh, weights, n):
+    """The training forward's conv1 + conv2 kernel leaves, beside the raw conv2 output, each 2x2 window's MAXIMUM where the conv2
+    block's gamma is >= 0 and its MINIMUM otherwise, and conv3 stages relu(sc z + sh) of that value instead of pooling the full
+    plane (csrc/conv_mfma.h ConvArgs::pout): exact because z -> sc z + sh and the ReLU are monotone and sign(sc) = sign(gamma).
+    The shipped gammas are all positive; here a third of them are negated and one is zero in every tower - the step must still
+    agree with the oracle (which pools AFTER the batch norm, as Lasagne does), decisions counted as everywhere else."""
+    w = {k: [a.copy() for a in v] for k, v in weights.items()}
+    for tower in ('axial', 'coronal', 'saggital'):
+        name = [k for k in w if k.startswith(tower[:4]) and k.endswith('conv2_bn')]
+        assert len(name) == 1, (tower, sorted(w))
+        gamma = w[name[0]][1]
+        gamma[::3] = -gamma[::3]
+        gamma[1] = 0.0
+        assert (gamma < 0).sum() >= 6 and (gamma > 0).sum() >= 6
+    worst, forced = _step_against_gate_aware_oracle(fresh, w, n, 0)
+    print('n = %d, signed gammas: worst relative gradient error %.3g; decisions taken from the GPU: %r' % (n, worst, forced))

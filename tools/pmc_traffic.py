@@ -25,7 +25,7 @@ FORWARD = {
 }
 TRAIN = {
     'conv1+conv2 fwd': r'^conv<20,20,30,1,3,8,',
-    'conv3 fwd': r'^conv<20,40,14,1,3,5,',
+    'conv3 fwd': r'^conv<20,40,14,1,3,[45],',
     'conv4 fwd': r'^conv<40,40,12,1,3,4,',
     'conv5 fwd': r'^conv<40,60,5,\d+,3,5,',
     'conv5 dgrad': r'^conv<60,40,7,',

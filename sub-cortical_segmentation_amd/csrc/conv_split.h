@@ -29,6 +29,7 @@ namespace scs {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kSplitActScale = 64.f;         // activations are stored times 2^6 (overflow beyond |a| = 1023: flagged, see below)
 constexpr float kSplitOverflow = 60000.f;      // a scaled activation above this sets the launch's overflow flag
@@ -43,9 +44,9 @@ struct Split12Args {
     const float* in[kTowers];     // [n][32][32]
     const float* w1[kTowers];     // kSp12W1Floats
     const uint4* w2[kTowers];     // kSp12W2Vec
-    const float* b2[kTowers];     // [20] folded bias of conv2 (unscaled)
-    float inv2[kTowers];          // 1 / (kSplitActScale * weight scale of conv2): power of two
-    float* out[kTowers];          // [n][20][14][14] f32 (the f32 kernels' pool1 layout)
+    const float* b2[kTowers];     // [32] folded bias of conv2 (20 used), then one float: 1 / (kSplitActScale * weight scale of conv2), a power of two
+    void* out[kTowers];           // OUT_SPLIT: [n][2][196 x 40 bytes] f16 planes [pixel][channel] (hi, lo; times kSplitActScale);
+                                  // else [n][20][14][14] f32 (the f32 kernels' pool1 layout)
     int n;
     unsigned int* flag;           // set to 1 when a scaled activation left the f16 range (results of the launch are then void)
 };
@@ -67,9 +68,15 @@ __device__ __forceinline__ void sp_split4_store(f32x4 v, unsigned char* hi, unsi
     *reinterpret_cast<f16x4*>(lo + off) = l;
 }
 
+// One B fragment = two 8-byte LDS reads (the two halves of the lane's 16 bytes, order by lane group: see the bank note above).
+// Volatile: the compiler otherwise pairs reads off the same base register ACROSS fragments into ds_read2_b64 (half the LDS rate,
+// 32-bank mapping) and reassembles the fragments with register moves - more vector instructions than MFMAs.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef const volatile __attribute__((address_space(3))) u32x2* sp_lds_cv8;   // explicit LDS address space: a volatile access through a
+                                                                               // generic pointer is compiled to a flat load
 __device__ __forceinline__ f16x8 sp_frag(const unsigned char* p0, const unsigned char* p1) {
-    const uint2 a = *reinterpret_cast<const uint2*>(p0), b = *reinterpret_cast<const uint2*>(p1);
-    const uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+    const u32x2 a = *(sp_lds_cv8)(p0), b = *(sp_lds_cv8)(p1);
+    const u32x4 v = {a.x, a.y, b.x, b.y};
     return __builtin_bit_cast(f16x8, v);
 }
 
@@ -82,7 +89,35 @@ __device__ __forceinline__ float sp_quad_max(float v) {
     return fmaxf(v, __builtin_bit_cast(float, b));
 }
 
+// pooled pixel w of a patch-tower: channels 4 j .. 4 j + 3 (v0) and, from lane group 0, 16 .. 19 (v1)
+template <bool OUT_SPLIT>
+__device__ __forceinline__ void sp12_store(unsigned char* op, int w, int j, f32x4 v0, f32x4 v1, float& vmax) {
+    if constexpr (OUT_SPLIT) {
+        f16x4 h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v0[i] *= kSplitActScale; h[i] = (_Float16)v0[i]; l[i] = (_Float16)(v0[i] - (float)h[i]); }
+        vmax = fmaxf(fmaxf(vmax, v0[0]), v0[1]); vmax = fmaxf(fmaxf(vmax, v0[2]), v0[3]);
+        *reinterpret_cast<f16x4*>(op + w * 40 + 8 * j) = h;
+        *reinterpret_cast<f16x4*>(op + 7840 + w * 40 + 8 * j) = l;
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v1[i] *= kSplitActScale; h[i] = (_Float16)v1[i]; l[i] = (_Float16)(v1[i] - (float)h[i]); }
+            vmax = fmaxf(fmaxf(vmax, v1[0]), v1[1]); vmax = fmaxf(fmaxf(vmax, v1[2]), v1[3]);
+            *reinterpret_cast<f16x4*>(op + w * 40 + 32) = h;
+            *reinterpret_cast<f16x4*>(op + 7840 + w * 40 + 32) = l;
+        }
+    } else {
+        float* o = reinterpret_cast<float*>(op);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[(4 * j + i) * 196 + w] = v0[i];
+            if (j == 0) o[(16 + i) * 196 + w] = v1[i];
+        }
+    }
+}
+
 // grid = 3 * G workgroups of 256 threads: workgroup b serves tower b % 3, patches b / 3, b / 3 + G, ...
+template <bool OUT_SPLIT>
 __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     unsigned char* s_hi = sp_smem;
@@ -117,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
     f32x4 bias0, bias1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bias0[i] = a.b2[tower][4 * j + i]; bias1[i] = a.b2[tower][16 + i]; }
-    const float inv = a.inv2[tower];
+    const float inv = a.b2[tower][32];
     // per-lane byte offsets of the wave's three pooling groups (16 pooled pixels each) and of the odd tile (pooled 192..195)
     int rd0[3], rd1[3];
 #pragma unroll
@@ -136,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
     }
     float vmax = 0.f;
     const float* inp = a.in[tower];
-    float* outp = a.out[tower];
+    unsigned char* outp = reinterpret_cast<unsigned char*>(a.out[tower]);
     float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wg < a.n) xr = reinterpret_cast<const float4*>(inp + (size_t)wg * 1024)[tid];
     int it = 0;
@@ -163,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
         }
         __syncthreads();                                     // planes complete
         // ---- conv2 on the f16 matrix cores
-        float* op = outp + (size_t)p * (20 * 196);
+        unsigned char* op = outp + (size_t)p * (20 * 196 * 4);      // both formats: 15 680 bytes per patch-tower
 #pragma unroll 1
         for (int k = 0; k < 3; ++k) {
             const unsigned char* h0 = s_hi + rd0[k];
@@ -173,28 +208,39 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
             f32x4 acc[4][2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { acc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            // fragments of k-step s + 1 are requested behind the MFMAs of the same tile of k-step s (at most 12 reads newer than the
+            // one a tile waits for: the LDS counter has 4 bits)
+            f16x8 fh[2][4], fl[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int off = (q >> 1) * 1200 + (q & 1) * 40;
+                fh[0][q] = sp_frag(h0 + off, h1 + off); fl[0][q] = sp_frag(l0 + off, l1 + off);
+            }
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int off = ((s >> 1) + (q >> 1)) * 1200 + (q & 1) * 40 + (s & 1) * 64;
-                    const f16x8 bh = sp_frag(h0 + off, h1 + off), bl = sp_frag(l0 + off, l1 + off);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][m], bh, acc[q][m], 0, 0, 0);
-                        acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bl, acc[q][m], 0, 0, 0);
-                        acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bh, acc[q][m], 0, 0, 0);
+                        acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][m], fh[s & 1][q], acc[q][m], 0, 0, 0);
+                        acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], fl[s & 1][q], acc[q][m], 0, 0, 0);
+                        acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], fh[s & 1][q], acc[q][m], 0, 0, 0);
                     }
+                    if (s + 1 < 6) {
+                        const int off = (((s + 1) >> 1) + (q >> 1)) * 1200 + (q & 1) * 40 + ((s + 1) & 1) * 64;
+                        fh[(s + 1) & 1][q] = sp_frag(h0 + off, h1 + off); fl[(s + 1) & 1][q] = sp_frag(l0 + off, l1 + off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             const int w = 16 * (wave + 4 * k) + n;
+            f32x4 v0, v1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v0 = fmaxf(fmaxf(acc[0][0][i], acc[1][0][i]), fmaxf(acc[2][0][i], acc[3][0][i]));
-                op[(4 * j + i) * 196 + w] = fmaxf(v0 * inv + bias0[i], 0.f);
-                const float v1 = fmaxf(fmaxf(acc[0][1][i], acc[1][1][i]), fmaxf(acc[2][1][i], acc[3][1][i]));
-                if (j == 0) op[(16 + i) * 196 + w] = fmaxf(v1 * inv + bias1[i], 0.f);
+                v0[i] = fmaxf(fmaxf(fmaxf(acc[0][0][i], acc[1][0][i]), fmaxf(acc[2][0][i], acc[3][0][i])) * inv + bias0[i], 0.f);
+                v1[i] = fmaxf(fmaxf(fmaxf(acc[0][1][i], acc[1][1][i]), fmaxf(acc[2][1][i], acc[3][1][i])) * inv + bias1[i], 0.f);
             }
+            sp12_store<OUT_SPLIT>(op, w, j, v0, v1, vmax);
         }
         if (wave == (it & 3)) {                              // the odd tile: pooled pixels 192..195, the four positions of each in one quad of lanes
             const unsigned char* h0 = s_hi + rs0;
@@ -214,27 +260,359 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
                 }
             }
             const int w = 192 + (n >> 2);
+            f32x4 v0, v1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v0 = sp_quad_max(acc[0][i]), v1 = sp_quad_max(acc[1][i]);
-                if ((n & 3) == 0) {
-                    op[(4 * j + i) * 196 + w] = fmaxf(v0 * inv + bias0[i], 0.f);
-                    if (j == 0) op[(16 + i) * 196 + w] = fmaxf(v1 * inv + bias1[i], 0.f);
-                }
+                v0[i] = fmaxf(sp_quad_max(acc[0][i]) * inv + bias0[i], 0.f);
+                v1[i] = fmaxf(sp_quad_max(acc[1][i]) * inv + bias1[i], 0.f);
             }
+            if ((n & 3) == 0) sp12_store<OUT_SPLIT>(op, w, j, v0, v1, vmax);
         }
     }
     if (vmax > kSplitOverflow) atomicOr(a.flag, 1u);
 }
 
 inline hipError_t conv12_split_set_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
 }
 
+template <bool OUT_SPLIT>
 inline void conv12_split_launch(const Split12Args& a, hipStream_t st, int wgs_per_tower = 170) {
     int g = wgs_per_tower < a.n ? wgs_per_tower : a.n;
     if (g < 1) return;
-    hipLaunchKernelGGL(conv12_split_kernel, dim3(3 * g), dim3(256), kSp12LdsBytes, st, a);
+    hipLaunchKernelGGL(conv12_split_kernel<OUT_SPLIT>, dim3(3 * g), dim3(256), kSp12LdsBytes, st, a);
+}
+
+
+// =====================================================================================================================
+// conv3 / conv4 (+ pool2) / conv5 on the split: activations arrive and leave as two f16 planes [pixel][channel] per patch-tower
+// (hi plane, then lo plane; values times kSplitActScale) - the same bytes per element as the f32 layout.
+// One wave per 16-channel output tile (its weights: KS k-steps x 2 pieces x 16 bytes per lane, in registers for the whole launch);
+// every wave walks all pixel tiles of the workgroup's G patch-towers, so the B operand is read by each of the MT waves.
+// Pixel tiles: 4 x 4 blocks of output pixels (plain), the four window positions of 16 pooled pixels (POOL), or the 3 x 3 outputs of
+// one patch (conv5: 9 of 16 lanes).
+template <int CIN_, int COUT_, int HIN_, bool POOL_, int OUTF_, int G_, int WPC_>
+struct SpCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, HIN = HIN_, G = G_, OUTF = OUTF_, WPC = WPC_;
+    static constexpr bool POOL = POOL_;
+    static constexpr int HO = HIN_ - 2, HP = HO / 2;
+    static constexpr int MT = (COUT_ + 15) / 16, NW = MT, NTH = 64 * MT;
+    static constexpr int PS = 2 * CIN_, RS = HIN_ * PS;                       // pixel / row stride of a plane, bytes
+    static constexpr int KSR = (3 * CIN_ + 31) / 32, KS = 3 * KSR;            // k-steps per tap row / in all
+    static constexpr int IN_PX = HIN_ * HIN_, IN_B = IN_PX * PS;              // one plane of one patch-tower in global memory
+    static constexpr int PLANE_B = IN_B + 32;                                 // in LDS: + pad for the last run's overrun
+    static constexpr int V = IN_B / 16;                                       // 16-byte pieces per plane
+    static constexpr int PF = (2 * V * G_ + NTH - 1) / NTH;                   // prefetch registers (uint4) per thread
+    static constexpr bool SMALL = (HO < 4);                                   // conv5: one tile per patch, lanes 0..8
+    static constexpr int NPOOL = HP * HP, NGRP = (NPOOL + 15) / 16;
+    static constexpr int TPP = SMALL ? 1 : (POOL_ ? 4 * NGRP : (HO / 4) * (HO / 4));   // pixel tiles per patch-tower
+    static constexpr int NT = TPP * G_;
+    static constexpr int OUT_PX = POOL_ ? NPOOL : HO * HO;
+    static constexpr int OUT_PS = 2 * COUT_, OUT_B = OUT_PX * OUT_PS;         // output plane (OUTF 0)
+    static constexpr size_t LDS_BYTES = (size_t)2 * G_ * PLANE_B;
+    static_assert(IN_B % 16 == 0, "planes are staged in 16-byte pieces");
+    static_assert(SMALL || POOL_ || HO % 4 == 0, "plain tiles are 4 x 4 pixel blocks");
+    static_assert(!SMALL || HO * HO <= 16, "small form: all outputs of a patch in one tile");
+    static_assert(32 * KSR - 3 * CIN_ <= 16 && 32 * KSR >= 3 * CIN_, "run padding stays inside the plane pad");
+};
+
+struct SplitArgs {
+    const unsigned char* in[kTowers];   // [n][2][IN_B]
+    const uint4* w[kTowers];            // [KS][MT][2][64] x 16 bytes
+    const float* bias[kTowers];         // [MT * 16] folded bias, then one float: 1 / (kSplitActScale * weight scale), a power of two
+    void* out[kTowers];                 // OUTF 0: [n][2][OUT_B] planes; OUTF 1: f32 [n][COUT][HO][HO]
+    int n;
+    unsigned int* flag;
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, m = tid >> 6, n = lane & 15, j = lane >> 4;
+    const int tower = blockIdx.x % kTowers, wg = blockIdx.x / kTowers, nwg = gridDim.x / kTowers;
+    // plane g: hi at g * 2 * PLANE_B, lo behind it
+    if (tid < 16 * C::G) {                                      // pads: zero once
+        const int g = tid >> 4, e = tid & 15;
+        reinterpret_cast<unsigned*>(sp_smem + (size_t)(2 * g) * C::PLANE_B + C::IN_B)[e & 7] = 0u;
+        reinterpret_cast<unsigned*>(sp_smem + (size_t)(2 * g + 1) * C::PLANE_B + C::IN_B)[e & 7] = 0u;
+    }
+    f16x8 wh[C::KS], wl[C::KS];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+        wh[s] = __builtin_bit_cast(f16x8, a.w[tower][((s * C::MT + m) * 2 + 0) * 64 + lane]);
+        wl[s] = __builtin_bit_cast(f16x8, a.w[tower][((s * C::MT + m) * 2 + 1) * 64 + lane]);
+    }
+    f32x4 bias;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias[i] = a.bias[tower][16 * m + 4 * j + i];
+    const float c0 = a.bias[tower][16 * C::MT];
+    const bool jvalid = 16 * m + 4 * j < C::COUT;
+    // per-lane byte offset of this lane's pixel inside a tile family
+    int rd0[C::POOL ? C::NGRP : 1], rd1[C::POOL ? C::NGRP : 1];
+    if constexpr (C::POOL) {
+#pragma unroll
+        for (int k = 0; k < C::NGRP; ++k) {
+            const int w = min(16 * k + n, C::NPOOL - 1), p0 = (2 * (w / C::HP)) * C::HIN + 2 * (w % C::HP);
+            const int x = C::PS * p0 + 16 * j;
+            rd0[k] = x + 8 * (j & 1); rd1[k] = x + 8 - 8 * (j & 1);
+        }
+    } else {
+        const int p0 = C::SMALL ? (n < 9 ? (n / 3) * C::HIN + n % 3 : 0) : (n >> 2) * C::HIN + (n & 3);
+        const int x = C::PS * p0 + 16 * j;
+        rd0[0] = x + 8 * (j & 1); rd1[0] = x + 8 - 8 * (j & 1);
+    }
+    float vmax = 0.f;
+    const unsigned char* inp = a.in[tower];
+    constexpr int SP_NTH = C::NTH, SP_PF = C::PF;
+    u32x4 pf[SP_PF];
+    // global -> registers (clamped, always valid addresses: straight-line loads) and registers -> LDS; macros, not lambdas: with the
+    // array captured by a closure the compiler kept it in scratch memory
+#define SP_FETCH(P_)                                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < SP_PF; ++r) {                                                                    \
+        const int e_ = min(tid + r * SP_NTH, 2 * C::V * C::G - 1), g_ = e_ / (2 * C::V), v_ = e_ - g_ * 2 * C::V;         \
+        pf[r] = reinterpret_cast<const u32x4*>(inp + (size_t)min((P_) + g_, a.n - 1) * 2 * C::IN_B)[v_];                   \
+    }
+#define SP_STASH(BASE_)                                                                                                    \
+    _Pragma("unroll") for (int r = 0; r < SP_PF; ++r) {                                                                    \
+        const int e_ = tid + r * SP_NTH;                                                                                   \
+        if (e_ < 2 * C::V * C::G) {                                                                                        \
+            const int pl_ = e_ / C::V, v_ = e_ - pl_ * C::V;                                                               \
+            reinterpret_cast<u32x4*>((BASE_) + (size_t)pl_ * C::PLANE_B)[v_] = pf[r];                                      \
+        }                                                                                                                  \
+    }
+    const int step = nwg * C::G;
+    if (wg * C::G < a.n) { SP_FETCH(wg * C::G) }
+    for (int p = wg * C::G; p < a.n; p += step) {
+        __syncthreads();                                     // every wave is done with the planes of the previous iteration
+        SP_STASH(sp_smem)
+        __syncthreads();
+        if (p + step < a.n) { SP_FETCH(p + step) }
+        f32x4 acc[C::NT];
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+            const int soff = (s / C::KSR) * C::RS + (s % C::KSR) * 64;
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) {
+                const int g = t / C::TPP, tt = t % C::TPP;
+                int off = g * 2 * C::PLANE_B + soff, k = 0;
+                if constexpr (C::POOL) { k = tt >> 2; off += ((tt >> 1) & 1) * C::RS + (tt & 1) * C::PS; }
+                else if constexpr (!C::SMALL) off += ((tt / (C::HO / 4)) * 4 * C::HIN + (tt % (C::HO / 4)) * 4) * C::PS;
+                const unsigned char* h0 = sp_smem + rd0[k] + off;
+                const unsigned char* h1 = sp_smem + rd1[k] + off;
+                const f16x8 bh = sp_frag(h0, h1), bl = sp_frag(h0 + C::PLANE_B, h1 + C::PLANE_B);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s], bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s], bh, acc[t], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: lane (n, j) holds channels 16 m + 4 j .. + 3 of its pixel
+#pragma unroll
+        for (int g = 0; g < C::G; ++g) {
+            if (p + g >= a.n) break;
+            constexpr int NOUT = C::POOL ? C::NGRP : C::TPP;
+#pragma unroll
+            for (int t = 0; t < NOUT; ++t) {
+                f32x4 v;
+                int px;                                          // output pixel of this lane, -1: none
+                if constexpr (C::POOL) {
+                    const f32x4* q = &acc[g * C::TPP + 4 * t];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaxf(q[0][i], q[1][i]), fmaxf(q[2][i], q[3][i]));
+                    px = 16 * t + n < C::NPOOL ? 16 * t + n : -1;
+                } else {
+                    v = acc[g * C::TPP + t];
+                    if constexpr (C::SMALL) px = n < 9 ? n : -1;
+                    else px = ((t / (C::HO / 4)) * 4 + (n >> 2)) * C::HO + (t % (C::HO / 4)) * 4 + (n & 3);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i] * c0 + bias[i], 0.f);
+                if (px < 0 || !jvalid) continue;
+                if constexpr (C::OUTF == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= kSplitActScale;
+                    vmax = fmaxf(fmaxf(vmax, v[0]), v[1]); vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);
+                    f16x4 h, l;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { h[i] = (_Float16)v[i]; l[i] = (_Float16)(v[i] - (float)h[i]); }
+                    unsigned char* o = reinterpret_cast<unsigned char*>(a.out[tower]) + (size_t)(p + g) * 2 * C::OUT_B + px * C::OUT_PS + 2 * (16 * m + 4 * j);
+                    *reinterpret_cast<f16x4*>(o) = h;
+                    *reinterpret_cast<f16x4*>(o + C::OUT_B) = l;
+                } else {
+                    float* o = reinterpret_cast<float*>(a.out[tower]) + (size_t)(p + g) * C::COUT * C::OUT_PX + (16 * m + 4 * j) * C::OUT_PX + px;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i * C::OUT_PX] = v[i];
+                }
+            }
+        }
+    }
+    if (C::OUTF == 0 && vmax > kSplitOverflow) atomicOr(a.flag, 1u);
+}
+
+// ---- the same layers with ALL output tiles per wave: one wave per SIMD (512 registers), every wave holds the weights of all MT
+// output tiles (MT * KS * 8 registers: 144 for conv3, 288 for conv4) and walks its own quarter of the iteration's pixel tiles, so
+// every B fragment is read from LDS once.  A workgroup (4 waves) stages G patch-towers per iteration into one of two LDS buffers
+// (global -> registers during the previous iteration's matrix phase -> LDS behind it): one barrier per iteration.
+template <class C>
+__global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    constexpr int NTH = 256, TPW = C::NT / 4, PF = (2 * C::V * C::G + NTH - 1) / NTH, BUF_B = 2 * C::G * C::PLANE_B;
+    static_assert(C::NT % 4 == 0 && (C::TPP % TPW == 0 || TPW % C::TPP == 0), "tiles split evenly over the four waves");
+    static_assert(!C::POOL || TPW == 4, "a wave owns one pooling group");
+    static_assert(C::OUTF == 0 && !C::SMALL, "split-plane outputs");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, j = lane >> 4;
+    const int tower = blockIdx.x % kTowers, wg = blockIdx.x / kTowers, nwg = gridDim.x / kTowers;
+    if (tid < 32 * C::G) {                                      // pads of both buffers: zero once
+        const int b = tid / (16 * C::G), g = (tid >> 4) % C::G, e = tid & 7;
+        reinterpret_cast<unsigned*>(sp_smem + (size_t)b * BUF_B + (size_t)(2 * g) * C::PLANE_B + C::IN_B)[e] = 0u;
+        reinterpret_cast<unsigned*>(sp_smem + (size_t)b * BUF_B + (size_t)(2 * g + 1) * C::PLANE_B + C::IN_B)[e] = 0u;
+    }
+    f16x8 wh[C::KS][C::MT], wl[C::KS][C::MT];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            wh[s][m] = __builtin_bit_cast(f16x8, a.w[tower][((s * C::MT + m) * 2 + 0) * 64 + lane]);
+            wl[s][m] = __builtin_bit_cast(f16x8, a.w[tower][((s * C::MT + m) * 2 + 1) * 64 + lane]);
+        }
+    f32x4 bias[C::MT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias[m][i] = a.bias[tower][16 * m + 4 * j + i];
+    const float c0 = a.bias[tower][16 * C::MT];
+    // this wave's tiles: t = wave * TPW + i -> patch g = t / TPP, tile tt = t % TPP
+    const int t0 = wave * TPW, g0 = t0 / C::TPP;
+    int rd0, rd1;
+    if constexpr (C::POOL) {
+        const int k = (t0 % C::TPP) >> 2;
+        const int w = min(16 * k + n, C::NPOOL - 1), p0 = (2 * (w / C::HP)) * C::HIN + 2 * (w % C::HP);
+        const int x = C::PS * p0 + 16 * j + g0 * 2 * C::PLANE_B;
+        rd0 = x + 8 * (j & 1); rd1 = x + 8 - 8 * (j & 1);
+    } else {
+        const int p0 = (n >> 2) * C::HIN + (n & 3);
+        const int x = C::PS * p0 + 16 * j + g0 * 2 * C::PLANE_B;
+        rd0 = x + 8 * (j & 1); rd1 = x + 8 - 8 * (j & 1);
+    }
+    float vmax = 0.f;
+    const unsigned char* inp = a.in[tower];
+    constexpr int SP_NTH = NTH, SP_PF = PF;
+    u32x4 pf[SP_PF];
+    const int step = nwg * C::G;
+    int p = wg * C::G, buf = 0;
+    if (p < a.n) { SP_FETCH(p) SP_STASH(sp_smem) }
+    __syncthreads();
+    if (p + step < a.n) { SP_FETCH(p + step) }
+    for (; p < a.n; p += step) {
+        const unsigned char* base = sp_smem + (size_t)buf * BUF_B;
+        // TB tiles per pass (POOL: the four positions of the wave's pooling group); the B fragments of k-step s + 1 are requested in
+        // front of the MFMAs of k-step s and the scheduler is kept from hoisting further (fragments of ALL k-steps in flight spill)
+        constexpr int TB = C::POOL ? 4 : 3;
+        static_assert(TPW % TB == 0, "passes");
+#pragma unroll
+        for (int i0 = 0; i0 < TPW; i0 += TB) {
+            f32x4 acc[TB][C::MT];
+#pragma unroll
+            for (int i = 0; i < TB; ++i)
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f16x8 fh[2][TB], fl[2][TB];
+            auto frags = [&](int s, int slot, int i) {
+                int off = (s / C::KSR) * C::RS + (s % C::KSR) * 64;
+                if constexpr (C::POOL) off += ((i >> 1) & 1) * C::RS + (i & 1) * C::PS;
+                else {
+                    const int tt = (i0 + i) % C::TPP;
+                    off += ((i0 + i) / C::TPP) * 2 * C::PLANE_B + ((tt / (C::HO / 4)) * 4 * C::HIN + (tt % (C::HO / 4)) * 4) * C::PS;
+                }
+                const unsigned char* h0 = base + rd0 + off;
+                const unsigned char* h1 = base + rd1 + off;
+                fh[slot][i] = sp_frag(h0, h1);
+                fl[slot][i] = sp_frag(h0 + C::PLANE_B, h1 + C::PLANE_B);
+            };
+#pragma unroll
+            for (int i = 0; i < TB; ++i) frags(0, 0, i);
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+#pragma unroll
+                for (int i = 0; i < TB; ++i) {
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m) {
+                        acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][m], fh[s & 1][i], acc[i][m], 0, 0, 0);
+                        acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], fl[s & 1][i], acc[i][m], 0, 0, 0);
+                        acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], fh[s & 1][i], acc[i][m], 0, 0, 0);
+                    }
+                    if (s + 1 < C::KS) frags(s + 1, (s + 1) & 1, i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- epilogue of the pass
+            constexpr int NOUT = C::POOL ? 1 : TB;
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) {
+                const int t = t0 + i0 + (C::POOL ? 0 : i), g = t / C::TPP, tt = t % C::TPP;
+                int px;
+                if constexpr (C::POOL) px = 16 * (tt >> 2) + n < C::NPOOL ? 16 * (tt >> 2) + n : -1;
+                else px = ((tt / (C::HO / 4)) * 4 + (n >> 2)) * C::HO + (tt % (C::HO / 4)) * 4 + (n & 3);
+                if (p + g >= a.n) px = -1;
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) {
+                    f32x4 v;
+                    if constexpr (C::POOL) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(fmaxf(acc[0][m][q], acc[1][m][q]), fmaxf(acc[2][m][q], acc[3][m][q]));
+                    } else v = acc[i][m];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] * c0 + bias[m][q], 0.f) * kSplitActScale;
+                    if (px < 0 || 16 * m + 4 * j >= C::COUT) continue;
+                    vmax = fmaxf(fmaxf(vmax, v[0]), v[1]); vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);
+                    f16x4 h, l;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { h[q] = (_Float16)v[q]; l[q] = (_Float16)(v[q] - (float)h[q]); }
+                    unsigned char* o = reinterpret_cast<unsigned char*>(a.out[tower]) + (size_t)(p + g) * 2 * C::OUT_B + px * C::OUT_PS + 2 * (16 * m + 4 * j);
+                    *reinterpret_cast<f16x4*>(o) = h;
+                    *reinterpret_cast<f16x4*>(o + C::OUT_B) = l;
+                }
+            }
+        }
+        if (p + step < a.n) {
+            SP_STASH(sp_smem + (size_t)(buf ^ 1) * BUF_B)
+            if (p + 2 * step < a.n) { SP_FETCH(p + 2 * step) }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (vmax > kSplitOverflow) atomicOr(a.flag, 1u);
+}
+
+using SpConv3 = SpCfg<20, 40, 14, false, 0, 4, 1>;     // 4 patch-towers per iteration: one per wave (9 tiles x 3 channel tiles)
+using SpConv4 = SpCfg<40, 40, 12, true, 0, 2, 1>;      // 2 per iteration: a wave owns one pooling group (4 tiles x 3 channel tiles)
+using SpConv5 = SpCfg<40, 60, 5, false, 1, 4, 2>;      // one wave per channel tile (conv_split_kernel)
+
+template <class C>
+inline hipError_t conv_split_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+}
+template <class C>
+inline hipError_t conv_split_all_set_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_split_all_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * C::LDS_BYTES));
+}
+
+template <class C>
+inline void conv_split_launch(const SplitArgs& a, hipStream_t st, int wgs_per_tower) {
+    const int units = (a.n + C::G - 1) / C::G;
+    const int g = wgs_per_tower < units ? wgs_per_tower : units;
+    if (g < 1) return;
+    hipLaunchKernelGGL(conv_split_kernel<C>, dim3(3 * g), dim3(C::NTH), C::LDS_BYTES, st, a);
+}
+template <class C>
+inline void conv_split_all_launch(const SplitArgs& a, hipStream_t st, int wgs_per_tower) {
+    const int units = (a.n + C::G - 1) / C::G;
+    const int g = wgs_per_tower < units ? wgs_per_tower : units;
+    if (g < 1) return;
+    hipLaunchKernelGGL(conv_split_all_kernel<C>, dim3(3 * g), dim3(256), 2 * C::LDS_BYTES, st, a);
 }
 
 }  // namespace scs

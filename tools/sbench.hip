@@ -29,94 +29,150 @@ static float pow2_scale(const std::vector<float>& w) {      // power of two s wi
 
 template <class T> static T* dev(const std::vector<T>& h) { T* d; CK(hipMalloc(&d, h.size() * sizeof(T))); CK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); return d; }
 
-static int bench_c12(int n) {
-    std::vector<float> in[3], w1[3], b1[3], w2[3], b2[3];
-    Split12Args a{};
-    a.n = n;
-    unsigned* flag; CK(hipMalloc(&flag, 4)); CK(hipMemset(flag, 0, 4));
-    a.flag = flag;
-    for (int t = 0; t < 3; ++t) {
-        in[t].resize((size_t)n * 1024); w1[t].resize(20 * 9); b1[t].resize(20); w2[t].resize(20 * 20 * 9); b2[t].resize(20);
-        for (auto& v : in[t]) v = gauss();
-        for (auto& v : w1[t]) v = 0.3f * gauss();
-        for (auto& v : b1[t]) v = 0.3f * gauss();
-        for (auto& v : w2[t]) v = 0.08f * gauss();
-        for (auto& v : b2[t]) v = 0.2f * gauss();
-        std::vector<float> w1p(kSp12W1Floats, 0.f);
-        for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int c = 0; c < 20; ++c) w1p[(4 * dy + dx) * 20 + c] = w1[t][c * 9 + dy * 3 + dx] * kSplitActScale;
-        for (int c = 0; c < 20; ++c) w1p[240 + c] = b1[t][c] * kSplitActScale;
-        const float sw = pow2_scale(w2[t]);
-        std::vector<unsigned short> pk((size_t)kSp12W2Vec * 8, 0);
-        for (int s = 0; s < 6; ++s) for (int m = 0; m < 2; ++m) for (int lane = 0; lane < 64; ++lane) for (int pos = 0; pos < 8; ++pos) {
-            const int r = lane & 15, j = lane >> 4, dy = s >> 1, half = s & 1, e = 8 * (4 * half + j) + sp_chunk_elem(j, pos), o = 16 * m + r;
-            float v = 0.f;
-            if (e < 60 && o < 20) v = w2[t][(o * 20 + e % 20) * 9 + dy * 3 + e / 20] * sw;
-            const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
-            pk[((((size_t)s * 2 + m) * 2 + 0) * 64 + lane) * 8 + pos] = h_bits(h);
-            pk[((((size_t)s * 2 + m) * 2 + 1) * 64 + lane) * 8 + pos] = h_bits(l);
-        }
-        a.in[t] = dev(in[t]); a.w1[t] = dev(w1p); a.w2[t] = reinterpret_cast<const uint4*>(dev(pk)); a.b2[t] = dev(b2[t]);
-        a.inv2[t] = 1.f / (kSplitActScale * sw);
-        float* o; CK(hipMalloc(&o, (size_t)n * 20 * 196 * 4)); CK(hipMemset(o, 0xFF, (size_t)n * 20 * 196 * 4));
-        a.out[t] = o;
+// split operands of a conv layer from its correlation weights wc[o][c][3][3]: [k-step][M tile][piece][lane] x 8 halves
+static std::vector<unsigned short> pack_split(const std::vector<float>& wc, int cin, int cout, float sw) {
+    const int KSR = (3 * cin + 31) / 32, KS = 3 * KSR, MT = (cout + 15) / 16;
+    std::vector<unsigned short> pk((size_t)KS * MT * 2 * 64 * 8, 0);
+    for (int s = 0; s < KS; ++s) for (int m = 0; m < MT; ++m) for (int lane = 0; lane < 64; ++lane) for (int pos = 0; pos < 8; ++pos) {
+        const int r = lane & 15, j = lane >> 4, dy = s / KSR, ks = s % KSR, e = 32 * ks + 8 * j + sp_chunk_elem(j, pos), o = 16 * m + r;
+        float v = 0.f;
+        if (e < 3 * cin && o < cout) v = wc[(o * cin + e % cin) * 9 + dy * 3 + e / cin] * sw;
+        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+        pk[((((size_t)s * MT + m) * 2 + 0) * 64 + lane) * 8 + pos] = h_bits(h);
+        pk[((((size_t)s * MT + m) * 2 + 1) * 64 + lane) * 8 + pos] = h_bits(l);
     }
-    CK(conv12_split_set_attr());
-    conv12_split_launch(a, nullptr);
+    return pk;
+}
+
+struct Layer { int cin, cout; std::vector<float> w, b; float sw; const uint4* d_w; const float* d_b; };
+static Layer make_layer(int cin, int cout, float wstd) {
+    Layer L; L.cin = cin; L.cout = cout; L.w.resize((size_t)cout * cin * 9); L.b.resize(cout);
+    for (auto& v : L.w) v = wstd * gauss();
+    for (auto& v : L.b) v = 0.2f * gauss();
+    L.sw = pow2_scale(L.w);
+    L.d_w = reinterpret_cast<const uint4*>(dev(pack_split(L.w, cin, cout, L.sw)));
+    const int MT = (cout + 15) / 16;
+    std::vector<float> bp(MT * 16 + 1, 0.f);
+    for (int c = 0; c < cout; ++c) bp[c] = L.b[c];
+    bp[MT * 16] = 1.f / (kSplitActScale * L.sw);
+    L.d_b = dev(bp);
+    return L;
+}
+// double-precision valid 3x3 correlation + bias + ReLU (+ 2x2 max-pool): in [cin][h][h] -> out [cout][ho][ho] or pooled
+static std::vector<double> conv_ref(const std::vector<double>& in, const Layer& L, int h, bool pool) {
+    const int ho = h - 2;
+    std::vector<double> z((size_t)L.cout * ho * ho);
+    for (int o = 0; o < L.cout; ++o) for (int y = 0; y < ho; ++y) for (int x = 0; x < ho; ++x) {
+        double s = L.b[o];
+        for (int c = 0; c < L.cin; ++c) for (int k = 0; k < 9; ++k) s += (double)L.w[(o * L.cin + c) * 9 + k] * in[(c * h + y + k / 3) * h + x + k % 3];
+        z[(o * ho + y) * ho + x] = s > 0 ? s : 0;
+    }
+    if (!pool) return z;
+    const int hp = ho / 2;
+    std::vector<double> q((size_t)L.cout * hp * hp);
+    for (int o = 0; o < L.cout; ++o) for (int y = 0; y < hp; ++y) for (int x = 0; x < hp; ++x) {
+        double m = 0;
+        for (int k = 0; k < 4; ++k) m = fmax(m, z[(o * ho + 2 * y + (k >> 1)) * ho + 2 * x + (k & 1)]);
+        q[(o * hp + y) * hp + x] = m;
+    }
+    return q;
+}
+
+template <class F>
+static float time_best(F f, int reps = 6) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0, nullptr)); f(); CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+    }
+    CK(hipGetLastError());
+    return best;
+}
+
+// the whole tower chain on the split: conv1+conv2+pool1 -> conv3 -> conv4+pool2 -> conv5 (f32 [n][540])
+static int bench_net(int n, bool c12_only) {
+    Layer L1[3], L2[3], L3[3], L4[3], L5[3];
+    std::vector<float> in[3];
+    Split12Args a12{}; SplitArgs a3{}, a4{}, a5{};
+    unsigned* flag; CK(hipMalloc(&flag, 4)); CK(hipMemset(flag, 0, 4));
+    a12.n = a3.n = a4.n = a5.n = n; a12.flag = a3.flag = a4.flag = a5.flag = flag;
+    float* out5[3]; float* out1f[3];
+    for (int t = 0; t < 3; ++t) {
+        in[t].resize((size_t)n * 1024);
+        for (auto& v : in[t]) v = gauss();
+        L1[t] = make_layer(1, 20, 0.3f); L2[t] = make_layer(20, 20, 0.08f); L3[t] = make_layer(20, 40, 0.08f);
+        L4[t] = make_layer(40, 40, 0.06f); L5[t] = make_layer(40, 60, 0.06f);
+        std::vector<float> w1p(kSp12W1Floats, 0.f);
+        for (int dy = 0; dy < 3; ++dy) for (int dx = 0; dx < 3; ++dx) for (int c = 0; c < 20; ++c) w1p[(4 * dy + dx) * 20 + c] = L1[t].w[c * 9 + dy * 3 + dx] * kSplitActScale;
+        for (int c = 0; c < 20; ++c) w1p[240 + c] = L1[t].b[c] * kSplitActScale;
+        a12.in[t] = dev(in[t]); a12.w1[t] = dev(w1p); a12.w2[t] = L2[t].d_w; a12.b2[t] = L2[t].d_b;
+        void *p1, *p3, *p4;
+        CK(hipMalloc(&p1, (size_t)n * 15680)); CK(hipMalloc(&p3, (size_t)n * 23040)); CK(hipMalloc(&p4, (size_t)n * 4000));
+        CK(hipMalloc(&out5[t], (size_t)n * 540 * 4)); CK(hipMalloc(&out1f[t], (size_t)n * 15680));
+        CK(hipMemset(out5[t], 0xFF, (size_t)n * 540 * 4));
+        a12.out[t] = p1;
+        a3.in[t] = (const unsigned char*)p1; a3.w[t] = L3[t].d_w; a3.bias[t] = L3[t].d_b; a3.out[t] = p3;
+        a4.in[t] = (const unsigned char*)p3; a4.w[t] = L4[t].d_w; a4.bias[t] = L4[t].d_b; a4.out[t] = p4;
+        a5.in[t] = (const unsigned char*)p4; a5.w[t] = L5[t].d_w; a5.bias[t] = L5[t].d_b; a5.out[t] = out5[t];
+    }
+    CK(conv12_split_set_attr()); CK(conv_split_all_set_attr<SpConv3>()); CK(conv_split_all_set_attr<SpConv4>()); CK(conv_split_set_attr<SpConv5>());
+    int g12 = 170, g3 = 85, g4 = 85, g5 = 170;
+    if (const char* e = getenv("SB_G")) sscanf(e, "%d,%d,%d,%d", &g12, &g3, &g4, &g5);
+    auto run_all = [&] {
+        conv12_split_launch<true>(a12, nullptr, g12);
+        if (c12_only) return;
+        conv_split_all_launch<SpConv3>(a3, nullptr, g3);
+        conv_split_all_launch<SpConv4>(a4, nullptr, g4);
+        conv_split_launch<SpConv5>(a5, nullptr, g5);
+    };
+    run_all();
     CK(hipDeviceSynchronize());
     unsigned hflag = 0; CK(hipMemcpy(&hflag, flag, 4, hipMemcpyDeviceToHost));
-    const int nchk = n < 4 ? n : 4;
-    double worst = 0, scale = 0, sum = 0; size_t cnt = 0;
-    std::vector<double> x1((size_t)20 * 900);
-    for (int t = 0; t < 3; ++t) {
-        std::vector<float> ho((size_t)nchk * 20 * 196);
-        // check the first and the last patches (the last ones come from late iterations of the persistent loop)
+    // f32-layout variant of conv1+conv2+pool1 for the error of that stage alone
+    Split12Args a12f = a12; for (int t = 0; t < 3; ++t) a12f.out[t] = out1f[t];
+    conv12_split_launch<false>(a12f, nullptr, g12);
+    CK(hipDeviceSynchronize());
+    const int nchk = n < 3 ? n : 3;
+    double w1e = 0, s1e = 0, w5e = 0, s5e = 0, sum5 = 0; size_t cnt5 = 0;
+    for (int t = 0; t < 3; ++t)
         for (int pass = 0; pass < 2; ++pass) {
             const int p0 = pass == 0 ? 0 : n - nchk;
-            CK(hipMemcpy(ho.data(), a.out[t] + (size_t)p0 * 20 * 196, ho.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<float> h1((size_t)nchk * 3920), h5((size_t)nchk * 540);
+            CK(hipMemcpy(h1.data(), out1f[t] + (size_t)p0 * 3920, h1.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(h5.data(), out5[t] + (size_t)p0 * 540, h5.size() * 4, hipMemcpyDeviceToHost));
             for (int p = 0; p < nchk; ++p) {
-                const float* x = in[t].data() + (size_t)(p0 + p) * 1024;
-                for (int c = 0; c < 20; ++c) for (int y = 0; y < 30; ++y) for (int xx = 0; xx < 30; ++xx) {
-                    double s = b1[t][c];
-                    for (int k = 0; k < 9; ++k) s += (double)w1[t][c * 9 + k] * (double)x[(y + k / 3) * 32 + xx + k % 3];
-                    x1[(c * 30 + y) * 30 + xx] = s > 0 ? s : 0;
-                }
-                for (int o = 0; o < 20; ++o) for (int wy = 0; wy < 14; ++wy) for (int wx = 0; wx < 14; ++wx) {
-                    double m = -1e300;
-                    for (int q = 0; q < 4; ++q) {
-                        const int y = 2 * wy + (q >> 1), xx = 2 * wx + (q & 1);
-                        double s = 0;
-                        for (int c = 0; c < 20; ++c) for (int k = 0; k < 9; ++k) s += (double)w2[t][(o * 20 + c) * 9 + k] * x1[(c * 30 + y + k / 3) * 30 + xx + k % 3];
-                        m = s > m ? s : m;
-                    }
-                    const double ref = m + b2[t][o] > 0 ? m + b2[t][o] : 0;
-                    const double d = fabs(ref - (double)ho[((size_t)p * 20 + o) * 196 + wy * 14 + wx]);
-                    worst = fmax(worst, d); scale = fmax(scale, fabs(ref)); sum += d; ++cnt;
-                }
+                std::vector<double> x(1024);
+                for (int i = 0; i < 1024; ++i) x[i] = in[t][(size_t)(p0 + p) * 1024 + i];
+                auto r1 = conv_ref(x, L1[t], 32, false);
+                auto r2 = conv_ref(r1, L2[t], 30, true);
+                for (size_t i = 0; i < r2.size(); ++i) { w1e = fmax(w1e, fabs(r2[i] - h1[(size_t)p * 3920 + i])); s1e = fmax(s1e, fabs(r2[i])); }
+                if (c12_only) continue;
+                auto r3 = conv_ref(r2, L3[t], 14, false);
+                auto r4 = conv_ref(r3, L4[t], 12, true);
+                auto r5 = conv_ref(r4, L5[t], 5, false);
+                for (size_t i = 0; i < r5.size(); ++i) { const double d = fabs(r5[i] - h5[(size_t)p * 540 + i]); w5e = fmax(w5e, d); s5e = fmax(s5e, fabs(r5[i])); sum5 += d; ++cnt5; }
             }
         }
-    }
-    printf("c12 split: n %d, overflow flag %u, max |err| %.3g, mean |err| %.3g, output scale %.3g (max err / scale %.3g)\n", n, hflag, worst, sum / cnt, scale, worst / scale);
-    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int g : {85, 128, 170, 171, 256, 341}) {
-        float best = 1e30f;
-        for (int i = 0; i < 6; ++i) {
-            CK(hipEventRecord(e0, nullptr));
-            conv12_split_launch(a, nullptr, g);
-            CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
-        }
-        CK(hipGetLastError());
-        const double flop = 2.0 * (162000.0 + 2822400.0) * 3.0 * n;
-        printf("c12 split: %d workgroups per tower: %d patches x 3 towers in %.3f ms = %.2f M patch-towers/s = %.1f f32-equivalent TFLOP/s\n",
-               g, n, best, 3.0 * n / (best * 1e-3) / 1e6, flop / (best * 1e-3) / 1e12);
-    }
+    printf("split towers: n %d, overflow flag %u | pool1: max |err| %.3g on scale %.3g (%.3g) | conv5 out: max |err| %.3g, mean %.3g on scale %.3g (max / scale %.3g)\n",
+           n, hflag, w1e, s1e, w1e / s1e, w5e, cnt5 ? sum5 / cnt5 : 0.0, s5e, s5e > 0 ? w5e / s5e : 0.0);
+    const float t12 = time_best([&] { conv12_split_launch<true>(a12, nullptr, g12); });
+    printf("conv1+conv2+pool1 (split out, %d wg/tower): %.3f ms per %d patches x 3 towers (f32 kernel: 4.44 ms per 25 000)\n", g12, t12, n);
+    if (c12_only) return 0;
+    const float t3 = time_best([&] { conv_split_all_launch<SpConv3>(a3, nullptr, g3); });
+    const float t4 = time_best([&] { conv_split_all_launch<SpConv4>(a4, nullptr, g4); });
+    const float t5 = time_best([&] { conv_split_launch<SpConv5>(a5, nullptr, g5); });
+    const float tall = time_best(run_all);
+    printf("conv3 (%d): %.3f ms (f32: 1.435) | conv4+pool2 (%d): %.3f ms (f32: 2.18) | conv5 (%d): %.3f ms (f32: 0.36) | all four launches: %.3f ms (f32: 8.4) per %d patches\n",
+           g3, t3, g4, t4, g5, t5, tall, n);
     return 0;
 }
 
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "c12";
     const int n = argc > 2 ? atoi(argv[2]) : 25000;
-    if (!strcmp(what, "c12")) return bench_c12(n);
+    if (!strcmp(what, "c12")) return bench_net(n, true);
+    if (!strcmp(what, "net")) return bench_net(n, false);
     printf("unknown bench %s\n", what);
     return 1;
 }

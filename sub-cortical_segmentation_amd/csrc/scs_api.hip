@@ -89,6 +89,58 @@ __global__ void pack_conv1_kernel(const float* __restrict__ W, const float* __re
     w1p[t] = v;
 }
 
+// ---- split operands (conv_split.h).  One workgroup per layer: weight scale = the power of two that puts max |folded weight| into
+// [2^12, 2^13), then every lane's 8 halves per (k-step, channel tile), high and low piece; bias [tiles * 16] + 1 / (act scale * weight scale)
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ W, const float* __restrict__ bn, int cin, int cout,
+                                                         uint4* __restrict__ wp, float* __restrict__ bias) {
+    __shared__ float s_red[256];
+    const int tid = threadIdx.x;
+    float mx = 0.f;
+    for (int e = tid; e < cout * cin * 9; e += 256) { const int n = e / (cin * 9); mx = fmaxf(mx, fabsf(W[e] * (bn[cout + n] * bn[3 * cout + n]))); }
+    s_red[tid] = mx;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) s_red[tid] = fmaxf(s_red[tid], s_red[tid + k]); __syncthreads(); }
+    mx = s_red[0];
+    int ex = 0;
+    if (mx > 0.f && mx < 3e38f) (void)frexpf(mx, &ex); else ex = 13;
+    const float sw = ldexpf(1.f, 13 - ex);
+    const int KSR = (3 * cin + 31) / 32, KS = 3 * KSR, MT = (cout + 15) / 16;
+    for (int idx = tid; idx < KS * MT * 64; idx += 256) {
+        const int lane = idx & 63, m = (idx >> 6) % MT, st = (idx >> 6) / MT, r = lane & 15, j = lane >> 4, dy = st / KSR, ks = st % KSR, o = 16 * m + r;
+        unsigned short hb[8], lb[8];
+        for (int pos = 0; pos < 8; ++pos) {
+            const int e = 32 * ks + 8 * j + sp_chunk_elem(j, pos);
+            float v = 0.f;
+            if (e < 3 * cin && o < cout) {
+                const int c = e % cin, dx = e / cin;
+                v = W[((o * cin + c) * 3 + (2 - dy)) * 3 + (2 - dx)];                 // true convolution -> correlation (as pack_conv_kernel)
+                v *= bn[cout + o] * bn[3 * cout + o];                                 // gamma * inv_std
+                v *= sw;
+            }
+            const _Float16 hh = (_Float16)v, ll = (_Float16)(v - (float)hh);
+            hb[pos] = __builtin_bit_cast(unsigned short, hh); lb[pos] = __builtin_bit_cast(unsigned short, ll);
+        }
+        wp[((st * MT + m) * 2 + 0) * 64 + lane] = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+        wp[((st * MT + m) * 2 + 1) * 64 + lane] = make_uint4(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16));
+    }
+    for (int n = tid; n < MT * 16; n += 256) bias[n] = n < cout ? bn[n] - bn[2 * cout + n] * bn[cout + n] * bn[3 * cout + n] : 0.f;
+    if (tid == 0) bias[MT * 16] = 1.f / (kSplitActScale * sw);
+}
+// conv1 for the transposed f32 MFMA form: [slot 4 dy + dx][20] + bias[20], both times the activation scale
+__global__ void pack_split1_kernel(const float* __restrict__ W, const float* __restrict__ bn, float* __restrict__ w1p) {
+    const int t = threadIdx.x;
+    if (t >= kSp12W1Floats) return;
+    float v = 0.f;
+    if (t < 240) {
+        const int slot = t / 20, c = t % 20, dy = slot >> 2, dx = slot & 3;
+        if (dx < 3) v = W[(c * 3 + (2 - dy)) * 3 + (2 - dx)] * (bn[20 + c] * bn[60 + c]) * kSplitActScale;
+    } else {
+        const int c = t - 240;
+        v = (bn[c] - bn[40 + c] * bn[20 + c] * bn[60 + c]) * kSplitActScale;
+    }
+    w1p[t] = v;
+}
+
 // dense: Wp[k][n] over [K4][NS] zero padded, bias padded to NS
 __global__ void pack_dense_kernel(const float* __restrict__ W, const float* __restrict__ b, int K, int N, int K4,
                                   int NS, float* __restrict__ wp, float* __restrict__ bp) {
@@ -370,6 +422,29 @@ static int alloc_packed(scs_ctx* h) {
     h->pk.fc1w = b + o_f1w; h->pk.fc1b = b + o_f1b;
     h->pk.fc2w = b + o_f2w; h->pk.fc2b = b + o_f2b;
     h->pk.outw = b + o_ow; h->pk.outb = b + o_ob;
+    // split operands
+    size_t so = 0;
+    auto stake = [&](size_t bytes) { size_t o = so; so += (bytes + 255) / 256 * 256; return o; };
+    size_t s_w1[kTowers], s_w[kTowers][kConvs], s_b[kTowers][kConvs];
+    for (int t = 0; t < kTowers; ++t) {
+        s_w1[t] = stake(kSp12W1Floats * 4);
+        for (int i = 1; i < kConvs; ++i) {
+            const int KS = 3 * ((3 * kCin[i] + 31) / 32), MT = (kCout[i] + 15) / 16;
+            s_w[t][i] = stake((size_t)KS * MT * 2 * 64 * 16); s_b[t][i] = stake((MT * 16 + 1) * 4);
+        }
+    }
+    SCS_HIP(hipMalloc(&h->sp_pack, so));
+    for (int t = 0; t < kTowers; ++t) {
+        h->sp.w1[t] = reinterpret_cast<const float*>(h->sp_pack + s_w1[t]);
+        for (int i = 1; i < kConvs; ++i) {
+            h->sp.w[t][i] = reinterpret_cast<const uint4*>(h->sp_pack + s_w[t][i]);
+            h->sp.bias[t][i] = reinterpret_cast<const float*>(h->sp_pack + s_b[t][i]);
+        }
+    }
+    SCS_HIP(hipMalloc(&h->sp_flag, sizeof(unsigned int)));
+    SCS_HIP(hipMemset(h->sp_flag, 0, sizeof(unsigned int)));
+    SCS_HIP(hipHostMalloc(&h->sp_flag_host, sizeof(unsigned int)));
+    *h->sp_flag_host = 0;
     return SCS_OK;
 }
 
@@ -385,6 +460,10 @@ int repack_inference(scs_ctx* h, hipStream_t st) {
                                kCout[i], 1, h->pk.convw[t][i], h->pk.convb[t][i]);
         hipLaunchKernelGGL(pack_dense_kernel, dim3(64), dim3(256), 0, st, P + T.d1W, P + T.d1b, kFlat, kD1, kFlat,
                            gemm_ns(kD1), h->pk.d1w[t], h->pk.d1b[t]);
+        hipLaunchKernelGGL(pack_split1_kernel, dim3(1), dim3(320), 0, st, P + T.convW[0], P + T.bn[0], const_cast<float*>(h->sp.w1[t]));
+        for (int i = 1; i < kConvs; ++i)
+            hipLaunchKernelGGL(pack_split_kernel, dim3(1), dim3(256), 0, st, P + T.convW[i], P + T.bn[i], kCin[i], kCout[i],
+                               const_cast<uint4*>(h->sp.w[t][i]), const_cast<float*>(h->sp.bias[t][i]));
     }
     hipLaunchKernelGGL(pack_dense_kernel, dim3(128), dim3(256), 0, st, P + H.fc1W, P + H.fc1b, kFC1, kFC1, kFC1,
                        gemm_ns(kFC1), h->pk.fc1w, h->pk.fc1b);
@@ -429,10 +508,39 @@ int ensure_workspace(scs_ctx* h, int need) {
 int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
                   int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev, const X0Src* x0,
-                  const int32_t* atlas_index) {
+                  const int32_t* atlas_index, bool split) {
     const PackedNet& pk = h->pk;
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     mark(0);
+    h->last_split = false;
+    if (split && ax && !x0 && !vol) {
+        // the towers on the f16 matrix cores (conv_split.h); activations between the launches are two f16 planes [pixel][channel]
+        // per patch-tower in the f32 path's buffers (same bytes per element); conv5 leaves f32 [n][540] for the head
+        Split12Args a12{};
+        a12.n = n; a12.flag = h->sp_flag;
+        const float* in3[kTowers] = {ax, co, sa};
+        for (int t = 0; t < kTowers; ++t) {
+            a12.in[t] = in3[t]; a12.w1[t] = h->sp.w1[t]; a12.w2[t] = h->sp.w[t][1]; a12.b2[t] = h->sp.bias[t][1]; a12.out[t] = h->a_pool1[t];
+        }
+        conv12_split_launch<true>(a12, st, 170);
+        mark(1);
+        SplitArgs sa3{}, sa4{}, sa5{};
+        sa3.n = sa4.n = sa5.n = n; sa3.flag = sa4.flag = sa5.flag = h->sp_flag;
+        for (int t = 0; t < kTowers; ++t) {
+            sa3.in[t] = reinterpret_cast<const unsigned char*>(h->a_pool1[t]); sa3.w[t] = h->sp.w[t][2]; sa3.bias[t] = h->sp.bias[t][2]; sa3.out[t] = h->a_conv3[t];
+            sa4.in[t] = reinterpret_cast<const unsigned char*>(h->a_conv3[t]); sa4.w[t] = h->sp.w[t][3]; sa4.bias[t] = h->sp.bias[t][3]; sa4.out[t] = h->a_pool2[t];
+            sa5.in[t] = reinterpret_cast<const unsigned char*>(h->a_pool2[t]); sa5.w[t] = h->sp.w[t][4]; sa5.bias[t] = h->sp.bias[t][4]; sa5.out[t] = h->a_conv5[t];
+        }
+        conv_split_all_launch<SpConv3>(sa3, st, 85);
+        mark(2);
+        conv_split_all_launch<SpConv4>(sa4, st, 85);
+        mark(3);
+        conv_split_launch<SpConv5>(sa5, st, 170);
+        mark(4);
+        h->last_split = true;
+        const float* c5s[kTowers] = {h->a_conv5[0], h->a_conv5[1], h->a_conv5[2]};
+        return forward_head(h, c5s, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, n, atlas_index);
+    }
     ConvArgs a{};
     a.n = n;
     // conv1 + conv2 + pool1
@@ -594,6 +702,10 @@ static int set_kernel_attrs() {
     SCS_HIP(conv_set_attr<CfgConv5>());
     SCS_HIP(conv345_fused_set_attr());
     SCS_HIP(conv_set_attr<CfgConv4NP>());
+    SCS_HIP(conv12_split_set_attr());
+    SCS_HIP(conv_split_all_set_attr<SpConv3>());
+    SCS_HIP(conv_split_all_set_attr<SpConv4>());
+    SCS_HIP(conv_split_set_attr<SpConv5>());
     SCS_HIP(gemm_set_attrs());
     return SCS_OK;
 }
@@ -631,6 +743,7 @@ int scs_create(int device, scs_handle* out) {
         o.tail_fused = env_int("SCS_TAIL_FUSED", -1);
         o.split_max_batch = env_int("SCS_SPLIT_MAX_BATCH", -1);
         o.fwd_fused = env_int("SCS_FWD_FUSED", -1);
+        o.fwd_split = env_int("SCS_FWD_SPLIT", -1);
         o.wgfin_early = env_int("SCS_WGFIN_EARLY", 1);
         o.c5_split = env_int("SCS_C5_SPLIT", -1);
         if (const char* e = getenv("SCS_WG_SLICES")) {
@@ -665,6 +778,9 @@ int scs_destroy(scs_handle h) {
     if (h->adam_m) (void)hipFree(h->adam_m);
     if (h->adam_v) (void)hipFree(h->adam_v);
     if (h->packed) (void)hipFree(h->packed);
+    if (h->sp_pack) (void)hipFree(h->sp_pack);
+    if (h->sp_flag) (void)hipFree(h->sp_flag);
+    if (h->sp_flag_host) (void)hipHostFree(h->sp_flag_host);
     if (h->ws) (void)hipFree(h->ws);
     if (h->dense_ws) (void)hipFree(h->dense_ws);
     if (h->dense_feat) (void)hipFree(h->dense_feat);
@@ -711,7 +827,7 @@ static int* option_slot(scs_ctx* h, const char* name) {
         {"dense_chain_max_batch", &o.dense_chain_max_batch}, {"c5_fused_max_batch", &o.c5_fused_max_batch},
         {"train_one_stream", &o.train_one_stream}, {"tail_side", &o.tail_side}, {"tail_fused", &o.tail_fused},
         {"split_max_batch", &o.split_max_batch},
-        {"fwd_fused", &o.fwd_fused},
+        {"fwd_fused", &o.fwd_fused}, {"fwd_split", &o.fwd_split}, {"split_fallbacks", &o.split_fallbacks},
         {"wgfin_early", &o.wgfin_early},
         {"c5_split", &o.c5_split},
         {"wg_slices_conv2", &o.wg_slices[0]}, {"wg_slices_conv3", &o.wg_slices[1]}, {"wg_slices_conv4", &o.wg_slices[2]},
@@ -794,6 +910,16 @@ static int balanced_chunk(int64_t n, int max_chunk) {
     return (int)(c > max_chunk ? max_chunk : c);
 }
 
+// behind the split kernels of a call: wait for the stream and read (and clear) the overflow flag: 1 = set, 0 = clean, < 0 = error
+static int split_overflowed(scs_ctx* h, hipStream_t st) {
+    SCS_HIP(hipMemcpyAsync(h->sp_flag_host, h->sp_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    SCS_HIP(hipStreamSynchronize(st));
+    if (*h->sp_flag_host == 0) return 0;
+    SCS_HIP(hipMemsetAsync(h->sp_flag, 0, sizeof(unsigned int), st));
+    ++h->opt.split_fallbacks;
+    return 1;
+}
+
 static int forward_common(scs_handle h, const float* ax, const float* co, const float* sa, const float* atlas,
                           const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
                           int64_t n, float* probs, int32_t* labels, void* stream) {
@@ -807,12 +933,21 @@ static int forward_common(scs_handle h, const float* ax, const float* co, const 
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
-    for (int64_t s = 0; s < n; s += step) {
-        const int m = (int)((n - s < step) ? (n - s) : step);
-        rc = forward_chunk(h, ax ? ax + s * 1024 : nullptr, co ? co + s * 1024 : nullptr, sa ? sa + s * 1024 : nullptr,
-                           atlas ? atlas + s * 15 : nullptr, vol, dx, dy, dz, centers ? centers + s * 3 : nullptr, atlas4d,
-                           m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, nullptr);
-        if (rc != SCS_OK) return rc;
+    // fwd_split: patch inputs run on the split kernels; the call then waits for the stream, reads the overflow flag and repeats
+    // the batch on the f32 kernels if a scaled activation left the f16 range (conv_split.h)
+    const bool split = h->opt.fwd_split > 0 && ax != nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool sp = split && pass == 0;
+        for (int64_t s = 0; s < n; s += step) {
+            const int m = (int)((n - s < step) ? (n - s) : step);
+            rc = forward_chunk(h, ax ? ax + s * 1024 : nullptr, co ? co + s * 1024 : nullptr, sa ? sa + s * 1024 : nullptr,
+                               atlas ? atlas + s * 15 : nullptr, vol, dx, dy, dz, centers ? centers + s * 3 : nullptr, atlas4d,
+                               m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, nullptr, nullptr, nullptr, sp);
+            if (rc != SCS_OK) return rc;
+        }
+        if (!sp) break;
+        rc = split_overflowed(h, st);
+        if (rc <= 0) return rc;                              // 0: clean; < 0: error; 1: repeat on the f32 kernels
     }
     return SCS_OK;
 }
@@ -996,7 +1131,8 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
     for (int64_t s = 0; s < n; s += step, ++c) {
         const int m = (int)((n - s < step) ? (n - s) : step);
         rc = forward_chunk(h, ax + s * 1024, co + s * 1024, sa + s * 1024, atlas + s * 15, nullptr, 0, 0, 0, nullptr, nullptr,
-                           m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, &ev[(size_t)c * 9]);
+                           m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, &ev[(size_t)c * 9], nullptr, nullptr,
+                           h->opt.fwd_split > 0);
         if (rc != SCS_OK) break;
     }
     if (rc == SCS_OK) {
@@ -1009,6 +1145,11 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
                 stage_ms[i] += ms;
             }
         *launches = nchunks;
+        if (h->opt.fwd_split > 0) {
+            const int ov = split_overflowed(h, st);
+            if (ov < 0) rc = ov;
+            else if (ov > 0) { set_error("scs_forward_profiled: a scaled activation left the f16 range of the split kernels (results void; scs_forward repeats such a batch on the f32 kernels)"); rc = SCS_ERR_STATE; }
+        }
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
@@ -1042,6 +1183,19 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
         SCS_ARG(count == 3 * n * per, "count does not match 3*n*per-patch size");
         for (int t = 0; t < kTowers; ++t)
             SCS_HIP(hipMemcpy(host_out + t * n * per, tow[t], n * per * sizeof(float), hipMemcpyDeviceToHost));
+        if (h->last_split && which <= 2) {
+            // the split forward left two f16 planes [pixel][channel] (hi, lo; times the activation scale) per patch-tower in the same
+            // bytes: back to f32 [channel][pixel]
+            const int ch = which == 0 ? 20 : 40, px = (int)per / ch;
+            std::vector<float> tmp(per);
+            for (size_t r = 0; r < 3 * n; ++r) {
+                const _Float16* hi = reinterpret_cast<const _Float16*>(host_out + r * per);
+                const _Float16* lo = hi + per;
+                for (int q = 0; q < px; ++q)
+                    for (int c = 0; c < ch; ++c) tmp[(size_t)c * px + q] = ((float)hi[q * ch + c] + (float)lo[q * ch + c]) / kSplitActScale;
+                memcpy(host_out + r * per, tmp.data(), per * sizeof(float));
+            }
+        }
     } else {
         SCS_ARG(count == n * per, "count does not match n*row size");
         SCS_HIP(hipMemcpy(host_out, single, n * per * sizeof(float), hipMemcpyDeviceToHost));

@@ -1,6 +1,7 @@
 // Per-instance state of libscs (opaque to callers: include/scs.h).
 #pragma once
 #include "conv_mfma.h"
+#include "conv_split.h"
 
 struct TrainWs;
 
@@ -21,6 +22,11 @@ struct scs_options {
     int wgfin_early = 1;             // SCS_WGFIN_EARLY: 0 = the conv3..5 partial-sum reduction at the END of the side stream (the round-3 order)
     int fwd_fused = -1;              // SCS_FWD_FUSED: 1 = inference conv3 -> conv4 + pool2 -> conv5 as one kernel per patch-tower, 2 = that kernel
                                      // storing the two intermediates too (scs_get_activation); default (-1, 0): three launches - they are faster
+    int fwd_split = -1;              // SCS_FWD_SPLIT: 1 = inference convolutions on the f16 matrix cores with every f32 operand as two f16 pieces
+                                     // (conv_split.h: f32-grade results, ~2x the f32-MFMA rate); scs_forward / scs_forward_profiled on patch inputs;
+                                     // the call then returns after the work has finished (it reads the overflow flag and, if a scaled activation
+                                     // left the f16 range, repeats the batch on the f32 kernels).  Default (-1, 0): the exact-f32 MFMA kernels
+    int split_fallbacks = 0;         // (counter, read with scs_get_option) batches repeated on the f32 kernels after such an overflow
 };
 
 struct scs_ctx {
@@ -45,6 +51,17 @@ struct scs_ctx {
     float* packed = nullptr;
     size_t packed_floats = 0;
     scs::PackedNet pk{};
+
+    // split (f16 x 2 pieces) inference operands: conv_split.h
+    unsigned char* sp_pack = nullptr;
+    struct SplitPacked {
+        const float* w1[scs::kTowers];                        // conv1: kSp12W1Floats
+        const uint4* w[scs::kTowers][scs::kConvs];            // i = 1..4: [k-step][channel tile][piece][lane] x 16 bytes
+        const float* bias[scs::kTowers][scs::kConvs];         // i = 1..4: [tiles * 16] folded bias + the accumulator scale
+    } sp{};
+    unsigned int* sp_flag = nullptr;           // overflow flag of the split kernels (device) ...
+    unsigned int* sp_flag_host = nullptr;      // ... and its pinned host copy
+    bool last_split = false;                   // the last forward left split planes in a_pool1 / a_conv3 / a_pool2
 
     // forward workspace (one chunk)
     int chunk = 32768;             // patches per internal chunk (workspace ~140 KB per patch)
@@ -83,7 +100,7 @@ int repack_inference(scs_ctx* h, hipStream_t st);
 int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
                   int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
-                  const X0Src* x0 = nullptr, const int32_t* atlas_index = nullptr);
+                  const X0Src* x0 = nullptr, const int32_t* atlas_index = nullptr, bool split = false);
 int forward_head(scs_ctx* h, const float* const c5[kTowers], const float* atlas, const float* vol, int dx, int dy, int dz,
                  const int32_t* centers, const float* atlas4d, int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
                  int atlas_rows, const int32_t* atlas_index);

@@ -1,0 +1,108 @@
+"""The split inference path (option fwd_split = 1: csrc/conv_split.h - convolutions on the f16 matrix cores, every f32 operand
+carried as two f16 pieces, f32 accumulation) against the float64 oracle AT THE SAME BARS as the exact-f32 path
+(tests/test_gpu_forward.py): probabilities within 1e-4, logits and per-layer activations within 2e-5 of their scale, labels exact
+outside the near-tie band - and against the f32 path itself.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold
+from oracle import np_oracle as O
+from test_gpu_forward import PROB_TOL, check_labels, run_forward
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def split(handle):
+    handle.set_option('fwd_split', 1)
+    handle.set_option('split_fallbacks', 0)
+    yield handle
+    handle.set_option('fwd_split', -1)
+
+
+@pytest.mark.parametrize('name', ['g1_random.npz', 'g2_volume.npz', 'g3_classes.npz', 'g4_ties.npz'])
+def test_golden_sets_on_the_split_path(handle, name):
+    g = gold(name)
+    n = g['ax'].shape[0]
+    p32, l32 = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+    lg32 = handle.get_activation(7, n * 16).reshape(n, 16)[:, :15]
+    handle.set_option('fwd_split', 1)
+    handle.set_option('split_fallbacks', 0)
+    try:
+        probs, labels = run_forward(handle, g['ax'], g['co'], g['sa'], g['atlas'])
+        logits = handle.get_activation(7, n * 16).reshape(n, 16)[:, :15]
+        assert handle.get_option('split_fallbacks') == 0        # the result below IS the split kernels'
+    finally:
+        handle.set_option('fwd_split', -1)
+    assert np.isfinite(probs).all()
+    err = np.abs(probs - g['probs']).max()
+    assert err < PROB_TOL, 'max |p - p_oracle| = %g' % err
+    assert np.abs(probs.sum(1) - 1).max() < 1e-5
+    check_labels(labels, g['probs'])
+    assert np.array_equal(labels, probs.argmax(1))
+    scale = max(1.0, float(np.abs(g['logits']).max()))
+    lerr = float(np.abs(logits - g['logits']).max())
+    lerr32 = float(np.abs(lg32 - g['logits']).max())
+    assert lerr <= 2e-5 * scale, 'max |logit - logit_oracle| = %g (scale %g)' % (lerr, scale)
+    print('%s: logit error vs the float64 oracle: split %.3g, exact-f32 path %.3g (scale %.3g); split vs f32 path: probabilities %.3g, '
+          'labels differing %d' % (name, lerr, lerr32, scale, np.abs(probs - p32).max(), int((labels != l32).sum())))
+    # the two device paths agree far inside the oracle bar
+    assert np.abs(probs - p32).max() < 2e-5
+    srt = np.sort(g['probs'], axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert np.array_equal(labels[clear], l32[clear])
+
+
+def test_per_layer_activations_on_the_split_path(split, weights):
+    g = gold('g2_volume.npz')
+    n = 24
+    args = [g[k][:n] for k in ('ax', 'co', 'sa', 'atlas')]
+    tr = {}
+    O.forward(weights, *args, trace=tr)
+    run_forward(split, *args)
+    towers = ('axial', 'coronal', 'saggital')
+
+    def close(got, ref, what):
+        scale = max(1.0, np.abs(ref).max())
+        err = np.abs(got - ref).max()
+        assert err <= 2e-5 * scale, '%s: max err %g (scale %g)' % (what, err, scale)
+
+    for which, key, per in ((0, 'pool1', 20 * 196), (1, 'conv3', 40 * 144), (2, 'pool2', 40 * 25), (3, 'conv5', 540)):
+        got = split.get_activation(which, 3 * n * per).reshape(3, n, -1)
+        for t, tn in enumerate(towers):
+            close(got[t], tr['%s_%s' % (tn, key)].reshape(n, -1), '%s_%s' % (tn, key))
+    logits = split.get_activation(7, n * 16).reshape(n, 16)
+    close(logits[:, :15], tr['logits'], 'logits')
+    assert split.get_option('split_fallbacks') == 0
+
+
+@pytest.mark.parametrize('n', [1, 3, 17, 700, 4099])
+def test_ragged_batches_on_the_split_path(handle, n):
+    """Persistent workgroups, 4 / 2 / 4 patch-towers per iteration in conv3 / conv4 / conv5: every remainder."""
+    rng = np.random.default_rng(n)
+    ax, co, sa = (rng.standard_normal((n, 1, 32, 32)).astype(np.float32) for _ in range(3))
+    at = rng.dirichlet(np.ones(15), n).astype(np.float32)
+    p32, l32 = run_forward(handle, ax, co, sa, at)
+    handle.set_option('fwd_split', 1)
+    handle.set_option('split_fallbacks', 0)
+    try:
+        probs, labels = run_forward(handle, ax, co, sa, at)
+        assert handle.get_option('split_fallbacks') == 0
+    finally:
+        handle.set_option('fwd_split', -1)
+    assert np.abs(probs - p32).max() < 2e-5
+    assert (labels != l32).sum() == 0 or np.abs(np.sort(p32, 1)[labels != l32, -1] - np.sort(p32, 1)[labels != l32, -2]).max() < 1e-5
+
+
+def test_out_of_range_activations_fall_back_to_the_f32_kernels(split):
+    """Activations are stored times 2^6 in f16 pieces: beyond |a| ~ 1000 a piece overflows.  The kernels flag it, the call repeats the
+    batch on the exact-f32 kernels: same bits as the f32 path, and the counter says so."""
+    g = gold('g1_random.npz')
+    big = 3.0e4
+    args = [g['ax'] * big, g['co'] * big, g['sa'] * big, g['atlas']]
+    probs, labels = run_forward(split, *args)
+    assert split.get_option('split_fallbacks') == 1
+    split.set_option('fwd_split', -1)
+    p32, l32 = run_forward(split, *args)
+    assert np.array_equal(probs, p32) and np.array_equal(labels, l32)

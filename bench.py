@@ -47,6 +47,8 @@ STAGE_MACS = [3 * (162000 + 2822400), 3 * 1036800, 3 * 1440000, 3 * 194400, 3 * 
 FWD_FLOP = 2 * sum(STAGE_MACS)                 # 35 407 800
 TRAIN_FLOP = 3 * FWD_FLOP                      # fwd + dgrad + wgrad
 PEAK_F32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+PEAK_F16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
+SPLIT_DTYPE = 'f32 operands as two f16 pieces each, three f16 MFMA products per multiply-add block, f32 accumulate (option fwd_split)'
 ALGO_BYTES_FWD = 3 * 4096 + 60 + 60            # patches + atlas in, probs out
 
 
@@ -513,6 +515,10 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-train-block', action='store_true', help='forward mode: skip the train_step block')
     ap.add_argument('--no-sustained', action='store_true', help='forward mode: skip the sustained block (>= 8 s forward, >= 3 s train)')
+    ap.add_argument('--dtype', choices=['f32', 'f16x2'], default='f32',
+                    help='forward mode: f32 = the exact-f32 MFMA kernels (the headline line); f16x2 = the split kernels (option fwd_split) as '
+                         'the line\'s value. The default line carries the split path as its "split" block either way')
+    ap.add_argument('--no-split', action='store_true', help='forward mode: skip the split block')
     ap.add_argument('--no-dice', action='store_true', help='forward mode: skip the dice block (full-size subject, GPU labels vs CPU port)')
     ap.add_argument('--train-steps', type=int, default=200, help='timed steps per batch size of the train_step block')
     ap.add_argument('--subjects', type=int, default=6, help='cohort mode: synthetic subjects per rank')
@@ -601,6 +607,8 @@ def main():
 
             def step():
                 h.forward(ax, co, sa, at, B, probs, labels, st)
+            if args.dtype == 'f16x2':
+                h.set_option('fwd_split', 1)
             workload = 'forward-only inference, synthetic 32x32x3-view float32 patches, batch %d per GPU (BASELINE configs[1])' % B
         else:
             # BASELINE configs[4], GPU stage only: one subject per GPU, gather-fused inference over a ~400 000-voxel ROI of a
@@ -643,7 +651,7 @@ def main():
         'value': value, 'unit': 'patches/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'dist_backend': backend,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32' if (args.mode != 'forward' or args.dtype == 'f32') else SPLIT_DTYPE, 'data': 'synthetic',
         'config': {'workload': workload, 'weights': 'miccai2012_v1 (shipped)', 'per_gpu_batch': B, 'chunk': chunk,
                    'parallelism': 'independent patch shards, no data-path collective' if args.mode != 'train'
                    else 'dp%d, one RCCL all-reduce of the 3.5 MB gradient arena per step' % world},
@@ -687,6 +695,55 @@ def main():
                                     'tflops': float(2.0 * macs[i] * B / (ms[i] * 1e-3) / 1e12) if ms[i] > 1e-3 else None}
                          for i in range(8) if macs[i] > 0}
         out['hbm_algorithmic_gbps'] = value / world * ALGO_BYTES_FWD / 1e9
+    if args.mode == 'forward' and args.dtype == 'f32' and not args.no_split:
+        # the same workload on the split kernels (csrc/conv_split.h), same contract (warm-up, K steps between barriers, max over
+        # ranks), its results compared with the f32 path's on the same inputs
+        p32, l32 = probs.clone(), labels.clone()
+        h.set_option('fwd_split', 1)
+        h.set_option('split_fallbacks', 0)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        sdt = dist.max_scalar(time.perf_counter() - t0)
+        sval = world * B * args.steps / sdt
+        if rank == 0:
+            sms, sl = h.forward_profiled(ax, co, sa, at, B, probs, labels, st)
+            sms2, _ = h.forward_profiled(ax, co, sa, at, B, probs, labels, st)
+            sms = (0.5 * (sms + sms2)).astype(np.float64)
+            sdom = int(np.argmax(sms))
+            sdur = float(sms[sdom]) / sl * 1e-3
+            sflop = 2.0 * STAGE_MACS[sdom] * B / sl
+            diff = (probs - p32).abs().max().item()
+            nd = int((labels != l32).sum().item())
+            srt = torch.sort(p32, dim=1).values
+            margin = (srt[:, -1] - srt[:, -2])
+            out['split'] = {
+                'value': sval, 'unit': 'patches/s', 'ms_per_step': 1e3 * sdt / args.steps, 'steps': args.steps, 'warmup': args.warmup,
+                'ratio_to_f32_line': sval / value, 'dtype': SPLIT_DTYPE,
+                'net_f32_equivalent_tflops': sval * FWD_FLOP / 1e12,
+                'vs_f32_path': {'max_abs_prob_diff': diff, 'labels_differ': nd,
+                                'labels_differ_max_f32_margin': float(margin[labels != l32].max().item()) if nd else 0.0,
+                                'batches_repeated_on_f32_kernels': h.get_option('split_fallbacks')},
+                'roofline': {'bound': 'mfma', 'kernel': STAGE_NAMES[sdom],
+                             'achieved': 3.0 * sflop / sdur / 1e12, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': 3.0 * sflop / sdur / 1e12 / PEAK_F16_TFLOPS,
+                             'achieved_f32_equivalent': sflop / sdur / 1e12, 'traffic': None,
+                             'note': 'algorithmic work of the split form = three f16 products per f32 multiply-add (padding of the 16-wide channel tiles '
+                                     'and 32-deep k blocks not counted); priced against the dense f16 MFMA peak',
+                             'launch_ms': sdur * 1e3, 'patches_per_launch': B / sl},
+                'stages': {STAGE_NAMES[i]: {'ms_per_step': float(sms[i]),
+                                            'f32_equivalent_tflops': float(2.0 * STAGE_MACS[i] * B / (sms[i] * 1e-3) / 1e12) if sms[i] > 1e-3 else None}
+                           for i in range(8)},
+            }
+        h.set_option('fwd_split', -1)
+        step()                                                              # probs / labels of the f32 path again
+        torch.cuda.synchronize()
     if args.mode == 'train' and rank == 0:
         for k in ('roofline', 'stages', 'launches_per_step', 'sum_of_launch_ms', 'train_step_ms', 'allreduce_ms', 'adam_ms',
                   'decomposition_note', 'per_rank_ms_per_step', 'update'):

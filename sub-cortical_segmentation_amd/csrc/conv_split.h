@@ -41,7 +41,9 @@ constexpr int kSp12W1Floats = 12 * 20 + 20;    // conv1 operands: [slot 4 dy + d
 constexpr int kSp12W2Vec = 6 * 2 * 2 * 64;     // conv2 operands: [k-step][M tile][piece][lane] x 16 bytes
 
 struct Split12Args {
-    const float* in[kTowers];     // [n][32][32]
+    const float* in[kTowers];     // [n][32][32]; VOL: in[0] = the z-scored volume [dimx][dimy][dimz], patches are cut around `centers`
+    const int32_t* centers;       // VOL: [n][3] centre voxels (tri-planar gather of base.py:293-306, zero padded)
+    int dimx, dimy, dimz;
     const float* w1[kTowers];     // kSp12W1Floats
     const uint4* w2[kTowers];     // kSp12W2Vec
     const float* b2[kTowers];     // [32] folded bias of conv2 (20 used), then one float: 1 / (kSplitActScale * weight scale of conv2), a power of two
@@ -117,7 +119,18 @@ __device__ __forceinline__ void sp12_store(unsigned char* op, int w, int j, f32x
 }
 
 // grid = 3 * G workgroups of 256 threads: workgroup b serves tower b % 3, patches b / 3, b / 3 + G, ...
-template <bool OUT_SPLIT>
+// one element of the tri-planar gather, zero padded (base.py:293-306): patch pixel (i, j) of `tower` around (cx, cy, cz):
+// axial [x-16+i][y-16+j][z], coronal [x-16+i][y][z-16+j], sagittal [x][y-16+i][z-16+j]  (as gather_voxel of conv_mfma.h)
+__device__ __forceinline__ float sp_gather(const float* __restrict__ vol, int dx, int dy, int dz, int tower, int cx, int cy, int cz, int i, int j) {
+    int vx, vy, vz;
+    if (tower == 0) { vx = cx - 16 + i; vy = cy - 16 + j; vz = cz; }
+    else if (tower == 1) { vx = cx - 16 + i; vy = cy; vz = cz - 16 + j; }
+    else { vx = cx; vy = cy - 16 + i; vz = cz - 16 + j; }
+    const bool ok = (unsigned)vx < (unsigned)dx && (unsigned)vy < (unsigned)dy && (unsigned)vz < (unsigned)dz;
+    return ok ? vol[((size_t)vx * dy + vy) * dz + vz] : 0.f;
+}
+
+template <bool OUT_SPLIT, bool VOL>
 __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     unsigned char* s_hi = sp_smem;
@@ -170,15 +183,23 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
         rs1 = x + 8 - 8 * (j & 1);
     }
     float vmax = 0.f;
-    const float* inp = a.in[tower];
+    const float* inp = VOL ? a.in[0] : a.in[tower];
     unsigned char* outp = reinterpret_cast<unsigned char*>(a.out[tower]);
+    auto load_x = [&](int p) -> float4 {                     // elements 4 tid .. 4 tid + 3 of patch p (row tid / 8, columns 4 (tid % 8) ..)
+        if constexpr (!VOL) return reinterpret_cast<const float4*>(inp + (size_t)p * 1024)[tid];
+        else {
+            const int cx = a.centers[3 * p], cy = a.centers[3 * p + 1], cz = a.centers[3 * p + 2], i = tid >> 3, j = 4 * (tid & 7);
+            return make_float4(sp_gather(inp, a.dimx, a.dimy, a.dimz, tower, cx, cy, cz, i, j), sp_gather(inp, a.dimx, a.dimy, a.dimz, tower, cx, cy, cz, i, j + 1),
+                               sp_gather(inp, a.dimx, a.dimy, a.dimz, tower, cx, cy, cz, i, j + 2), sp_gather(inp, a.dimx, a.dimy, a.dimz, tower, cx, cy, cz, i, j + 3));
+        }
+    };
     float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wg < a.n) xr = reinterpret_cast<const float4*>(inp + (size_t)wg * 1024)[tid];
+    if (wg < a.n) xr = load_x(wg);
     int it = 0;
     for (int p = wg; p < a.n; p += nwg, ++it) {
         reinterpret_cast<float4*>(s_x)[tid] = xr;
         __syncthreads();                                     // raw patch in place; every wave is done with the planes of the previous patch
-        if (p + nwg < a.n) xr = reinterpret_cast<const float4*>(inp + (size_t)(p + nwg) * 1024)[tid];
+        if (p + nwg < a.n) xr = load_x(p + nwg);
         // ---- conv1 on the f32 matrix cores: 60 tiles of 16 pixels over the 32-wide row domain (columns 30, 31 are not stored)
 #pragma unroll 3
         for (int tt = 0; tt < 15; ++tt) {
@@ -273,16 +294,18 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
 }
 
 inline hipError_t conv12_split_set_attr() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_split_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSp12LdsBytes);
 }
 
-template <bool OUT_SPLIT>
+template <bool OUT_SPLIT, bool VOL = false>
 inline void conv12_split_launch(const Split12Args& a, hipStream_t st, int wgs_per_tower = 170) {
     int g = wgs_per_tower < a.n ? wgs_per_tower : a.n;
     if (g < 1) return;
-    hipLaunchKernelGGL(conv12_split_kernel<OUT_SPLIT>, dim3(3 * g), dim3(256), kSp12LdsBytes, st, a);
+    hipLaunchKernelGGL((conv12_split_kernel<OUT_SPLIT, VOL>), dim3(3 * g), dim3(256), kSp12LdsBytes, st, a);
 }
 
 

@@ -513,16 +513,18 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     mark(0);
     h->last_split = false;
-    if (split && ax && !x0 && !vol) {
+    if (split && (ax || vol) && !x0) {
         // the towers on the f16 matrix cores (conv_split.h); activations between the launches are two f16 planes [pixel][channel]
         // per patch-tower in the f32 path's buffers (same bytes per element); conv5 leaves f32 [n][540] for the head
         Split12Args a12{};
         a12.n = n; a12.flag = h->sp_flag;
-        const float* in3[kTowers] = {ax, co, sa};
+        const float* in3[kTowers] = {vol ? vol : ax, co, sa};
         for (int t = 0; t < kTowers; ++t) {
             a12.in[t] = in3[t]; a12.w1[t] = h->sp.w1[t]; a12.w2[t] = h->sp.w[t][1]; a12.b2[t] = h->sp.bias[t][1]; a12.out[t] = h->a_pool1[t];
         }
-        conv12_split_launch<true>(a12, st, 170);
+        a12.centers = centers; a12.dimx = dx; a12.dimy = dy; a12.dimz = dz;
+        if (vol) conv12_split_launch<true, true>(a12, st, 170);          // patches cut inside the kernel (scs_forward_volume*)
+        else conv12_split_launch<true>(a12, st, 170);
         mark(1);
         SplitArgs sa3{}, sa4{}, sa5{};
         sa3.n = sa4.n = sa5.n = n; sa3.flag = sa4.flag = sa5.flag = h->sp_flag;
@@ -935,7 +937,7 @@ static int forward_common(scs_handle h, const float* ax, const float* co, const 
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
     // fwd_split: patch inputs run on the split kernels; the call then waits for the stream, reads the overflow flag and repeats
     // the batch on the f32 kernels if a scaled activation left the f16 range (conv_split.h)
-    const bool split = h->opt.fwd_split > 0 && ax != nullptr;
+    const bool split = h->opt.fwd_split > 0;
     for (int pass = 0; pass < 2; ++pass) {
         const bool sp = split && pass == 0;
         for (int64_t s = 0; s < n; s += step) {

@@ -106,3 +106,45 @@ def test_out_of_range_activations_fall_back_to_the_f32_kernels(split):
     split.set_option('fwd_split', -1)
     p32, l32 = run_forward(split, *args)
     assert np.array_equal(probs, p32) and np.array_equal(labels, l32)
+
+
+def test_gather_fused_volume_path_on_the_split_kernels_equals_their_patch_path(split):
+    """scs_forward_volume with fwd_split: the conv1 + conv2 + pool1 split kernel cuts the patches itself (tri-planar gather of
+    base.py:293-306, zero padded): the same bits as the split patch entry on the patches the literal restatement cut."""
+    from test_gpu_forward import dev
+    from oracle import patches_ref as R
+    g = gold('g2_volume.npz')
+    vol = R.zscore_inference(g['volume']).astype(np.float32)
+    probs, labels = run_forward(split, g['ax'], g['co'], g['sa'], g['atlas'])
+    n = g['centers'].shape[0]
+    d_pr = torch.empty((n, 15), device='cuda:0')
+    d_lb = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+    split.forward_volume(dev(vol), vol.shape, dev(g['centers'], torch.int32), dev(g['atlas4d']), n, d_pr, d_lb, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pr.cpu().numpy(), probs) and np.array_equal(d_lb.cpu().numpy(), labels)
+    assert np.abs(probs - g['probs']).max() < PROB_TOL
+    assert split.get_option('split_fallbacks') == 0
+
+
+def test_full_size_properties_on_the_split_path(split):
+    """BASELINE configs[1] size (100 000 patches) on the split kernels: rows sum to 1, a shuffled batch gives the shuffled result bit
+    for bit (persistent workgroups: a patch's result must not depend on which workgroup or iteration computed it), determinism."""
+    from cnn_cort import synth
+    from test_gpu_forward import dev
+    n = 100000
+    ax, co, sa, at = synth.patch_batch(n, seed=0)
+    d = [dev(a) for a in (ax, co, sa, at)]
+    st = torch.cuda.current_stream().cuda_stream
+    p1 = torch.empty((n, 15), device='cuda:0')
+    l1 = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+    split.forward(*d, n, p1, l1, st)
+    perm = torch.randperm(n, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(1))
+    p2 = torch.empty_like(p1)
+    l2 = torch.empty_like(l1)
+    split.forward(*[x[perm].contiguous() for x in d], n, p2, l2, st)
+    p3 = torch.empty_like(p1)
+    split.forward(*d, n, p3, None, st)
+    torch.cuda.synchronize()
+    assert torch.equal(p2, p1[perm]) and torch.equal(l2, l1[perm]) and torch.equal(p3, p1)
+    assert (p1.sum(1) - 1).abs().max().item() < 1e-5
+    assert split.get_option('split_fallbacks') == 0

@@ -31,9 +31,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SP_ABLATE
+#define SP_ABLATE 0          // tools/sbench timing experiments only (results are wrong when set): 1 conv1 stage only on a workgroup's first
+#endif                       // patch, 2 no conv2 MFMAs after the first k-step, 3 no stores, 4 no overflow tracking; conv_split_all_kernel:
+                             // 5 no staging after the first iteration, 6 no epilogue, 7 one k-step only, 8 no barrier
 constexpr float kSplitActScale = 64.f;         // activations are stored times 2^6 (overflow beyond |a| = 1023: flagged, see below)
 constexpr float kSplitOverflow = 60000.f;      // a scaled activation above this sets the launch's overflow flag
-constexpr int kSp12PlanePx = 904;              // conv1 plane: 30 x 30 pixels + 4 pad pixels (run overrun of the last rows)
+constexpr int kSp12PlanePx = 904;              // conv1 plane: 30 x 30 pixels + 4 pad pixels: the last runs overrun 8 bytes into the pad (kept zero);
+                                               // pad bytes 32.. are the dummy slot of the conv1 columns that do not exist
 constexpr int kSp12PlaneBytes = kSp12PlanePx * 40;
 constexpr int kSp12XFloats = 1024 + 64;        // raw patch + pad (tiles of the 32-wide domain read up to 2 rows + 3 past the end)
 constexpr size_t kSp12LdsBytes = 2 * (size_t)kSp12PlaneBytes + kSp12XFloats * 4;
@@ -58,14 +63,35 @@ __host__ __device__ constexpr int sp_run_dx(int e, int cin) { return e / cin; }
 
 // lane's element order inside its 16-byte chunk: lane groups with odd j hold the two 8-byte halves swapped
 __host__ __device__ constexpr int sp_chunk_elem(int j, int pos) { return (j & 1) ? (pos ^ 4) : pos; }
-
+// ReLU, overflow tracking and the two-piece split of four f32 values (channels 4j .. 4j+3 of one pixel) -> 8 + 8 bytes of the LDS planes.
+// ReLU as an integer max on the bits (no NaN canonicalisation); the low piece as ONE mixed-precision fma per value (f16 operand
+// widened inside the instruction: v_fma_mixlo / mixhi_f16), rounded to nearest like the high piece.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sp_relu(float x) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
+__device__ __forceinline__ void sp_split4(f32x4 v, f16x4& h, f16x4& l) {
+    const f16x2 h01 = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2), h23 = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
+    h = f16x4{h01[0], h01[1], h23[0], h23[1]};
+    // l = f16(v - h): v_fma_mix{lo,hi}_f16 take the f16 operand as it is (op_sel_hi) and round the f32 result once, to nearest -
+    // one instruction per value where the compiler's own selection is widen + packed subtract + narrow
+    const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(u01), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(u01), "v"(v[1]));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(u23), "v"(v[2]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(u23), "v"(v[3]));
+    const f16x2 a = __builtin_bit_cast(f16x2, l01), b = __builtin_bit_cast(f16x2, l23);
+    l = f16x4{a[0], a[1], b[0], b[1]};
+}
 __device__ __forceinline__ void sp_split4_store(f32x4 v, unsigned char* hi, unsigned char* lo, int off, float& vmax) {
-    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    vmax = fmaxf(fmaxf(vmax, v[0]), v[1]);
-    vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);
-    f16x4 h, l;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { h[i] = (_Float16)v[i]; l[i] = (_Float16)(v[i] - (float)h[i]); }
+    for (int i = 0; i < 4; ++i) v[i] = sp_relu(v[i]);
+    if (SP_ABLATE != 4) {
+        vmax = fmaxf(fmaxf(vmax, v[0]), v[1]);
+        vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);
+    }
+    f16x4 h, l;
+    sp_split4(v, h, l);
     *reinterpret_cast<f16x4*>(hi + off) = h;
     *reinterpret_cast<f16x4*>(lo + off) = l;
 }
@@ -94,16 +120,19 @@ __device__ __forceinline__ float sp_quad_max(float v) {
 // pooled pixel w of a patch-tower: channels 4 j .. 4 j + 3 (v0) and, from lane group 0, 16 .. 19 (v1)
 template <bool OUT_SPLIT>
 __device__ __forceinline__ void sp12_store(unsigned char* op, int w, int j, f32x4 v0, f32x4 v1, float& vmax) {
+    if (SP_ABLATE == 3 && v0[0] != 123.25f) return;
     if constexpr (OUT_SPLIT) {
         f16x4 h, l;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v0[i] *= kSplitActScale; h[i] = (_Float16)v0[i]; l[i] = (_Float16)(v0[i] - (float)h[i]); }
+        for (int i = 0; i < 4; ++i) v0[i] *= kSplitActScale;
+        sp_split4(v0, h, l);
         vmax = fmaxf(fmaxf(vmax, v0[0]), v0[1]); vmax = fmaxf(fmaxf(vmax, v0[2]), v0[3]);
         *reinterpret_cast<f16x4*>(op + w * 40 + 8 * j) = h;
         *reinterpret_cast<f16x4*>(op + 7840 + w * 40 + 8 * j) = l;
         if (j == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { v1[i] *= kSplitActScale; h[i] = (_Float16)v1[i]; l[i] = (_Float16)(v1[i] - (float)h[i]); }
+            for (int i = 0; i < 4; ++i) v1[i] *= kSplitActScale;
+            sp_split4(v1, h, l);
             vmax = fmaxf(fmaxf(vmax, v1[0]), v1[1]); vmax = fmaxf(fmaxf(vmax, v1[2]), v1[3]);
             *reinterpret_cast<f16x4*>(op + w * 40 + 32) = h;
             *reinterpret_cast<f16x4*>(op + 7840 + w * 40 + 32) = l;
@@ -201,21 +230,39 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
         __syncthreads();                                     // raw patch in place; every wave is done with the planes of the previous patch
         if (p + nwg < a.n) xr = load_x(p + nwg);
         // ---- conv1 on the f32 matrix cores: 60 tiles of 16 pixels over the 32-wide row domain (columns 30, 31 are not stored)
-#pragma unroll 3
-        for (int tt = 0; tt < 15; ++tt) {
-            const int T = wave + 4 * tt;
-            f32x4 d = b1m;
+        if (SP_ABLATE != 1 || it == 0) {
+        // five tiles at a time: their 15 operand reads, then the MFMAs of the five accumulators interleaved (a tile's three MFMAs
+        // depend on each other), then the five epilogues; columns 30, 31 of the 32-wide domain go to a dummy slot behind the planes
+#pragma unroll 1
+        for (int g5 = 0; g5 < 3; ++g5) {
+            float bx[5][3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], s_x[16 * T + n + j + 32 * s], d, 0, 0, 0);
-            const int y = T >> 1, x = 16 * (T & 1) + n;
-            if (x < 30) sp_split4_store(d, s_hi, s_lo, (y * 30 + x) * 40 + 8 * j, vmax);
+            for (int u = 0; u < 5; ++u)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) bx[u][s] = s_x[16 * (wave + 4 * (5 * g5 + u)) + n + j + 32 * s];
+            f32x4 d[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) d[u] = b1m;
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int u = 0; u < 5; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], bx[u][s], d[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int T = wave + 4 * (5 * g5 + u), y = T >> 1, x = 16 * (T & 1) + n;
+                sp_split4_store(d[u], s_hi, s_lo, x < 30 ? (y * 30 + x) * 40 + 8 * j : 900 * 40 + 32 + 8 * j, vmax);
+            }
         }
         for (int Q = wave; Q < 15; Q += 4) {
+            float bx[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bx[t] = s_x[64 * Q + lane + (t / 3) * 32 + t % 3];
             f32x4 d = b1r;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) d = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[t], s_x[64 * Q + lane + (t / 3) * 32 + t % 3], d, 0, 0, 0);
+            for (int t = 0; t < 9; ++t) d = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[t], bx[t], d, 0, 0, 0);
             const int pp = 64 * Q + lane, y = pp >> 5, x = pp & 31;
-            if (x < 30) sp_split4_store(d, s_hi, s_lo, (y * 30 + x) * 40 + 32, vmax);
+            sp_split4_store(d, s_hi, s_lo, x < 30 ? (y * 30 + x) * 40 + 32 : 900 * 40 + 64, vmax);
+        }
         }
         __syncthreads();                                     // planes complete
         // ---- conv2 on the f16 matrix cores
@@ -238,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
                 fh[0][q] = sp_frag(h0 + off, h1 + off); fl[0][q] = sp_frag(l0 + off, l1 + off);
             }
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
+            for (int s = 0; s < (SP_ABLATE == 2 ? 1 : 6); ++s) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -341,6 +388,26 @@ struct SpCfg {
     static_assert(32 * KSR - 3 * CIN_ <= 16 && 32 * KSR >= 3 * CIN_, "run padding stays inside the plane pad");
 };
 
+// pooled pixel (window) that lane n of pooling group k serves, -1: none
+template <class C>
+__device__ __forceinline__ int sp_window(int k, int n) {
+    const int w = 16 * k + n;
+    return w < C::NPOOL ? w : -1;
+}
+// byte offsets (inside an LDS plane) of the two 8-byte halves this lane reads for tile family k: its pixel, its lane group's
+// 16-byte chunk, odd lane groups in the opposite order (bank note at the top of the file).
+// (Measured and not kept: rows padded to 968 bytes with a window-to-lane partition that makes every conv4 read conflict-free, and a
+// 576-byte row / chunk order 0,2,1,3 for conv3 - no gain on either: the reads are not what these two kernels wait for.)
+template <class C>
+__device__ __forceinline__ void sp_lane_base(int k, int n, int j, int& rd0, int& rd1) {
+    int row, col;
+    if constexpr (C::POOL) { const int w = max(sp_window<C>(k, n), 0); row = 2 * (w / C::HP); col = 2 * (w % C::HP); }
+    else if constexpr (C::SMALL) { row = n < 9 ? n / 3 : 0; col = n < 9 ? n % 3 : 0; }
+    else { row = n >> 2; col = n & 3; }
+    const int x = row * C::RS + col * C::PS + 16 * j;
+    rd0 = x + 8 * (j & 1); rd1 = x + 8 - 8 * (j & 1);
+}
+
 struct SplitArgs {
     const unsigned char* in[kTowers];   // [n][2][IN_B]
     const uint4* w[kTowers];            // [KS][MT][2][64] x 16 bytes
@@ -374,18 +441,8 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
     const bool jvalid = 16 * m + 4 * j < C::COUT;
     // per-lane byte offset of this lane's pixel inside a tile family
     int rd0[C::POOL ? C::NGRP : 1], rd1[C::POOL ? C::NGRP : 1];
-    if constexpr (C::POOL) {
 #pragma unroll
-        for (int k = 0; k < C::NGRP; ++k) {
-            const int w = min(16 * k + n, C::NPOOL - 1), p0 = (2 * (w / C::HP)) * C::HIN + 2 * (w % C::HP);
-            const int x = C::PS * p0 + 16 * j;
-            rd0[k] = x + 8 * (j & 1); rd1[k] = x + 8 - 8 * (j & 1);
-        }
-    } else {
-        const int p0 = C::SMALL ? (n < 9 ? (n / 3) * C::HIN + n % 3 : 0) : (n >> 2) * C::HIN + (n & 3);
-        const int x = C::PS * p0 + 16 * j;
-        rd0[0] = x + 8 * (j & 1); rd1[0] = x + 8 - 8 * (j & 1);
-    }
+    for (int k = 0; k < (C::POOL ? C::NGRP : 1); ++k) sp_lane_base<C>(k, n, j, rd0[k], rd1[k]);
     float vmax = 0.f;
     const unsigned char* inp = a.in[tower];
     constexpr int SP_NTH = C::NTH, SP_PF = C::PF;
@@ -423,7 +480,7 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
                 const int g = t / C::TPP, tt = t % C::TPP;
                 int off = g * 2 * C::PLANE_B + soff, k = 0;
                 if constexpr (C::POOL) { k = tt >> 2; off += ((tt >> 1) & 1) * C::RS + (tt & 1) * C::PS; }
-                else if constexpr (!C::SMALL) off += ((tt / (C::HO / 4)) * 4 * C::HIN + (tt % (C::HO / 4)) * 4) * C::PS;
+                else if constexpr (!C::SMALL) off += (tt / (C::HO / 4)) * 4 * C::RS + (tt % (C::HO / 4)) * 4 * C::PS;
                 const unsigned char* h0 = sp_smem + rd0[k] + off;
                 const unsigned char* h1 = sp_smem + rd1[k] + off;
                 const f16x8 bh = sp_frag(h0, h1), bl = sp_frag(h0 + C::PLANE_B, h1 + C::PLANE_B);
@@ -445,7 +502,7 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
                     const f32x4* q = &acc[g * C::TPP + 4 * t];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(fmaxf(q[0][i], q[1][i]), fmaxf(q[2][i], q[3][i]));
-                    px = 16 * t + n < C::NPOOL ? 16 * t + n : -1;
+                    px = sp_window<C>(t, n);
                 } else {
                     v = acc[g * C::TPP + t];
                     if constexpr (C::SMALL) px = n < 9 ? n : -1;
@@ -459,8 +516,7 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
                     for (int i = 0; i < 4; ++i) v[i] *= kSplitActScale;
                     vmax = fmaxf(fmaxf(vmax, v[0]), v[1]); vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);
                     f16x4 h, l;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { h[i] = (_Float16)v[i]; l[i] = (_Float16)(v[i] - (float)h[i]); }
+                    sp_split4(v, h, l);
                     unsigned char* o = reinterpret_cast<unsigned char*>(a.out[tower]) + (size_t)(p + g) * 2 * C::OUT_B + px * C::OUT_PS + 2 * (16 * m + 4 * j);
                     *reinterpret_cast<f16x4*>(o) = h;
                     *reinterpret_cast<f16x4*>(o + C::OUT_B) = l;
@@ -510,16 +566,8 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
     // this wave's tiles: t = wave * TPW + i -> patch g = t / TPP, tile tt = t % TPP
     const int t0 = wave * TPW, g0 = t0 / C::TPP;
     int rd0, rd1;
-    if constexpr (C::POOL) {
-        const int k = (t0 % C::TPP) >> 2;
-        const int w = min(16 * k + n, C::NPOOL - 1), p0 = (2 * (w / C::HP)) * C::HIN + 2 * (w % C::HP);
-        const int x = C::PS * p0 + 16 * j + g0 * 2 * C::PLANE_B;
-        rd0 = x + 8 * (j & 1); rd1 = x + 8 - 8 * (j & 1);
-    } else {
-        const int p0 = (n >> 2) * C::HIN + (n & 3);
-        const int x = C::PS * p0 + 16 * j + g0 * 2 * C::PLANE_B;
-        rd0 = x + 8 * (j & 1); rd1 = x + 8 - 8 * (j & 1);
-    }
+    sp_lane_base<C>(C::POOL ? (t0 % C::TPP) >> 2 : 0, n, j, rd0, rd1);
+    rd0 += g0 * 2 * C::PLANE_B; rd1 += g0 * 2 * C::PLANE_B;
     float vmax = 0.f;
     const unsigned char* inp = a.in[tower];
     constexpr int SP_NTH = NTH, SP_PF = PF;
@@ -548,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
                 if constexpr (C::POOL) off += ((i >> 1) & 1) * C::RS + (i & 1) * C::PS;
                 else {
                     const int tt = (i0 + i) % C::TPP;
-                    off += ((i0 + i) / C::TPP) * 2 * C::PLANE_B + ((tt / (C::HO / 4)) * 4 * C::HIN + (tt % (C::HO / 4)) * 4) * C::PS;
+                    off += ((i0 + i) / C::TPP) * 2 * C::PLANE_B + (tt / (C::HO / 4)) * 4 * C::RS + (tt % (C::HO / 4)) * 4 * C::PS;
                 }
                 const unsigned char* h0 = base + rd0 + off;
                 const unsigned char* h1 = base + rd1 + off;
@@ -558,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
 #pragma unroll
             for (int i = 0; i < TB; ++i) frags(0, 0, i);
 #pragma unroll
-            for (int s = 0; s < C::KS; ++s) {
+            for (int s = 0; s < (SP_ABLATE == 7 ? 1 : C::KS); ++s) {
 #pragma unroll
                 for (int i = 0; i < TB; ++i) {
 #pragma unroll
@@ -577,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
             for (int i = 0; i < NOUT; ++i) {
                 const int t = t0 + i0 + (C::POOL ? 0 : i), g = t / C::TPP, tt = t % C::TPP;
                 int px;
-                if constexpr (C::POOL) px = 16 * (tt >> 2) + n < C::NPOOL ? 16 * (tt >> 2) + n : -1;
+                if constexpr (C::POOL) px = sp_window<C>(tt >> 2, n);
                 else px = ((tt / (C::HO / 4)) * 4 + (n >> 2)) * C::HO + (tt % (C::HO / 4)) * 4 + (n & 3);
                 if (p + g >= a.n) px = -1;
 #pragma unroll
@@ -590,21 +638,21 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] * c0 + bias[m][q], 0.f) * kSplitActScale;
                     if (px < 0 || 16 * m + 4 * j >= C::COUT) continue;
+                    if (SP_ABLATE == 6 && v[0] != 123.25f) continue;
                     vmax = fmaxf(fmaxf(vmax, v[0]), v[1]); vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);
                     f16x4 h, l;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { h[q] = (_Float16)v[q]; l[q] = (_Float16)(v[q] - (float)h[q]); }
+                    sp_split4(v, h, l);
                     unsigned char* o = reinterpret_cast<unsigned char*>(a.out[tower]) + (size_t)(p + g) * 2 * C::OUT_B + px * C::OUT_PS + 2 * (16 * m + 4 * j);
                     *reinterpret_cast<f16x4*>(o) = h;
                     *reinterpret_cast<f16x4*>(o + C::OUT_B) = l;
                 }
             }
         }
-        if (p + step < a.n) {
+        if (p + step < a.n && SP_ABLATE != 5) {
             SP_STASH(sp_smem + (size_t)(buf ^ 1) * BUF_B)
             if (p + 2 * step < a.n) { SP_FETCH(p + 2 * step) }
         }
-        __syncthreads();
+        if (SP_ABLATE != 8) __syncthreads();
         buf ^= 1;
     }
     if (vmax > kSplitOverflow) atomicOr(a.flag, 1u);

@@ -49,6 +49,8 @@ def load_options(user_config):
         options['augment'] = user_config.get('model', 'augment').strip()
     if user_config.has_option('model', 'seed'):
         options['seed'] = user_config.getint('model', 'seed')
+    if user_config.has_option('model', 'fwd_split'):
+        options['fwd_split'] = user_config.get('model', 'fwd_split').strip()      # 'True': inference on the split kernels (nets.py)
     return options
 
 

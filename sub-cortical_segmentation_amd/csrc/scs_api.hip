@@ -1100,11 +1100,21 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
             }
         }
         const Buf& d = buf[which];
-        rc = forward_chunk(h, d.ax, d.co, d.sa, d.at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d.pr, d.lb, sc, nullptr);
         hipError_t e = hipSuccess;
-        if (rc == SCS_OK && probs) e = hipMemcpyAsync(probs + s * 15, d.pr, m * 60, hipMemcpyDeviceToHost, sc);
-        if (rc == SCS_OK && e == hipSuccess && labels) e = hipMemcpyAsync(labels + s, d.lb, m * 4, hipMemcpyDeviceToHost, sc);
-        if (e == hipSuccess) e = hipStreamSynchronize(sc);
+        for (int pass = 0; pass < 2; ++pass) {
+            // fwd_split: the chunk on the split kernels first; its overflow flag comes back with the results, and a flagged chunk
+            // is repeated on the f32 kernels (conv_split.h)
+            const bool sp = h->opt.fwd_split > 0 && pass == 0;
+            rc = forward_chunk(h, d.ax, d.co, d.sa, d.at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d.pr, d.lb, sc, nullptr, nullptr, nullptr, sp);
+            if (rc == SCS_OK && sp) e = hipMemcpyAsync(h->sp_flag_host, h->sp_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, sc);
+            if (rc == SCS_OK && e == hipSuccess && probs) e = hipMemcpyAsync(probs + s * 15, d.pr, m * 60, hipMemcpyDeviceToHost, sc);
+            if (rc == SCS_OK && e == hipSuccess && labels) e = hipMemcpyAsync(labels + s, d.lb, m * 4, hipMemcpyDeviceToHost, sc);
+            if (e == hipSuccess) e = hipStreamSynchronize(sc);
+            if (rc != SCS_OK || e != hipSuccess || !sp || *h->sp_flag_host == 0) break;
+            e = hipMemsetAsync(h->sp_flag, 0, sizeof(unsigned int), sc);
+            ++h->opt.split_fallbacks;
+            if (e != hipSuccess) break;
+        }
         if (next.joinable()) next.join();
         if (inline_upload) upload(s + hstep, which ^ 1, &nerr);
         if (rc != SCS_OK) return rc;

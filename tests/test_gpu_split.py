@@ -148,3 +148,27 @@ def test_full_size_properties_on_the_split_path(split):
     assert torch.equal(p2, p1[perm]) and torch.equal(l2, l1[perm]) and torch.equal(p3, p1)
     assert (p1.sum(1) - 1).abs().max().item() < 1e-5
     assert split.get_option('split_fallbacks') == 0
+
+
+def test_net_predict_with_fwd_split_option(weights):
+    """options['fwd_split'] = 'True' -> build_model's Net runs predict / predict_proba on the split kernels, for NumPy inputs (the library's
+    double-buffered host entry, scs_forward_host) and for device tensors (scs_forward): labels of the f32 net, probabilities within 2e-5."""
+    import os
+    import tempfile
+    from cnn_cort import nets, params as P
+    g = gold('g3_classes.npz')
+    X = {'in1': g['ax'], 'in2': g['co'], 'in3': g['sa'], 'in4': g['atlas']}
+    with tempfile.TemporaryDirectory() as d:
+        opt = {'experiment': 'e', 'net_verbose': 0, 'train_split': 0.25, 'max_epochs': 1, 'patience': 1, 'patch_size': (32, 32),
+               'load_weights': 'False', 'device': 0}
+        n32 = nets.build_model(d, dict(opt))
+        n32.load_params_from(weights)
+        nsp = nets.build_model(d, dict(opt, fwd_split='True'))
+        nsp.load_params_from(weights)
+        p32, l32 = n32.predict_proba(X), n32.predict(X)
+        psp, lsp = nsp.predict_proba(X), nsp.predict(X)
+        assert nsp._handle.get_option('fwd_split') == 1 and nsp._handle.get_option('split_fallbacks') == 0
+        assert np.abs(psp - p32).max() < 2e-5 and np.array_equal(lsp, l32)
+        assert np.abs(psp - g['probs']).max() < PROB_TOL
+        Xd = {k: torch.from_numpy(np.ascontiguousarray(v)).to('cuda:0') for k, v in X.items()}
+        assert np.array_equal(nsp.predict(Xd), l32)

@@ -31,6 +31,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SP_ROWREUSE
+#define SP_ROWREUSE 1        // conv1+conv2+pool1: every LDS fragment of the conv2 stage read once for both window rows it serves (0: per tile and k-step)
+#endif
 #ifndef SP_ABLATE
 #define SP_ABLATE 0          // tools/sbench timing experiments only (results are wrong when set): 1 conv1 stage only on a workgroup's first
 #endif                       // patch, 2 no conv2 MFMAs after the first k-step, 3 no stores, 4 no overflow tracking; conv_split_all_kernel:
@@ -276,6 +279,39 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
             f32x4 acc[4][2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { acc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#if SP_ROWREUSE
+            // fragment f = 4 R + 2 half + column parity: pixel row R (0..3) of the windows' 4 x 2 pixels, read ONCE and used by the window
+            // row it serves as tap row R (output row 0) and as tap row R - 1 (output row 1): 16 fragment pairs per group instead of 24;
+            // three in flight
+            f16x8 fh[3], fl[3];
+            auto rdfrag = [&](int f) {
+                const int off = (f >> 2) * 1200 + (f & 1) * 40 + ((f >> 1) & 1) * 64;
+                fh[f % 3] = sp_frag(h0 + off, h1 + off); fl[f % 3] = sp_frag(l0 + off, l1 + off);
+            };
+            rdfrag(0); rdfrag(1);
+#pragma unroll
+            for (int f = 0; f < (SP_ABLATE == 2 ? 4 : 16); ++f) {
+                const int R = f >> 2, hh = (f >> 1) & 1, qc = f & 1;
+                if (f + 2 < 16) rdfrag(f + 2);
+                const f16x8 bh = fh[f % 3], bl = fl[f % 3];
+#pragma unroll
+                for (int piece = 0; piece < 3; ++piece) {
+#pragma unroll
+                    for (int use = 0; use < 2; ++use) {
+                        const int dy = R - use;
+                        if (dy < 0 || dy > 2) continue;
+                        const int s = 2 * dy + hh, q = 2 * use + qc;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            if (piece == 0) acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][m], bh, acc[q][m], 0, 0, 0);
+                            else if (piece == 1) acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bl, acc[q][m], 0, 0, 0);
+                            else acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bh, acc[q][m], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
             // fragments of k-step s + 1 are requested behind the MFMAs of the same tile of k-step s (at most 12 reads newer than the
             // one a tile waits for: the LDS counter has 4 bits)
             f16x8 fh[2][4], fl[2][4];
@@ -301,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#endif
             const int w = 16 * (wave + 4 * k) + n;
             f32x4 v0, v1;
 #pragma unroll

@@ -448,6 +448,7 @@ constexpr int kWgProblems = 6;
 struct WgGroupArgs {
     WgProblem p[kWgProblems]; int K;
     const float* loss_rows; float* loss_mean;      // one extra workgroup (blockIdx.z = kWgProblems): mean of the K per-row losses
+    const unsigned int* poison;                    // or null: a non-zero word turns the mean into NaN (option train_split: a value left the f16 range)
 };
 
 // Workgroup tile: 16 MT rows x 16 NT columns.  32 x 64 makes the six problems of the training step 405 workgroups - one
@@ -467,7 +468,10 @@ __global__ __launch_bounds__(256, 2) void dense_wgrad_kernel(WgGroupArgs g) {
         double* s_d = reinterpret_cast<double*>(s_r);
         if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = v;
         __syncthreads();
-        if (threadIdx.x == 0) g.loss_mean[0] = (float)(((s_d[0] + s_d[1]) + (s_d[2] + s_d[3])) / g.K);
+        if (threadIdx.x == 0) {
+            const bool bad = g.poison && *g.poison != 0u;
+            g.loss_mean[0] = bad ? __builtin_nanf("") : (float)(((s_d[0] + s_d[1]) + (s_d[2] + s_d[3])) / g.K);
+        }
         return;
     }
     WgProblem P = g.p[0];

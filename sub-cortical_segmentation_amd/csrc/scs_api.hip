@@ -746,6 +746,7 @@ int scs_create(int device, scs_handle* out) {
         o.split_max_batch = env_int("SCS_SPLIT_MAX_BATCH", -1);
         o.fwd_fused = env_int("SCS_FWD_FUSED", -1);
         o.fwd_split = env_int("SCS_FWD_SPLIT", -1);
+        o.train_split = env_int("SCS_TRAIN_SPLIT", -1);
         o.wgfin_early = env_int("SCS_WGFIN_EARLY", 1);
         o.c5_split = env_int("SCS_C5_SPLIT", -1);
         if (const char* e = getenv("SCS_WG_SLICES")) {
@@ -829,7 +830,7 @@ static int* option_slot(scs_ctx* h, const char* name) {
         {"dense_chain_max_batch", &o.dense_chain_max_batch}, {"c5_fused_max_batch", &o.c5_fused_max_batch},
         {"train_one_stream", &o.train_one_stream}, {"tail_side", &o.tail_side}, {"tail_fused", &o.tail_fused},
         {"split_max_batch", &o.split_max_batch},
-        {"fwd_fused", &o.fwd_fused}, {"fwd_split", &o.fwd_split}, {"split_fallbacks", &o.split_fallbacks},
+        {"fwd_fused", &o.fwd_fused}, {"fwd_split", &o.fwd_split}, {"split_fallbacks", &o.split_fallbacks}, {"train_split", &o.train_split},
         {"wgfin_early", &o.wgfin_early},
         {"c5_split", &o.c5_split},
         {"wg_slices_conv2", &o.wg_slices[0]}, {"wg_slices_conv3", &o.wg_slices[1]}, {"wg_slices_conv4", &o.wg_slices[2]},

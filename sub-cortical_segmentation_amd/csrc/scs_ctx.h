@@ -27,6 +27,9 @@ struct scs_options {
                                      // the call then returns after the work has finished (it reads the overflow flag and, if a scaled activation
                                      // left the f16 range, repeats the batch on the f32 kernels).  Default (-1, 0): the exact-f32 MFMA kernels
     int split_fallbacks = 0;         // (counter, read with scs_get_option) batches repeated on the f32 kernels after such an overflow
+    int train_split = -1;            // SCS_TRAIN_SPLIT: 1 = the training forward's conv1 + conv2 block on the f16 matrix cores with split operands
+                                     // (conv_split_train.h: f32-grade results; a scaled activation beyond the f16 range turns the step's loss into NaN);
+                                     // default (-1, 0): the exact-f32 MFMA kernel
 };
 
 struct scs_ctx {

@@ -34,6 +34,7 @@
 #include "scs_ctx.h"
 #include "wgrad_mfma.h"
 #include "train_cfg.h"
+#include "conv_split_train.h"
 
 namespace scs {
 
@@ -87,6 +88,11 @@ struct TrainWs {       // global namespace: forward-declared by scs_ctx.h
     float* l1p[kTowers]{};                     // [20][12]: flipped conv1 taps (9), sc, sh, pad
     float* l1m[kTowers]{};                     // [20][2]: mean, inv_std of conv1's batch statistics
     double* mom = nullptr;                     // [3][100] R (9x9), S (column 9), count
+    // option train_split (conv_split_train.h): conv1 operands of the transposed split form, raw conv2 weights as split pieces, accumulator scale
+    float* w1s[kTowers]{};                     // kSp12W1Floats (the dx = 3 slots stay zero)
+    uint4* w2s[kTowers]{};                     // kSp12W2Vec
+    float* inv2s[kTowers]{};                   // one float
+    unsigned int* split_flag = nullptr;        // set when a scaled activation left the f16 range (the step's loss is then NaN)
     bool tickets_dirty = false;                // a step failed between launches: the tickets are zeroed before the next one
     double* fin_grp = nullptr;                 // group records of the in-kernel finalize steps (inside `base`)
     unsigned long long* chain_stamps = nullptr; // diagnostic time stamps of dense_chain_kernel (SCS_CHAIN_STAMPS)
@@ -160,9 +166,12 @@ static int train_ensure(scs_ctx* h, int n) {
                 of[t][i] = off; off += al64(conv_pack_floats(i));
                 og[t][i] = off; off += al64((size_t)(kCout[i] / 4) * conv_chunk_floats(kCin[i]));
             }
+        size_t os2[kTowers];
+        for (int t = 0; t < kTowers; ++t) { os2[t] = off; off += al64((size_t)kSp12W2Vec * 4); }
         SCS_HIP(hipMalloc(&w->pack_base, off * sizeof(float)));
         for (int t = 0; t < kTowers; ++t)
             for (int i = 1; i < kConvs; ++i) { w->wpk[t][i] = w->pack_base + of[t][i]; w->wdg[t][i] = w->pack_base + og[t][i]; }
+        for (int t = 0; t < kTowers; ++t) w->w2s[t] = reinterpret_cast<uint4*>(w->pack_base + os2[t]);
         SCS_HIP(hipMalloc(&w->eval_acc, 2 * sizeof(double)));
         SCS_HIP(hipMalloc(&w->wT, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats + kTowers * kC5WcFloats) * sizeof(float)));
         SCS_HIP(hipMemset(w->wT, 0, (size_t)(270 * kTld + 540 * kTld + 3 * 180 * kTld + kW2Floats + kTowers * kC5WcFloats) * sizeof(float)));   // pad columns stay zero
@@ -182,6 +191,9 @@ static int train_ensure(scs_ctx* h, int n) {
             for (int i = 0; i < kConvs; ++i) { o_ss[t][i] = stake(128); o_lo[t][i] = stake(256); o_cf[t][i] = stake(256); }
             o_w1[t] = stake(kW1Floats + 4); o_l1[t] = stake(240); o_lm[t] = stake(40);
         }
+        size_t o_w1s[kTowers], o_i2[kTowers];
+        for (int t = 0; t < kTowers; ++t) { o_w1s[t] = stake(kSp12W1Floats); o_i2[t] = stake(4); }
+        const size_t o_sf = stake(4);
         SCS_HIP(hipMalloc(&w->small, so * sizeof(float)));
         SCS_HIP(hipMemset(w->small, 0, so * sizeof(float)));
         for (int t = 0; t < kTowers; ++t) {
@@ -191,7 +203,9 @@ static int train_ensure(scs_ctx* h, int n) {
                 w->cf4[t][i] = reinterpret_cast<float4*>(w->small + o_cf[t][i]);
             }
             w->w1p[t] = w->small + o_w1[t]; w->l1p[t] = w->small + o_l1[t]; w->l1m[t] = w->small + o_lm[t];
+            w->w1s[t] = w->small + o_w1s[t]; w->inv2s[t] = w->small + o_i2[t];
         }
+        w->split_flag = reinterpret_cast<unsigned int*>(w->small + o_sf);
         SCS_HIP(hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
         SCS_HIP(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
@@ -397,6 +411,7 @@ struct Bn1Args {
     Ptr3 w1p, l1p, l1m;
     unsigned int* counter;        // in-launch finalize: arrival tickets (FinArgs layout, fin_counter_words(units) words per tower), or null
     double* rec;                  // in-launch finalize: group records [tower][groups][128]
+    Ptr3 w1s;                     // option train_split: the same folded taps as [slot 4 dy + dx][20] + shift [20], times kSplitActScale (or null)
 };
 
 __device__ __forceinline__ void st_sc1(float* p, float v) {
@@ -438,6 +453,7 @@ __device__ __forceinline__ void bn1_final_body(const float* __restrict__ part, c
     float* const w1 = sel3(b.w1p.p, t);
     float* const l1 = sel3(b.l1p.p, t) + c * 12;
     float* const lm = sel3(b.l1m.p, t);
+    float* const w1s = sel3(b.w1s.p, t);
     float wr[9], b_beta = 0.f, b_gamma = 0.f, b_mean = 0.f, b_inv = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[k] = 0.f;
@@ -522,9 +538,11 @@ __device__ __forceinline__ void bn1_final_body(const float* __restrict__ part, c
         l1[k] = (float)wf[k];
         const float v = (float)wf[k] * sc;
         if (c < 16) w1[k * 16 + c] = v; else w1[192 + k * 4 + (c - 16)] = v;
+        if (w1s) w1s[(4 * (k / 3) + k % 3) * 20 + c] = v * kSplitActScale;
     }
     l1[9] = sc; l1[10] = sh; l1[11] = 0.f;
     w1[240 + c] = sh;
+    if (w1s) w1s[240 + c] = sh * kSplitActScale;
     lm[2 * c] = (float)mean; lm[2 * c + 1] = (float)inv;
 }
 
@@ -587,13 +605,20 @@ __device__ __forceinline__ void moments_body(const X0Src& x0, float* __restrict_
 // next kPrepWorkgroups the prep jobs (nothing in either half depends on the other; one launch instead of two on the
 // step's critical path.  The prep jobs on the side stream beside the moments was tried: the fork / join events cost more than
 // the 8 us the jobs take - 0.628 against 0.616 ms per step, profiles/r03_notes.txt).
-__global__ __launch_bounds__(256) void prep_moments_kernel(PrepArgs a, X0Src x0, float* __restrict__ mom_part, int n, int ppb, int units, Bn1Args b) {
+struct SplitPackJobs { const float* W[kTowers]; uint4* wp[kTowers]; float* inv[kTowers]; int cin, cout; unsigned int* flag; };   // option train_split: one workgroup per job, behind the prep jobs
+__global__ __launch_bounds__(256) void prep_moments_kernel(PrepArgs a, X0Src x0, float* __restrict__ mom_part, int n, int ppb, int units, Bn1Args b,
+                                                           SplitPackJobs sj) {
     const int bx = blockIdx.x - kTowers * units;
-    if (bx >= kPrepJobs * kPrepBlocks) prep_body(a, kPrepBigJob, bx - (kPrepJobs - 1) * kPrepBlocks);   // the big job's extra workgroups: blocks 64 ..
+    if (bx >= kPrepWorkgroups) {
+        __shared__ float s_red[256];
+        const int t = bx - kPrepWorkgroups;
+        if (t == 0 && threadIdx.x == 0) *sj.flag = 0u;          // this step's overflow flag (the loss-mean workgroup reads it)
+        pack_split_raw(sel3(sj.W, t), sj.cin, sj.cout, sel3(sj.wp, t), sel3(sj.inv, t), s_red);
+    } else if (bx >= kPrepJobs * kPrepBlocks) prep_body(a, kPrepBigJob, bx - (kPrepJobs - 1) * kPrepBlocks);   // the big job's extra workgroups: blocks 64 ..
     else if (bx >= 0) prep_body(a, bx / kPrepBlocks, bx % kPrepBlocks);
     else moments_body(x0, mom_part, n, ppb, units, (int)blockIdx.x / units, (int)blockIdx.x % units, b);
 }
-inline dim3 prep_moments_grid(int units) { return dim3(kPrepWorkgroups + kTowers * units); }
+inline dim3 prep_moments_grid(int units, int split_jobs = 0) { return dim3(kPrepWorkgroups + kTowers * units + split_jobs); }
 
 // The finalize as a launch of its own (batches beyond kBn1FusedMaxBatch): one workgroup per tower.
 __global__ __launch_bounds__(1024) void bn1_final_kernel(const float* __restrict__ part, int units, int n, Bn1Args b) {
@@ -1006,6 +1031,7 @@ static AdamCoef adam_coef(double t, float lr, float b1, float b2, float eps) {
 // dynamic-LDS attributes are per device: set them for the device of every handle that trains (cheap; once per handle)
 static int set_train_attrs(TrainWs* w, int device) {
     if (w->attr_device == device) return SCS_OK;
+    SCS_HIP(conv12_split_train_set_attr());
     SCS_HIP(conv_set_attr<TF12>()); SCS_HIP(conv_set_attr<TF3>()); SCS_HIP(conv_set_attr<TF4>()); SCS_HIP(conv_set_attr<TF5>());
     SCS_HIP(conv_set_attr<DG5>()); SCS_HIP(conv_set_attr<DG4>()); SCS_HIP(conv_set_attr<DG3>()); SCS_HIP(conv_set_attr<DG2>());
     SCS_HIP(conv_set_attr<TF3N>()); SCS_HIP(conv_set_attr<TF4N>()); SCS_HIP(conv_set_attr<DG5N>()); SCS_HIP(conv_set_attr<DG4N>());
@@ -1087,6 +1113,8 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
     // (option wgfin_early = 0 restores that order): 0.5547 -> 0.5449 ms at batch 256, 0.4131 -> 0.4035 at 128, same GPU
     const bool wgfin_early = opt.wgfin_early != 0;
     const bool adam_early = wgfin_early && tail_on_main;
+    // option train_split: the conv1 + conv2 block of the forward pass on the f16 matrix cores with split operands (conv_split_train.h)
+    const bool tsplit = opt.train_split > 0;
 
     w->prof = stage_ms != nullptr;
     if (w->prof) {
@@ -1136,12 +1164,20 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         // completes a tower's moments also finalizes conv1's batch statistics there (beside the prep jobs: no launch of its own on
         // the step's critical path); option bn1_fused_max_batch overrides the bound (0: always a launch; tests run both forms)
         Bn1Args b1{P, T0.convW[0], T0.bn[0], kTowerFloats, w->mom, Ptr3{{w->w1p[0], w->w1p[1], w->w1p[2]}}, Ptr3{{w->l1p[0], w->l1p[1], w->l1p[2]}},
-                   Ptr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, nullptr};
+                   Ptr3{{w->l1m[0], w->l1m[1], w->l1m[2]}}, nullptr, nullptr, Ptr3{}};
+        SplitPackJobs sj{};
+        if (tsplit) {
+            for (int t = 0; t < kTowers; ++t) {
+                b1.w1s.p[t] = w->w1s[t];
+                sj.W[t] = P + T0.convW[1] + t * kTowerFloats; sj.wp[t] = w->w2s[t]; sj.inv[t] = w->inv2s[t];
+            }
+            sj.cin = kCin[1]; sj.cout = kCout[1]; sj.flag = w->split_flag;
+        }
         const bool bn1_fused = n <= (opt.bn1_fused_max_batch >= 0 ? std::min(opt.bn1_fused_max_batch, w->cap) : kBn1FusedMaxBatch);
         if (bn1_fused) { b1.counter = w->fin_counter; b1.rec = w->fin_grp; }
         run(ST_PREP, st, [&] {
-            hipLaunchKernelGGL(prep_moments_kernel, prep_moments_grid(units1), dim3(256), 0, st, pa, x0, w->mom_part, n,
-                               ppb, units1, b1);
+            hipLaunchKernelGGL(prep_moments_kernel, prep_moments_grid(units1, tsplit ? kTowers : 0), dim3(256), 0, st, pa, x0, w->mom_part, n,
+                               ppb, units1, b1, sj);
         });
         if (!bn1_fused) run(ST_FIN1, st, [&] { hipLaunchKernelGGL(bn1_final_kernel, dim3(kTowers), dim3(1024), 0, st, w->mom_part, units1, n, b1); });
     }
@@ -1192,12 +1228,22 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
             a.fin.bn[t] = P + T0.bn[i] + t * kTowerFloats;
             a.fin.ss[t] = reinterpret_cast<float*>(w->ss[t][i]); a.fin.coef[t] = reinterpret_cast<float*>(w->low4[t][i]);
         }
-        const bool kFwdFin[kConvs] = {false, TF12::FIN != 0, TF3::FIN != 0 && fin_in_kernel, TF4::FIN != 0 && fin_in_kernel, TF5::FIN != 0};
-        if (i == 1) run(ST_CONV12, st, [&] { conv_launch<TF12>(a, st); });
+        const bool kFwdFin[kConvs] = {false, TF12::FIN != 0 || (tsplit && fin_in_kernel), TF3::FIN != 0 && fin_in_kernel, TF4::FIN != 0 && fin_in_kernel, TF5::FIN != 0};
+        if (i == 1 && tsplit) {
+            SplitTrain12Args sa{};
+            sa.x0 = x0; sa.n = n; sa.stats = w->stat_part; sa.flag = w->split_flag;
+            for (int t = 0; t < kTowers; ++t) {
+                sa.w1[t] = w->w1s[t]; sa.w2[t] = w->w2s[t]; sa.inv2[t] = w->inv2s[t];
+                sa.gamma2[t] = P + T0.bn[1] + t * kTowerFloats + kCout[1];
+                sa.out[t] = w->Z[t][1]; sa.pout[t] = w->ZP[t];
+            }
+            if (fin_in_kernel) sa.fin = a.fin;                    // the kernel's last workgroup finalizes BN2 (no launch of its own)
+            run(ST_CONV12, st, [&] { conv12_split_train_launch(sa, st); });
+        } else if (i == 1) run(ST_CONV12, st, [&] { conv_launch<TF12>(a, st); });
         else if (i == 2) run(ST_CONV3, st, [&] { if (split) conv_launch<TF3B>(a, st); else if (fin_in_kernel) conv_launch<TF3>(a, st); else conv_launch<TF3N>(a, st); });
         else if (i == 3) run(ST_CONV4, st, [&] { if (split) conv_launch<TF4B>(a, st); else if (fin_in_kernel) conv_launch<TF4>(a, st); else conv_launch<TF4N>(a, st); });
         else run(ST_CONV5, st, [&] { conv_launch<TF5>(a, st); });
-        const int units = n * kStatBands[i];
+        const int units = (i == 1 && tsplit) ? n : n * kStatBands[i];      // the split kernel leaves one statistics unit per patch-tower
         if (kFwdFin[i]) {
             // the conv kernel's last workgroup has already finalized this layer's statistics
         } else if (i < kConvs - 1) {
@@ -1300,6 +1346,7 @@ static int train_step_impl(scs_ctx* h, const X0Src& x0, const float* atlas, cons
         WgGroupArgs wg{};
         wg.K = n;
         wg.loss_rows = w->loss_rows; wg.loss_mean = w->loss_dev;
+        wg.poison = tsplit ? w->split_flag : nullptr;
         wg.p[0] = WgProblem{w->R2, kFC2ld, w->dlog, 16, G + H.outW, kClasses, G + H.outb, kFC2, kClasses};
         wg.p[1] = WgProblem{w->cat2, kFC1ld, w->dR2, kFC2ld, G + H.fc2W, kFC2, G + H.fc2b, kFC1 + kAtlas, kFC2};
         wg.p[2] = WgProblem{w->featd, kFlat, w->dcat, kFC1, G + H.fc1W, kFC1, G + H.fc1b, kFlat, kFC1};

@@ -1,0 +1,92 @@
+"""Option train_split on the MI355X: the training forward's convolutions on the f16 matrix cores with every f32 operand as two f16
+pieces (csrc/conv_split_train.h), at the bars of the f32-MFMA step: every gradient within 1e-4 of its array's scale of the float64
+oracle with the step's own ReLU / pooling decisions handed to the oracle's backward pass (tests/test_gpu_train.py), the raw conv
+outputs and the batch statistics the kernels leave against the f32 kernels' on the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+from cnn_cort import params as P
+from test_gpu_train import _step_against_gate_aware_oracle, dev, arena, fresh   # noqa: F401  (fresh: fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n', [1, 5, 37, 128, 129, 170, 255, 256, 257, 511])
+def test_split_training_step_at_ragged_batch_sizes(fresh, weights, n):
+    """scs_train_step with train_split = 1 against the oracle; 170 / 511: one and three patch-towers per persistent workgroup."""
+    fresh.set_option('train_split', 1)
+    worst, forced = _step_against_gate_aware_oracle(fresh, weights, n, 0)
+    print('train_split, n = %d: worst relative gradient error %.3g; decisions taken from the GPU: %r' % (n, worst, forced))
+
+
+@pytest.mark.parametrize('n', [5, 37])
+def test_split_training_step_on_random_draws(fresh, weights, n):
+    fresh.set_option('train_split', 1)
+    for draw in range(1, 6):
+        _step_against_gate_aware_oracle(fresh, weights, n, draw, stale_rows=False)
+
+
+@pytest.mark.parametrize('n', [5, 128])
+def test_split_pool1_follows_the_sign_of_gamma(fresh, weights, n):
+    """As test_pool1_taken_before_batch_norm_follows_the_sign_of_gamma: negated and zero gammas in the conv2 block."""
+    w = {k: [a.copy() for a in v] for k, v in weights.items()}
+    for tower in ('axial', 'coronal', 'saggital'):
+        name = [k for k in w if k.startswith(tower[:4]) and k.endswith('conv2_bn')]
+        gamma = w[name[0]][1]
+        gamma[::3] = -gamma[::3]
+        gamma[1] = 0.0
+    fresh.set_option('train_split', 1)
+    worst, forced = _step_against_gate_aware_oracle(fresh, w, n, 0)
+    print('train_split, n = %d, signed gammas: worst relative gradient error %.3g; %r' % (n, worst, forced))
+
+
+@pytest.mark.parametrize('n', [3, 64, 300])
+def test_split_forward_buffers_against_the_f32_kernels(weights, n):
+    """The buffers the forward pass leaves - raw conv2 output, the (scale, shift) of every block's batch norm, the loss and all
+    gradients - from the split form against the f32-MFMA form on the same batch: f32-grade agreement (2e-5 of each array's scale;
+    the two forms round differently, nothing more), and the split form is deterministic."""
+    from cnn_cort import _hip, synth
+    ax, co, sa, at = synth.patch_batch(n, seed=11 + n)
+    rng = np.random.RandomState(n)
+    y = rng.randint(0, 15, n).astype(np.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for form in ('f32', 'split', 'split2'):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        h.set_option('train_split', 0 if form == 'f32' else 1)
+        loss = h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=5, stream=st)
+        z2 = [h.get_train_buffer(100 + 10 * t + 2, n * 20 * 28 * 28).copy() for t in range(3)]
+        ss = [h.get_train_buffer(200 + 10 * t + i, 2 * c).copy() for t in range(3) for i, c in ((2, 20), (3, 40), (4, 40), (5, 60))]
+        out[form] = (loss, z2, ss, arena(h, 'grad'))
+        h.close()
+    assert np.isfinite(out['split'][0])
+    assert abs(out['split'][0] - out['f32'][0]) <= 1e-5 * max(1.0, abs(out['f32'][0]))
+    for a, b in zip(out['split'][1], out['f32'][1]):
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    for a, b in zip(out['split'][2], out['f32'][2]):
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    # bit-for-bit repeatable
+    assert out['split'][0] == out['split2'][0]
+    for a, b in zip(out['split'][1], out['split2'][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out['split'][3], out['split2'][3])
+
+
+def test_split_overflow_turns_the_loss_into_nan(weights):
+    """A conv1 activation beyond the f16 range of the scaled planes (|a| > 1023) cannot be represented by the split form: the step
+    must not return a plausible loss (conv_split_train.h: the patch-tower's outputs are poisoned)."""
+    from cnn_cort import _hip, synth
+    n = 8
+    ax, co, sa, at = synth.patch_batch(n, seed=3)
+    w = {k: [a.copy() for a in v] for k, v in weights.items()}
+    w['axial_ch_conv1_bn'][1][:] = 5000.0          # gamma: normalised activations times 5000
+    y = np.zeros(n, np.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    h = _hip.Handle(0)
+    h.set_params(P.params_to_flat(w))
+    h.set_option('train_split', 1)
+    loss = h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=5, stream=st)
+    h.close()
+    assert not np.isfinite(loss), loss

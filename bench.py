@@ -48,6 +48,8 @@ FWD_FLOP = 2 * sum(STAGE_MACS)                 # 35 407 800
 TRAIN_FLOP = 3 * FWD_FLOP                      # fwd + dgrad + wgrad
 PEAK_F32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 PEAK_F16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
+TRAIN_SPLIT_DTYPE = ('f32; the forward pass of the conv1 + conv2 block with f32 operands as two f16 pieces each, three f16 MFMA products per '
+                     'multiply-add block, f32 accumulate (option train_split); every other kernel on the exact-f32 MFMA')
 SPLIT_DTYPE = 'f32 operands as two f16 pieces each, three f16 MFMA products per multiply-add block, f32 accumulate (option fwd_split)'
 ALGO_BYTES_FWD = 3 * 4096 + 60 + 60            # patches + atlas in, probs out
 
@@ -594,6 +596,8 @@ def main():
     train_out = None
     if args.mode == 'train':
         B = args.batch or 256
+        if args.dtype == 'f16x2':
+            h.set_option('train_split', 1)
         train_out, train_step_fn = measure_train(torch, dist, h, B, args.steps, args.warmup, rank, world, dev, st, profile=True)
         value, dt_ms = train_out['value'], train_out['ms_per_step']
         flop_per_patch = TRAIN_FLOP
@@ -651,7 +655,7 @@ def main():
         'value': value, 'unit': 'patches/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'dist_backend': backend,
         'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': dt_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if (args.mode != 'forward' or args.dtype == 'f32') else SPLIT_DTYPE, 'data': 'synthetic',
+        'dtype': 'f32' if args.dtype == 'f32' or args.mode == 'volume' else (SPLIT_DTYPE if args.mode == 'forward' else TRAIN_SPLIT_DTYPE), 'data': 'synthetic',
         'config': {'workload': workload, 'weights': 'miccai2012_v1 (shipped)', 'per_gpu_batch': B, 'chunk': chunk,
                    'parallelism': 'independent patch shards, no data-path collective' if args.mode != 'train'
                    else 'dp%d, one RCCL all-reduce of the 3.5 MB gradient arena per step' % world},
@@ -761,9 +765,22 @@ def main():
                     r['net_frac_of_device_mfma_issue_rate'] = r['net_tflops'] / (issue * world)
                 blk['batch%d' % tb] = r
                 tstep, tms = stp, r['ms_per_step']
+            sblk = {}
+            if not args.no_split:
+                # the same steps with option train_split (csrc/conv_split_train.h): same contract, same batches
+                h.set_option('train_split', 1)
+                for tb in (128, 256):
+                    r, _ = measure_train(torch, dist, h, tb, args.train_steps, 20, rank, world, dev, st, profile=True)
+                    r['frac_of_f32_peak'] = r['net_frac_of_f32_peak']
+                    r['ratio_to_f32_step'] = blk['batch%d' % tb]['ms_per_step'] / r['ms_per_step']
+                    sblk['batch%d' % tb] = r
+                h.set_option('train_split', -1)
+                sblk['dtype'] = TRAIN_SPLIT_DTYPE
             if rank == 0:
                 out['train_step'] = dict(blk, metric='tri-view 32x32 patches/s (train step: scs_train_step + all-reduce + scs_adam_apply)',
                                          flop_per_patch=TRAIN_FLOP, dtype='f32', data='synthetic')
+                if sblk:
+                    out['train_step']['split'] = sblk
         if not args.no_sustained:
             sus = sustained_block(torch, dist, step, B, dt_ms, tstep, 256, tms, world)
             if rank == 0:

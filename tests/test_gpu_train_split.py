@@ -1,7 +1,9 @@
 """Option train_split on the MI355X: the training forward's convolutions on the f16 matrix cores with every f32 operand as two f16
 pieces (csrc/conv_split_train.h), at the bars of the f32-MFMA step: every gradient within 1e-4 of its array's scale of the float64
 oracle with the step's own ReLU / pooling decisions handed to the oracle's backward pass (tests/test_gpu_train.py), the raw conv
-outputs and the batch statistics the kernels leave against the f32 kernels' on the same inputs."""
+outputs and the batch statistics the kernels leave against the f32 kernels' on the same inputs.  The option covers the conv1 + conv2
+block (conv12_split_train_kernel); conv3 / conv4 in the same form were built, passed these tests and were slower than the f32-MFMA
+kernels (tools/experiments/conv_split_train34.h, profiles/NOTES_r05.md)."""
 import numpy as np
 import pytest
 import torch
@@ -12,9 +14,11 @@ from test_gpu_train import _step_against_gate_aware_oracle, dev, arena, fresh   
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('n', [1, 5, 37, 128, 129, 170, 255, 256, 257, 511])
+@pytest.mark.parametrize('n', [1, 2, 5, 37, 128, 129, 170, 255, 256, 257, 340, 341, 511, 700])
 def test_split_training_step_at_ragged_batch_sizes(fresh, weights, n):
-    """scs_train_step with train_split = 1 against the oracle; 170 / 511: one and three patch-towers per persistent workgroup."""
+    """scs_train_step with train_split = 1 against the oracle; the sizes cross the grid's switch - one workgroup per patch-tower up to
+    256, 160 persistent ones beyond - and the in-kernel finalize's slices (257 .. 511: several rounds of units per workgroup;
+    700: beyond fin_max_batch = 512 the statistics are finalized by the launch of their own)."""
     fresh.set_option('train_split', 1)
     worst, forced = _step_against_gate_aware_oracle(fresh, weights, n, 0)
     print('train_split, n = %d: worst relative gradient error %.3g; decisions taken from the GPU: %r' % (n, worst, forced))
@@ -57,14 +61,14 @@ def test_split_forward_buffers_against_the_f32_kernels(weights, n):
         h.set_params(P.params_to_flat(weights))
         h.set_option('train_split', 0 if form == 'f32' else 1)
         loss = h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=5, stream=st)
-        z2 = [h.get_train_buffer(100 + 10 * t + 2, n * 20 * 28 * 28).copy() for t in range(3)]
+        z2 = [h.get_train_buffer(100 + 10 * t + i, n * c * ho * ho).copy() for t in range(3) for i, c, ho in ((2, 20, 28), (3, 40, 12), (4, 40, 10), (5, 60, 3))]
         ss = [h.get_train_buffer(200 + 10 * t + i, 2 * c).copy() for t in range(3) for i, c in ((2, 20), (3, 40), (4, 40), (5, 60))]
         out[form] = (loss, z2, ss, arena(h, 'grad'))
         h.close()
     assert np.isfinite(out['split'][0])
     assert abs(out['split'][0] - out['f32'][0]) <= 1e-5 * max(1.0, abs(out['f32'][0]))
-    for a, b in zip(out['split'][1], out['f32'][1]):
-        assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    for k, (a, b) in enumerate(zip(out['split'][1], out['f32'][1])):             # raw outputs of conv2 .. conv5 of every tower
+        assert np.abs(a - b).max() <= (2e-6 if k % 4 == 0 else 1e-5) * np.abs(b).max(), (k, np.abs(a - b).max() / np.abs(b).max())
     for a, b in zip(out['split'][2], out['f32'][2]):
         assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
     # bit-for-bit repeatable

@@ -50,7 +50,8 @@ PEAK_F32_TFLOPS = 157.3                        # MI355X_MICROARCH.md: fp32 vecto
 PEAK_F16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 TRAIN_SPLIT_DTYPE = ('f32; the forward pass of the conv1 + conv2 block with f32 operands as two f16 pieces each, three f16 MFMA products per '
                      'multiply-add block, f32 accumulate (option train_split); every other kernel on the exact-f32 MFMA')
-SPLIT_DTYPE = 'f32 operands as two f16 pieces each, three f16 MFMA products per multiply-add block, f32 accumulate (option fwd_split)'
+SPLIT_DTYPE = ('f32 operands as two f16 pieces each, three f16 MFMA products per multiply-add block, f32 accumulate (option fwd_split: '
+               'conv2..conv5 and the dense head d1 / FC1 / fc_2; conv1 and the 270 x 15 out layer in exact f32)')
 ALGO_BYTES_FWD = 3 * 4096 + 60 + 60            # patches + atlas in, probs out
 
 

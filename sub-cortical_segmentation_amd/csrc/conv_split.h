@@ -449,7 +449,10 @@ struct SplitArgs {
     const unsigned char* in[kTowers];   // [n][2][IN_B]
     const uint4* w[kTowers];            // [KS][MT][2][64] x 16 bytes
     const float* bias[kTowers];         // [MT * 16] folded bias, then one float: 1 / (kSplitActScale * weight scale), a power of two
-    void* out[kTowers];                 // OUTF 0: [n][2][OUT_B] planes; OUTF 1: f32 [n][COUT][HO][HO]
+    void* out[kTowers];                 // OUTF 0: [n][2][OUT_B] planes; OUTF 1: f32 [n][COUT][HO][HO]; OUTF 2: rows of the split dense head
+                                        // (dense_split.h): [n] x (4 * out_kp + 16) bytes, feature = channel * OUT_PX + pixel (the flatten order
+                                        // of nets.py:178): high halves, low halves at + 2 * out_kp bytes, values times kSplitActScale
+    int out_kp;                         // OUTF 2: halves per piece of a row
     int n;
     unsigned int* flag;
 };
@@ -557,6 +560,15 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
                     unsigned char* o = reinterpret_cast<unsigned char*>(a.out[tower]) + (size_t)(p + g) * 2 * C::OUT_B + px * C::OUT_PS + 2 * (16 * m + 4 * j);
                     *reinterpret_cast<f16x4*>(o) = h;
                     *reinterpret_cast<f16x4*>(o + C::OUT_B) = l;
+                } else if constexpr (C::OUTF == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] *= kSplitActScale;
+                    vmax = fmaxf(fmaxf(vmax, v[0]), v[1]); vmax = fmaxf(fmaxf(vmax, v[2]), v[3]);
+                    f16x4 h, l;
+                    sp_split4(v, h, l);
+                    _Float16* o = reinterpret_cast<_Float16*>(reinterpret_cast<unsigned char*>(a.out[tower]) + (size_t)(p + g) * (4 * a.out_kp + 16)) + (16 * m + 4 * j) * C::OUT_PX + px;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { o[i * C::OUT_PX] = h[i]; o[a.out_kp + i * C::OUT_PX] = l[i]; }
                 } else {
                     float* o = reinterpret_cast<float*>(a.out[tower]) + (size_t)(p + g) * C::COUT * C::OUT_PX + (16 * m + 4 * j) * C::OUT_PX + px;
 #pragma unroll
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
             }
         }
     }
-    if (C::OUTF == 0 && vmax > kSplitOverflow) atomicOr(a.flag, 1u);
+    if (C::OUTF != 1 && vmax > kSplitOverflow) atomicOr(a.flag, 1u);
 }
 
 // ---- the same layers with ALL output tiles per wave: one wave per SIMD (512 registers), every wave holds the weights of all MT
@@ -698,6 +710,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
 using SpConv3 = SpCfg<20, 40, 14, false, 0, 4, 1>;     // 4 patch-towers per iteration: one per wave (9 tiles x 3 channel tiles)
 using SpConv4 = SpCfg<40, 40, 12, true, 0, 2, 1>;      // 2 per iteration: a wave owns one pooling group (4 tiles x 3 channel tiles)
 using SpConv5 = SpCfg<40, 60, 5, false, 1, 4, 2>;      // one wave per channel tile (conv_split_kernel)
+using SpConv5R = SpCfg<40, 60, 5, false, 2, 4, 2>;     // the same, leaving rows of the split dense head
 
 template <class C>
 inline hipError_t conv_split_set_attr() {

@@ -180,6 +180,39 @@ __global__ void atlas_gather_kernel(const float* __restrict__ atlas4d, const int
     dst[15] = 0.f;
 }
 
+// the same two for the split dense head (dense_split.h): columns 540..554 of fc_2's input rows as high / low halves times kSplitActScale
+__device__ __forceinline__ void atlas_row_split(const float (&v)[15], unsigned char* __restrict__ rows, int row) {
+    _Float16* hi = reinterpret_cast<_Float16*>(rows + (size_t)row * ds_row_bytes(kDsKpFC2)) + kFC1;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) {
+        const float x = v[c] * kSplitActScale;
+        const _Float16 hh = (_Float16)x;
+        hi[c] = hh; hi[kDsKpFC2 + c] = (_Float16)(x - (float)hh);
+    }
+}
+__global__ void atlas_concat_split_kernel(const float* __restrict__ atlas, const int32_t* __restrict__ index, int n_rows, unsigned char* __restrict__ rows, int n) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int src = index ? max(0, min(index[row], n_rows - 1)) : row;
+    float v[15];
+#pragma unroll
+    for (int c = 0; c < 15; ++c) v[c] = atlas[(size_t)src * 15 + c];
+    atlas_row_split(v, rows, row);
+}
+__global__ void atlas_gather_split_kernel(const float* __restrict__ atlas4d, const int32_t* __restrict__ centers,
+                                          int dx, int dy, int dz, unsigned char* __restrict__ rows, int n) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int x = centers[row * 3], y = centers[row * 3 + 1], z = centers[row * 3 + 2];
+    const bool inside = (unsigned)x < (unsigned)dx && (unsigned)y < (unsigned)dy && (unsigned)z < (unsigned)dz;
+    const float* src = atlas4d + (inside ? (((size_t)x * dy + y) * dz + z) * 15 : 0);
+    float v[15], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) { v[c] = inside ? src[c] : 0.f; s += v[c]; }     // (as atlas_gather_kernel: base.py:388-394)
+    if (s == 0.f) v[14] = 1.f;
+    atlas_row_split(v, rows, row);
+}
+
 // out_layer (270 -> 15) + softmax + argmax, one lane per patch row (4 050 MACs per row: 0.02 % of the net).
 __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ fc2, const float* __restrict__ wout /*[270][16]*/,
                                                       const float* __restrict__ bout /*[16]*/, int n,
@@ -425,13 +458,17 @@ static int alloc_packed(scs_ctx* h) {
     // split operands
     size_t so = 0;
     auto stake = [&](size_t bytes) { size_t o = so; so += (bytes + 255) / 256 * 256; return o; };
-    size_t s_w1[kTowers], s_w[kTowers][kConvs], s_b[kTowers][kConvs];
+    size_t s_w1[kTowers], s_w[kTowers][kConvs], s_b[kTowers][kConvs], s_dw[5], s_db[5];
     for (int t = 0; t < kTowers; ++t) {
         s_w1[t] = stake(kSp12W1Floats * 4);
         for (int i = 1; i < kConvs; ++i) {
             const int KS = 3 * ((3 * kCin[i] + 31) / 32), MT = (kCout[i] + 15) / 16;
             s_w[t][i] = stake((size_t)KS * MT * 2 * 64 * 16); s_b[t][i] = stake((MT * 16 + 1) * 4);
         }
+    }
+    for (int l = 0; l < 5; ++l) {
+        const int KS = l == 4 ? DsFC2::KS : DsK17::KS, MT = l < 3 ? kDsD1Tiles : (l == 3 ? kDsFC1Tiles : kDsFC2Tiles);
+        s_dw[l] = stake((size_t)KS * MT * 2 * 64 * 16); s_db[l] = stake((MT * 16 + 1) * 4);
     }
     SCS_HIP(hipMalloc(&h->sp_pack, so));
     for (int t = 0; t < kTowers; ++t) {
@@ -440,6 +477,10 @@ static int alloc_packed(scs_ctx* h) {
             h->sp.w[t][i] = reinterpret_cast<const uint4*>(h->sp_pack + s_w[t][i]);
             h->sp.bias[t][i] = reinterpret_cast<const float*>(h->sp_pack + s_b[t][i]);
         }
+    }
+    for (int l = 0; l < 5; ++l) {
+        h->sp.dw[l] = reinterpret_cast<const uint4*>(h->sp_pack + s_dw[l]);
+        h->sp.db[l] = reinterpret_cast<const float*>(h->sp_pack + s_db[l]);
     }
     SCS_HIP(hipMalloc(&h->sp_flag, sizeof(unsigned int)));
     SCS_HIP(hipMemset(h->sp_flag, 0, sizeof(unsigned int)));
@@ -471,6 +512,16 @@ int repack_inference(scs_ctx* h, hipStream_t st) {
                        kFC1ld, gemm_ns(kFC2), h->pk.fc2w, h->pk.fc2b);
     hipLaunchKernelGGL(pack_dense_kernel, dim3(8), dim3(256), 0, st, P + H.outW, P + H.outb, kFC2, kClasses, kFC2, 16,
                        h->pk.outw, h->pk.outb);
+    // the dense head's split operands (dense_split.h)
+    for (int t = 0; t < kTowers; ++t) {
+        const TowerOff T = tower_off(t * kTowerFloats);
+        hipLaunchKernelGGL(pack_dense_split_kernel, dim3(1), dim3(256), 0, st, P + T.d1W, P + T.d1b, kFlat, kD1, DsK17::KS, kDsD1Tiles,
+                           const_cast<uint4*>(h->sp.dw[t]), const_cast<float*>(h->sp.db[t]));
+    }
+    hipLaunchKernelGGL(pack_dense_split_kernel, dim3(1), dim3(256), 0, st, P + H.fc1W, P + H.fc1b, kFC1, kFC1, DsK17::KS, kDsFC1Tiles,
+                       const_cast<uint4*>(h->sp.dw[3]), const_cast<float*>(h->sp.db[3]));
+    hipLaunchKernelGGL(pack_dense_split_kernel, dim3(1), dim3(256), 0, st, P + H.fc2W, P + H.fc2b, kFC1 + kAtlas, kFC2, DsFC2::KS, kDsFC2Tiles,
+                       const_cast<uint4*>(h->sp.dw[4]), const_cast<float*>(h->sp.db[4]));
     SCS_HIP(hipGetLastError());
     return SCS_OK;
 }
@@ -484,6 +535,7 @@ int ensure_workspace(scs_ctx* h, int need) {
     if (h->ws && h->ws_chunk >= need) return SCS_OK;
     SCS_HIP(hipDeviceSynchronize());                       // a previous call may still be using the old buffers
     if (h->ws) { SCS_HIP(hipFree(h->ws)); h->ws = nullptr; }
+    if (h->r_base) { SCS_HIP(hipFree(h->r_base)); h->r_base = nullptr; }
     if (h->stage_dev) { SCS_HIP(hipFree(h->stage_dev)); h->stage_dev = nullptr; h->stage_floats = 0; }
     const size_t c = (size_t)need;
     size_t off = 0;
@@ -499,8 +551,53 @@ int ensure_workspace(scs_ctx* h, int need) {
         h->a_pool2[t] = h->ws + o2[t]; h->a_conv5[t] = h->ws + o5[t];
     }
     h->a_feat = h->ws + of; h->a_fc1 = h->ws + o_fc1; h->a_fc2 = h->ws + o_fc2; h->a_logits = h->ws + o_lg;
+    {   // rows of the split dense head: zero once (pads and K padding are never written afterwards)
+        const size_t rb17 = (size_t)ds_row_bytes(DsK17::KP), rb18 = (size_t)ds_row_bytes(DsFC2::KP);
+        const size_t tot = c * (4 * rb17 + rb18);
+        SCS_HIP(hipMalloc(&h->r_base, tot));
+        SCS_HIP(hipMemset(h->r_base, 0, tot));
+        for (int t = 0; t < kTowers; ++t) h->r_c5[t] = h->r_base + (size_t)t * c * rb17;
+        h->r_feat = h->r_base + 3 * c * rb17;
+        h->r_fc1 = h->r_base + 4 * c * rb17;
+    }
     h->ws_chunk = need;
     h->last_n = 0;
+    return SCS_OK;
+}
+
+// ----------------------------------------------------------------------------- the fusion head on the split kernels
+// d1 x3 -> FC1 -> [FC1 | atlas] -> fc_2 on dense_split.h's kernels (rows of halves between the layers), then the f32 out layer +
+// softmax + argmax as in forward_head; the towers' block-5 rows are in h->r_c5; marks 5..8 of the profiled forward.
+static int forward_head_split(scs_ctx* h, const float* atlas, const float* vol, int dx, int dy, int dz, const int32_t* centers,
+                              const float* atlas4d, int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
+                              int atlas_rows, const int32_t* atlas_index) {
+    auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
+    DenseSplitArgs d{};
+    d.n = n; d.flag = h->sp_flag;
+    d.mt_total = kDsD1Tiles; d.nfb = 1; d.kp_out = DsK17::KP;
+    for (int t = 0; t < kTowers; ++t) {
+        d.in[t] = h->r_c5[t]; d.w[t] = h->sp.dw[t]; d.bias[t] = h->sp.db[t]; d.out[t] = h->r_feat;
+        d.col0[t] = t * kD1; d.n_store[t] = t == kTowers - 1 ? kD1 + (DsK17::KP - kFC1) : kD1;      // the last tower also clears FC1's K padding
+    }
+    dense_split_launch<DsK17>(d, kTowers, st);
+    mark(5);
+    d.mt_total = kDsFC1Tiles; d.nfb = 3; d.kp_out = DsFC2::KP;
+    d.in[0] = h->r_feat; d.w[0] = h->sp.dw[3]; d.bias[0] = h->sp.db[3]; d.out[0] = h->r_fc1; d.col0[0] = 0; d.n_store[0] = DsFC2::KP;
+    dense_split_launch<DsK17>(d, 1, st);
+    if (vol && atlas4d)
+        hipLaunchKernelGGL(atlas_gather_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->r_fc1, n);
+    else
+        hipLaunchKernelGGL(atlas_concat_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas, atlas_index, atlas_rows, h->r_fc1, n);
+    mark(6);
+    d.mt_total = kDsFC2Tiles; d.nfb = 3; d.ld_out = kFC2ld;
+    d.in[0] = h->r_fc1; d.w[0] = h->sp.dw[4]; d.bias[0] = h->sp.db[4]; d.out[0] = h->a_fc2; d.col0[0] = 0; d.n_store[0] = kFC2ld;
+    dense_split_launch<DsFC2>(d, 1, st);
+    mark(7);
+    hipLaunchKernelGGL(head_out_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->a_fc2, h->pk.outw, h->pk.outb, n,
+                       h->a_logits, probs, labels);
+    mark(8);
+    SCS_HIP(hipGetLastError());
+    h->last_n = n;
     return SCS_OK;
 }
 
@@ -513,6 +610,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     mark(0);
     h->last_split = false;
+    h->last_split_head = false;
     if (split && (ax || vol) && !x0) {
         // the towers on the f16 matrix cores (conv_split.h); activations between the launches are two f16 planes [pixel][channel]
         // per patch-tower in the f32 path's buffers (same bytes per element); conv5 leaves f32 [n][540] for the head
@@ -537,9 +635,16 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
         mark(2);
         conv_split_all_launch<SpConv4>(sa4, st, 85);
         mark(3);
-        conv_split_launch<SpConv5>(sa5, st, 170);
+        const bool shead = h->opt.split_head != 0;
+        if (shead) {
+            for (int t = 0; t < kTowers; ++t) sa5.out[t] = h->r_c5[t];
+            sa5.out_kp = DsK17::KP;
+            conv_split_launch<SpConv5R>(sa5, st, 170);
+        } else conv_split_launch<SpConv5>(sa5, st, 170);
         mark(4);
         h->last_split = true;
+        h->last_split_head = shead;
+        if (shead) return forward_head_split(h, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, n, atlas_index);
         const float* c5s[kTowers] = {h->a_conv5[0], h->a_conv5[1], h->a_conv5[2]};
         return forward_head(h, c5s, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, n, atlas_index);
     }
@@ -708,6 +813,9 @@ static int set_kernel_attrs() {
     SCS_HIP(conv_split_all_set_attr<SpConv3>());
     SCS_HIP(conv_split_all_set_attr<SpConv4>());
     SCS_HIP(conv_split_set_attr<SpConv5>());
+    SCS_HIP(conv_split_set_attr<SpConv5R>());
+    SCS_HIP(dense_split_set_attr<DsK17>());
+    SCS_HIP(dense_split_set_attr<DsFC2>());
     SCS_HIP(gemm_set_attrs());
     return SCS_OK;
 }
@@ -747,6 +855,7 @@ int scs_create(int device, scs_handle* out) {
         o.fwd_fused = env_int("SCS_FWD_FUSED", -1);
         o.fwd_split = env_int("SCS_FWD_SPLIT", -1);
         o.train_split = env_int("SCS_TRAIN_SPLIT", -1);
+        o.split_head = env_int("SCS_SPLIT_HEAD", -1);
         o.wgfin_early = env_int("SCS_WGFIN_EARLY", 1);
         o.c5_split = env_int("SCS_C5_SPLIT", -1);
         if (const char* e = getenv("SCS_WG_SLICES")) {
@@ -785,6 +894,7 @@ int scs_destroy(scs_handle h) {
     if (h->sp_flag) (void)hipFree(h->sp_flag);
     if (h->sp_flag_host) (void)hipHostFree(h->sp_flag_host);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->r_base) (void)hipFree(h->r_base);
     if (h->dense_ws) (void)hipFree(h->dense_ws);
     if (h->dense_feat) (void)hipFree(h->dense_feat);
     if (h->box_flag) (void)hipFree(h->box_flag);
@@ -830,7 +940,7 @@ static int* option_slot(scs_ctx* h, const char* name) {
         {"dense_chain_max_batch", &o.dense_chain_max_batch}, {"c5_fused_max_batch", &o.c5_fused_max_batch},
         {"train_one_stream", &o.train_one_stream}, {"tail_side", &o.tail_side}, {"tail_fused", &o.tail_fused},
         {"split_max_batch", &o.split_max_batch},
-        {"fwd_fused", &o.fwd_fused}, {"fwd_split", &o.fwd_split}, {"split_fallbacks", &o.split_fallbacks}, {"train_split", &o.train_split},
+        {"fwd_fused", &o.fwd_fused}, {"fwd_split", &o.fwd_split}, {"split_fallbacks", &o.split_fallbacks}, {"train_split", &o.train_split}, {"split_head", &o.split_head},
         {"wgfin_early", &o.wgfin_early},
         {"c5_split", &o.c5_split},
         {"wg_slices_conv2", &o.wg_slices[0]}, {"wg_slices_conv3", &o.wg_slices[1]}, {"wg_slices_conv4", &o.wg_slices[2]},
@@ -1212,6 +1322,20 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
     } else {
         SCS_ARG(count == n * per, "count does not match n*row size");
         SCS_HIP(hipMemcpy(host_out, single, n * per * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (h->last_split_head && which >= 3 && which <= 5) {
+        // the split head keeps these as rows of halves (dense_split.h): back to the f32 layouts of the ids
+        const int kp = which == 5 ? DsFC2::KP : DsK17::KP, cols = which == 5 ? kFC1 + kAtlas : kFlat, rb = ds_row_bytes(kp);
+        std::vector<unsigned char> rows(n * rb);
+        for (int t = 0; t < (which == 3 ? kTowers : 1); ++t) {
+            const unsigned char* src = which == 3 ? h->r_c5[t] : (which == 4 ? h->r_feat : h->r_fc1);
+            SCS_HIP(hipMemcpy(rows.data(), src, rows.size(), hipMemcpyDeviceToHost));
+            for (size_t r = 0; r < n; ++r) {
+                const _Float16* hi = reinterpret_cast<const _Float16*>(rows.data() + r * rb);
+                float* o = host_out + ((size_t)t * n + r) * per;
+                for (int c = 0; c < (int)per; ++c) o[c] = c < cols ? ((float)hi[c] + (float)hi[kp + c]) / kSplitActScale : 0.f;
+            }
+        }
     }
     return SCS_OK;
 }

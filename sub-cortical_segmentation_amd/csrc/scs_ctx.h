@@ -2,6 +2,7 @@
 #pragma once
 #include "conv_mfma.h"
 #include "conv_split.h"
+#include "dense_split.h"
 
 struct TrainWs;
 
@@ -27,6 +28,8 @@ struct scs_options {
                                      // the call then returns after the work has finished (it reads the overflow flag and, if a scaled activation
                                      // left the f16 range, repeats the batch on the f32 kernels).  Default (-1, 0): the exact-f32 MFMA kernels
     int split_fallbacks = 0;         // (counter, read with scs_get_option) batches repeated on the f32 kernels after such an overflow
+    int split_head = -1;             // SCS_SPLIT_HEAD: with fwd_split, 0 = the dense head on the f32-MFMA GEMMs (round-5's first form); default
+                                     // (-1, 1): d1 x3, FC1, fc_2 on the split kernels of dense_split.h as well
     int train_split = -1;            // SCS_TRAIN_SPLIT: 1 = the training forward's conv1 + conv2 block on the f16 matrix cores with split operands
                                      // (conv_split_train.h: f32-grade results; a scaled activation beyond the f16 range turns the step's loss into NaN);
                                      // default (-1, 0): the exact-f32 MFMA kernel
@@ -61,10 +64,19 @@ struct scs_ctx {
         const float* w1[scs::kTowers];                        // conv1: kSp12W1Floats
         const uint4* w[scs::kTowers][scs::kConvs];            // i = 1..4: [k-step][channel tile][piece][lane] x 16 bytes
         const float* bias[scs::kTowers][scs::kConvs];         // i = 1..4: [tiles * 16] folded bias + the accumulator scale
+        const uint4* dw[5];                                   // dense_split.h: d1 of the three towers, FC1, fc_2
+        const float* db[5];                                   // [tiles * 16] bias + the accumulator scale
     } sp{};
+    // activation rows of the split dense head (dense_split.h: rows of 4 * kp + 16 bytes, cleared at allocation, written by the split
+    // kernels alone: pads and K padding stay zero)
+    unsigned char* r_c5[scs::kTowers]{};      // [chunk] rows of 544 halves per piece: the towers' flattened block-5 outputs
+    unsigned char* r_feat = nullptr;          // [chunk] rows of 544: d1 x3 side by side (FC1's input)
+    unsigned char* r_fc1 = nullptr;           // [chunk] rows of 576: FC1 output + atlas prior (fc_2's input)
+    unsigned char* r_base = nullptr;
     unsigned int* sp_flag = nullptr;           // overflow flag of the split kernels (device) ...
     unsigned int* sp_flag_host = nullptr;      // ... and its pinned host copy
     bool last_split = false;                   // the last forward left split planes in a_pool1 / a_conv3 / a_pool2
+    bool last_split_head = false;              // ... and rows of halves in r_c5 / r_feat / r_fc1 (the split dense head)
 
     // forward workspace (one chunk)
     int chunk = 32768;             // patches per internal chunk (workspace ~140 KB per patch)

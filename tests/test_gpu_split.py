@@ -72,9 +72,25 @@ def test_per_layer_activations_on_the_split_path(split, weights):
         got = split.get_activation(which, 3 * n * per).reshape(3, n, -1)
         for t, tn in enumerate(towers):
             close(got[t], tr['%s_%s' % (tn, key)].reshape(n, -1), '%s_%s' % (tn, key))
+    # the dense head on the split kernels (csrc/dense_split.h): rows of halves between the layers, handed back in the f32 layouts
+    feat = split.get_activation(4, n * 540).reshape(n, 540)
+    close(feat, np.concatenate([tr['%s_d1' % t] for t in towers], axis=1), 'd1 concat')
+    fc1 = split.get_activation(5, n * 556).reshape(n, 556)
+    close(fc1[:, :540], tr['FC1'], 'FC1')
+    assert np.abs(fc1[:, 540:555] - args[3]).max() <= 2e-7 and np.all(fc1[:, 555] == 0)     # the prior: two f16 pieces of each value
+    fc2 = split.get_activation(6, n * 272).reshape(n, 272)
+    close(fc2[:, :270], tr['fc_2'], 'fc_2')
     logits = split.get_activation(7, n * 16).reshape(n, 16)
     close(logits[:, :15], tr['logits'], 'logits')
     assert split.get_option('split_fallbacks') == 0
+    # ... and with the head left on the f32-MFMA GEMMs (option split_head = 0: the towers alone on the split kernels)
+    split.set_option('split_head', 0)
+    try:
+        run_forward(split, *args)
+        close(split.get_activation(4, n * 540).reshape(n, 540), feat, 'd1 concat, f32 head vs split head')
+        close(split.get_activation(7, n * 16).reshape(n, 16), logits, 'logits, f32 head vs split head')
+    finally:
+        split.set_option('split_head', -1)
 
 
 @pytest.mark.parametrize('n', [1, 3, 17, 700, 4099])

@@ -738,7 +738,8 @@ def main():
                 'roofline': {'bound': 'mfma', 'kernel': STAGE_NAMES[sdom],
                              'achieved': 3.0 * sflop / sdur / 1e12, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                              'frac': 3.0 * sflop / sdur / 1e12 / PEAK_F16_TFLOPS,
-                             'achieved_f32_equivalent': sflop / sdur / 1e12, 'traffic': None,
+                             'achieved_f32_equivalent': sflop / sdur / 1e12,
+                             'traffic': measured_traffic('split: ' + STAGE_NAMES[sdom])[0] if B == 100000 else None,
                              'note': 'algorithmic work of the split form = three f16 products per f32 multiply-add (padding of the 16-wide channel tiles '
                                      'and 32-deep k blocks not counted); priced against the dense f16 MFMA peak',
                              'launch_ms': sdur * 1e3, 'patches_per_launch': B / sl},

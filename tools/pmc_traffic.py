@@ -23,8 +23,18 @@ FORWARD = {
     'conv4+pool2': r'^conv<40,40,12,\d+,1,0,',
     'conv5': r'^conv<40,60,5,\d+,0,0,',
 }
+# the split kernels of the same stages (option fwd_split: csrc/conv_split.h, dense_split.h); keys carry the prefix 'split: '
+SPLIT = {
+    'conv1+conv2+pool1': r'conv12_split_kernel<true, false>',
+    'conv3': r'conv_split_all_kernel<SpCfg<20, 40, 14,',
+    'conv4+pool2': r'conv_split_all_kernel<SpCfg<40, 40, 12,',
+    'conv5': r'conv_split_kernel<SpCfg<40, 60, 5,',
+    'd1x3 / FC1 (one kernel, two launches: the average)': r'dense_split_kernel<DsCfg<17,',
+    'fc_2': r'dense_split_kernel<DsCfg<18,',
+}
 TRAIN = {
     'conv1+conv2 fwd': r'^conv<20,20,30,1,3,8,',
+    'conv1+conv2 fwd (train_split)': r'conv12_split_train_kernel',
     'conv3 fwd': r'^conv<20,40,14,1,3,[45],',
     'conv4 fwd': r'^conv<40,40,12,1,3,4,',
     'conv5 fwd': r'^conv<40,60,5,\d+,3,5,',
@@ -61,6 +71,11 @@ def main():
         if r:
             out[name] = r[0]
             out['_detail'][name] = {'read': r[1], 'write': r[2]}
+    for name, pat in SPLIT.items():
+        r = pick(fwd, pat)
+        if r:
+            out['split: ' + name] = r[0]
+            out['_detail']['split: ' + name] = {'read': r[1], 'write': r[2]}
     for name, pat in TRAIN.items():
         r = pick(trn, pat)
         if r:

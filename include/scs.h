@@ -92,6 +92,14 @@ int scs_set_chunk(scs_handle h, int patches_per_chunk);
  *   "train_one_stream"       SCS_TRAIN_ONE_STREAM       1: every launch in order on the caller's stream
  *   "tail_side"              SCS_TAIL_SIDE              1: the round-2 stream order of the step's last launches
  *   "wg_slices_conv2".."wg_slices_conv5"  SCS_WG_SLICES="b,c,d,e"  batch slices of the weight-gradient kernels (0 = default)
+ *   "fwd_split"              SCS_FWD_SPLIT              inference: 1 = conv2..conv5 and the dense head on the f16 matrix cores with every f32 operand
+ *                                                       as two f16 pieces, f32 accumulation (f32-grade results at ~2.4x the rate).  scs_forward,
+ *                                                       scs_forward_host, scs_forward_volume / _rows, scs_forward_profiled; the call then waits for its
+ *                                                       work, reads an overflow flag and repeats a batch whose scaled activations left the f16 range on
+ *                                                       the f32 kernels ("split_fallbacks": how often, readable with scs_get_option).  Default 0
+ *   "split_head"             SCS_SPLIT_HEAD             0: with fwd_split, the dense head stays on the f32 GEMMs.  Default 1
+ *   "train_split"            SCS_TRAIN_SPLIT            training: 1 = the forward pass of the conv1 + conv2 block on the split kernels; a scaled
+ *                                                       activation beyond the f16 range makes that step's loss NaN.  Default 0
  * Unknown name or value outside [-1, 2^20]: SCS_ERR_ARG. */
 int scs_set_option(scs_handle h, const char* name, int64_t value);
 int scs_get_option(scs_handle h, const char* name, int64_t* value);

@@ -556,6 +556,7 @@ int ensure_workspace(scs_ctx* h, int need) {
         const size_t tot = c * (4 * rb17 + rb18);
         SCS_HIP(hipMalloc(&h->r_base, tot));
         SCS_HIP(hipMemset(h->r_base, 0, tot));
+        SCS_HIP(hipDeviceSynchronize());                   // (the kernels that fill these rows may run on a non-blocking stream)
         for (int t = 0; t < kTowers; ++t) h->r_c5[t] = h->r_base + (size_t)t * c * rb17;
         h->r_feat = h->r_base + 3 * c * rb17;
         h->r_fc1 = h->r_base + 4 * c * rb17;

@@ -14,7 +14,7 @@ from test_gpu_train import _step_against_gate_aware_oracle, dev, arena, fresh   
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('n', [1, 2, 5, 37, 128, 129, 170, 255, 256, 257, 340, 341, 511, 700])
+@pytest.mark.parametrize('n', [1, 5, 37, 128, 170, 256, 257, 511, 700])
 def test_split_training_step_at_ragged_batch_sizes(fresh, weights, n):
     """scs_train_step with train_split = 1 against the oracle; the sizes cross the grid's switch - one workgroup per patch-tower up to
     256, 160 persistent ones beyond - and the in-kernel finalize's slices (257 .. 511: several rounds of units per workgroup;
@@ -27,7 +27,7 @@ def test_split_training_step_at_ragged_batch_sizes(fresh, weights, n):
 @pytest.mark.parametrize('n', [5, 37])
 def test_split_training_step_on_random_draws(fresh, weights, n):
     fresh.set_option('train_split', 1)
-    for draw in range(1, 6):
+    for draw in range(1, 4):
         _step_against_gate_aware_oracle(fresh, weights, n, draw, stale_rows=False)
 
 

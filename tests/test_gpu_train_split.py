@@ -94,3 +94,42 @@ def test_split_overflow_turns_the_loss_into_nan(weights):
     loss = h.train_step(dev(ax), dev(co), dev(sa), dev(at), dev(y, torch.uint8), n, seed=5, stream=st)
     h.close()
     assert not np.isfinite(loss), loss
+
+
+from test_gpu_compact import toy, device_form   # noqa: E402,F401  (toy: fixture)
+
+
+@pytest.mark.parametrize('augmented', [False, True])
+def test_split_step_from_volumes_equals_the_step_from_patches(toy, weights, augmented):
+    """With train_split the input patches are cut (and, with the opt-in augmentation, mirrored) inside the split kernel's own loads
+    (conv_split_train.h: X0RowRegs): the step from volumes + voxel rows must equal the step from the materialised views bit for bit."""
+    from cnn_cort import _hip
+    from cnn_cort.nets import rotate_flip_views
+    _, mat, cs = toy
+    d = device_form(cs)
+    n, lo = 40, 3
+    st = torch.cuda.current_stream().cuda_stream
+    views = [dev(mat[v][lo:lo + n]) for v in range(3)]
+    flips = None
+    if augmented:
+        rng = np.random.RandomState(4)
+        idx = rng.choice(n, n // 2, replace=False)
+        choices = [rng.randint(0, 3, size=idx.size) for _ in range(3)]
+        f = np.zeros(n, np.uint8)
+        for v in range(3):
+            f[idx] |= (np.array([3, 2, 1], np.uint8)[choices[v]] << (2 * v)).astype(np.uint8)
+        flips = torch.from_numpy(f).to('cuda:0')
+        views = [v.contiguous() for v in rotate_flip_views(views, torch.from_numpy(idx).to('cuda:0'), [torch.from_numpy(c).to('cuda:0') for c in choices])]
+    out = []
+    for compact in (False, True):
+        h = _hip.Handle(0)
+        h.set_params(P.params_to_flat(weights))
+        h.set_option('train_split', 1)
+        if compact:
+            kw = {'flips': flips} if augmented else {}
+            loss = h.train_step_volume(d['vols'], d['desc'], d['samples'], d['atlas'], d['y'], d['index'][lo:lo + n], n, seed=9, stream=st, **kw)
+        else:
+            loss = h.train_step(views[0], views[1], views[2], dev(mat[3][lo:lo + n]), dev(mat[4][lo:lo + n], torch.uint8), n, seed=9, stream=st)
+        out.append((loss, arena(h, 'grad')))
+        h.close()
+    assert np.isfinite(out[0][0]) and out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])

@@ -51,6 +51,8 @@ def load_options(user_config):
         options['seed'] = user_config.getint('model', 'seed')
     if user_config.has_option('model', 'fwd_split'):
         options['fwd_split'] = user_config.get('model', 'fwd_split').strip()      # 'True': inference on the split kernels (nets.py)
+    if user_config.has_option('model', 'fit_split'):
+        options['fit_split'] = user_config.get('model', 'fit_split').strip()      # 'True': fit()'s forward conv1 + conv2 block on the split kernels
     return options
 
 

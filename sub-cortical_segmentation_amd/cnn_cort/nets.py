@@ -113,11 +113,14 @@ class Net:
 
     def __init__(self, weights_file=None, history_file=None, max_epochs=100, patience=20, eval_size=0.25,
                  batch_size=128, verbose=0, device=None, update_learning_rate=0.001, seed=0, augment=False,
-                 fit_slice=16384, fit_resident_bytes=2 << 30, fwd_split=False):
+                 fit_slice=16384, fit_resident_bytes=2 << 30, fwd_split=False, fit_split=False):
         self.augment = bool(augment)
         # inference (predict / predict_proba / test_scan's patch entries) on the split kernels: convolutions on the f16 matrix cores
         # with every f32 operand as two f16 pieces, f32-grade results at ~2x the rate (csrc/conv_split.h; option fwd_split of libscs)
         self.fwd_split = bool(fwd_split)
+        # training: the forward pass of the conv1 + conv2 block on the split kernels (csrc/conv_split_train.h; option train_split of
+        # libscs - named fit_split here: `train_split` is the reference's hold-out fraction, configuration.cfg [model])
+        self.fit_split = bool(fit_split)
         self.fit_slice = int(fit_slice)                      # samples per streamed slice of a materialised training set
         self.fit_resident_bytes = int(fit_resident_bytes)    # sets up to this size are uploaded once instead
         self.weights_file = weights_file
@@ -165,6 +168,8 @@ class Net:
                 self._handle = _hip.Handle(self._dev())
                 if self.fwd_split:
                     self._handle.set_option('fwd_split', 1)
+                if self.fit_split:
+                    self._handle.set_option('train_split', 1)
             if self._params is None:
                 self._params = P.init_params(self.seed)       # Lasagne default initialisers (training from scratch)
                 self._dirty = True
@@ -854,7 +859,7 @@ def build_model(weights_path, options):
               max_epochs=options['max_epochs'], patience=options['patience'], eval_size=options['train_split'],
               batch_size=options.get('batch_size') or 128, verbose=options['net_verbose'],
               device=options.get('device'), augment=is_true(options.get('augment')),
-              seed=int(options.get('seed') or 0), fwd_split=is_true(options.get('fwd_split')))
+              seed=int(options.get('seed') or 0), fwd_split=is_true(options.get('fwd_split')), fit_split=is_true(options.get('fit_split')))
     if is_true(options['load_weights']):
         if net.verbose:
             print("    --> loading weights from ", net_weights)

@@ -133,3 +133,29 @@ def test_split_step_from_volumes_equals_the_step_from_patches(toy, weights, augm
         out.append((loss, arena(h, 'grad')))
         h.close()
     assert np.isfinite(out[0][0]) and out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
+def test_fit_with_the_fit_split_option(weights, tmp_path):
+    """options['fit_split'] = 'True' -> build_model's Net trains with libscs' option train_split (the key is NOT 'train_split': that is
+    the reference's hold-out fraction): fit() on a small set walks a history within 1e-4 of the f32 net's (two epochs, same seeds) and
+    learns; the handle reports the option."""
+    from cnn_cort import nets, synth
+    n = 512
+    ax, co, sa, at = synth.patch_batch(n, seed=21)
+    y = np.random.RandomState(3).randint(0, 15, n).astype(np.uint8)
+    X = {'in1': ax, 'in2': co, 'in3': sa, 'in4': at}
+    opt = {'experiment': 'e', 'net_verbose': 0, 'train_split': 0.25, 'max_epochs': 2, 'patience': 5, 'patch_size': (32, 32),
+           'load_weights': 'False', 'device': 0, 'batch_size': 64, 'seed': 4}
+    hist = {}
+    for key in ('f32', 'split'):
+        d = tmp_path / key
+        d.mkdir()
+        net = nets.build_model(str(d), dict(opt, fit_split='True') if key == 'split' else dict(opt))
+        net.load_params_from({k: [a.copy() for a in v] for k, v in weights.items()})
+        net.fit(X, y)
+        assert net._handle.get_option('train_split') == (1 if key == 'split' else -1)
+        hist[key] = [(r['train_loss'], r['valid_loss']) for r in net.train_history_]
+    assert len(hist['split']) == 2 and all(np.isfinite(v) for r in hist['split'] for v in r)
+    for a, b in zip(hist['split'], hist['f32']):
+        assert abs(a[0] - b[0]) <= 1e-4 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-4 * max(1.0, abs(b[1])), (hist['split'], hist['f32'])
+    assert hist['split'][1][0] < hist['split'][0][0]

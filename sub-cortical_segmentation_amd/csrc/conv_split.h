@@ -34,6 +34,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SP_ROWREUSE
 #define SP_ROWREUSE 1        // conv1+conv2+pool1: every LDS fragment of the conv2 stage read once for both window rows it serves (0: per tile and k-step)
 #endif
+#ifndef SP_GLDS
+#define SP_GLDS 1            // conv3 / conv4 (conv_split_all_kernel): the next iteration's planes copied global -> LDS by global_load_lds_dwordx4 (no
+#endif                       // registers, no LDS-write pass) instead of through 48-64 prefetch registers per thread (0: the register-staged form)
 #ifndef SP_ABLATE
 #define SP_ABLATE 0          // tools/sbench timing experiments only (results are wrong when set): 1 conv1 stage only on a workgroup's first
 #endif                       // patch, 2 no conv2 MFMAs after the first k-step, 3 no stores, 4 no overflow tracking; conv_split_all_kernel:
@@ -583,11 +586,15 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
 // ---- the same layers with ALL output tiles per wave: one wave per SIMD (512 registers), every wave holds the weights of all MT
 // output tiles (MT * KS * 8 registers: 144 for conv3, 288 for conv4) and walks its own quarter of the iteration's pixel tiles, so
 // every B fragment is read from LDS once.  A workgroup (4 waves) stages G patch-towers per iteration into one of two LDS buffers
-// (global -> registers during the previous iteration's matrix phase -> LDS behind it): one barrier per iteration.
+// (copied global -> LDS by global_load_lds_dwordx4 under the previous iteration's matrix phase - no registers, no LDS-write pass;
+// SP_GLDS = 0: through 48-64 prefetch registers per thread, the first form: conv3 26 % slower): one barrier per iteration.
 template <class C>
 __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    constexpr int NTH = 256, TPW = C::NT / 4, PF = (2 * C::V * C::G + NTH - 1) / NTH, BUF_B = 2 * C::G * C::PLANE_B;
+    constexpr int NTH = 256, TPW = C::NT / 4, BUF_B = 2 * C::G * C::PLANE_B;
+#if !SP_GLDS
+    constexpr int PF = (2 * C::V * C::G + NTH - 1) / NTH;
+#endif
     static_assert(C::NT % 4 == 0 && (C::TPP % TPW == 0 || TPW % C::TPP == 0), "tiles split evenly over the four waves");
     static_assert(!C::POOL || TPW == 4, "a wave owns one pooling group");
     static_assert(C::OUTF == 0 && !C::SMALL, "split-plane outputs");
@@ -619,15 +626,42 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
     rd0 += g0 * 2 * C::PLANE_B; rd1 += g0 * 2 * C::PLANE_B;
     float vmax = 0.f;
     const unsigned char* inp = a.in[tower];
-    constexpr int SP_NTH = NTH, SP_PF = PF;
-    u32x4 pf[SP_PF];
     const int step = nwg * C::G;
     int p = wg * C::G, buf = 0;
+#if SP_GLDS
+    // plane pl (patch-tower g = pl / 2, piece pl & 1) of the iteration at patch P: IN_B contiguous bytes -> LDS at pl * PLANE_B, in
+    // 1 KB wave instructions (the last one of a plane partly masked); the four waves take the planes' chunks round robin
+    constexpr int CPP = (C::IN_B + 1023) / 1024, NCH = 2 * C::G * CPP;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    auto copy_planes = [&](int P, unsigned char* dstbuf) {
+#pragma unroll
+        for (int c0 = 0; c0 < NCH; c0 += 4) {
+            const int c = c0 + wv;
+            if (c < NCH) {
+                const int pl = c / CPP, k = c - pl * CPP, off = k * 1024 + lane * 16;
+                if (off < C::IN_B) {
+                    const unsigned char* src = inp + (size_t)min(P + (pl >> 1), a.n - 1) * 2 * C::IN_B + (size_t)(pl & 1) * C::IN_B + off;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dstbuf + pl * C::PLANE_B + k * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+    if (p < a.n) copy_planes(p, sp_smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#else
+    constexpr int SP_NTH = NTH, SP_PF = PF;
+    u32x4 pf[SP_PF];
     if (p < a.n) { SP_FETCH(p) SP_STASH(sp_smem) }
     __syncthreads();
     if (p + step < a.n) { SP_FETCH(p + step) }
+#endif
     for (; p < a.n; p += step) {
         const unsigned char* base = sp_smem + (size_t)buf * BUF_B;
+#if SP_GLDS
+        if (p + step < a.n && SP_ABLATE != 5) copy_planes(p + step, sp_smem + (size_t)(buf ^ 1) * BUF_B);
+#endif
         // TB tiles per pass (POOL: the four positions of the wave's pooling group); the B fragments of k-step s + 1 are requested in
         // front of the MFMAs of k-step s and the scheduler is kept from hoisting further (fragments of ALL k-steps in flight spill)
         constexpr int TB = C::POOL ? 4 : 3;
@@ -697,10 +731,14 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
                 }
             }
         }
+#if SP_GLDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next planes has landed
+#else
         if (p + step < a.n && SP_ABLATE != 5) {
             SP_STASH(sp_smem + (size_t)(buf ^ 1) * BUF_B)
             if (p + 2 * step < a.n) { SP_FETCH(p + 2 * step) }
         }
+#endif
         if (SP_ABLATE != 8) __syncthreads();
         buf ^= 1;
     }

@@ -339,7 +339,11 @@ inline hipError_t conv12_split_train_set_attr() {
 inline void conv12_split_train_launch(const SplitTrain12Args& a, hipStream_t st, int wgs_per_tower = 0) {
     static_assert(160 % kFinGroup == 0, "finalize slices");
     if (wgs_per_tower <= 0) wgs_per_tower = a.n <= 256 ? a.n : 160;
-    const int g = wgs_per_tower < a.n ? wgs_per_tower : a.n;
+    int g = wgs_per_tower < a.n ? wgs_per_tower : a.n;
+    if (a.fin.counter && g < a.n && g % kFinGroup != 0) {                        // several rounds: the finalize's slices need whole groups
+        g = g - g % kFinGroup < kFinGroup ? kFinGroup : g - g % kFinGroup;
+        if (g > a.n) g = a.n;
+    }
     if (g < 1) return;
     hipLaunchKernelGGL(conv12_split_train_kernel, dim3(3 * g), dim3(256), kSpT12LdsBytes, st, a);
 }

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256, 1) void dense_split_kernel(DenseSplitArgs a) {
     };
     int p0 = wg * kDsPB, b = 0;
     if (p0 < a.n) copy_block(p0, ds_smem);
-    __syncthreads();                                         // (waits for the copies: an LDS-DMA is a pending write on the VM counter)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's copies have landed (an LDS-DMA is a pending write on the VM counter) ...
+    __syncthreads();                                         // ... and so have everybody else's
     for (; p0 < a.n; p0 += nwg * kDsPB) {
         const unsigned char* cur = ds_smem + (size_t)b * C::BUF_B;
         const int pn = p0 + nwg * kDsPB;
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(256, 1) void dense_split_kernel(DenseSplitArgs a) {
                 }
             }
         }
-        __syncthreads();                                     // the next block's rows have landed; everybody is done with this one's
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next block's rows has landed (and its stores have left)
+        __syncthreads();                                     // the whole block has; everybody is done with this one's rows
         b ^= 1;
     }
     if (!(vmax <= kSplitOverflow)) atomicOr(a.flag, 1u);

@@ -591,9 +591,9 @@ __global__ __launch_bounds__(C::NTH, C::WPC) void conv_split_kernel(SplitArgs a)
 template <class C>
 __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    constexpr int NTH = 256, TPW = C::NT / 4, BUF_B = 2 * C::G * C::PLANE_B;
+    constexpr int TPW = C::NT / 4, BUF_B = 2 * C::G * C::PLANE_B;
 #if !SP_GLDS
-    constexpr int PF = (2 * C::V * C::G + NTH - 1) / NTH;
+    constexpr int NTH = 256, PF = (2 * C::V * C::G + NTH - 1) / NTH;
 #endif
     static_assert(C::NT % 4 == 0 && (C::TPP % TPW == 0 || TPW % C::TPP == 0), "tiles split evenly over the four waves");
     static_assert(!C::POOL || TPW == 4, "a wave owns one pooling group");

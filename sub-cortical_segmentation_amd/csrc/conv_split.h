@@ -673,6 +673,46 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
             for (int i = 0; i < TB; ++i)
 #pragma unroll
                 for (int m = 0; m < C::MT; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if SP_ROWREUSE
+            if constexpr (C::POOL) {
+                // pooling group: pixel row R (0..3) of the windows' 4 x 2 pixels is tap row R of the upper window row and tap row R - 1 of
+                // the lower one: fragment f = (R KSR + ks) 2 + column parity is read ONCE and used for both (32 fragment pairs per group
+                // instead of 48; conv1+conv2+pool1 does the same); three in flight
+                constexpr int NF = 4 * C::KSR * 2;
+                f16x8 rh[3], rl[3];
+                auto rdf = [&](int f) {
+                    const int off = ((f >> 1) / C::KSR) * C::RS + ((f >> 1) % C::KSR) * 64 + (f & 1) * C::PS;
+                    const unsigned char* h0 = base + rd0 + off;
+                    const unsigned char* h1 = base + rd1 + off;
+                    rh[f % 3] = sp_frag(h0, h1);
+                    rl[f % 3] = sp_frag(h0 + C::PLANE_B, h1 + C::PLANE_B);
+                };
+                rdf(0); rdf(1);
+#pragma unroll
+                for (int f = 0; f < (SP_ABLATE == 7 ? 2 : NF); ++f) {
+                    const int R = (f >> 1) / C::KSR, ks = (f >> 1) % C::KSR, qc = f & 1;
+                    if (f + 2 < NF) rdf(f + 2);
+                    const f16x8 bh = rh[f % 3], bl = rl[f % 3];
+#pragma unroll
+                    for (int piece = 0; piece < 3; ++piece) {
+#pragma unroll
+                        for (int use = 0; use < 2; ++use) {
+                            const int dy = R - use;
+                            if (dy < 0 || dy > 2) continue;
+                            const int s = dy * C::KSR + ks, i = 2 * use + qc;
+#pragma unroll
+                            for (int m = 0; m < C::MT; ++m) {
+                                if (piece == 0) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][m], bh, acc[i][m], 0, 0, 0);
+                                else if (piece == 1) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bl, acc[i][m], 0, 0, 0);
+                                else acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bh, acc[i][m], 0, 0, 0);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
+#endif
+            {
             f16x8 fh[2][TB], fl[2][TB];
             auto frags = [&](int s, int slot, int i) {
                 int off = (s / C::KSR) * C::RS + (s % C::KSR) * 64;
@@ -701,6 +741,7 @@ __global__ __launch_bounds__(256, 1) void conv_split_all_kernel(SplitArgs a) {
                     if (s + 1 < C::KS) frags(s + 1, (s + 1) & 1, i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             }
             // ---- epilogue of the pass
             constexpr int NOUT = C::POOL ? 1 : TB;

@@ -80,7 +80,7 @@ def test_split_forward_buffers_against_the_f32_kernels(weights, n):
 
 def test_split_overflow_turns_the_loss_into_nan(weights):
     """A conv1 activation beyond the f16 range of the scaled planes (|a| > 1023) cannot be represented by the split form: the step
-    must not return a plausible loss (conv_split_train.h: the patch-tower's outputs are poisoned)."""
+    must not return a plausible loss (conv_split_train.h raises a flag; the workgroup that forms the batch-mean loss turns it into NaN)."""
     from cnn_cort import _hip, synth
     n = 8
     ax, co, sa, at = synth.patch_batch(n, seed=3)

@@ -271,9 +271,15 @@ def train_forward_backward(params, ax, co, sa, atlas, y, masks, debug=None, gate
     r2 = relu(pre2)
     h2 = prelu(r2, P['prelu_f2'][0])
     W3, b3 = P['out_layer']
-    probs = softmax(h2 @ W3 + b3)
+    logits = h2 @ W3 + b3
+    probs = softmax(logits)
     yi = np.asarray(y).astype(np.int64)
-    loss = float(-np.log(probs[np.arange(N), yi]).mean())
+    # mean categorical cross-entropy (nets.py:235) from the LOGITS: logsumexp(z) - z[y].  -log(softmax(z)[y]) is the same number
+    # until a probability underflows (a logit gap beyond ~745 in float64), where it turns into inf and every comparison
+    # against it becomes vacuous; `probs` stays what the backward pass uses.
+    zmax = logits.max(axis=1)
+    lse = zmax + np.log(np.exp(logits - zmax[:, None]).sum(axis=1))
+    loss = float((lse - logits[np.arange(N), yi]).mean())
 
     # ---- backward
     dz = probs.copy()

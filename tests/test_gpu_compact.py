@@ -86,6 +86,7 @@ def test_step_from_volumes_equals_step_from_patches_and_the_oracle(toy, weights,
         lit.append(x[:, None])
     assert all(np.array_equal(a, b) for a, b in zip(lit, (ax, co, sa)))
     loss_ref, grads_ref, _, _ = O.train_forward_backward(weights, lit[0], lit[1], lit[2], cs.atlas[rows], cs.y[rows], masks)
+    assert np.isfinite(loss_ref), loss_ref
     assert abs(out[1][0] - loss_ref) <= 2e-4 * max(1.0, abs(loss_ref))
     got = P.flat_to_params(out[1][1])
     for name, shapes in P.LAYER_SPEC:

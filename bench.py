@@ -478,13 +478,39 @@ def dice_block(local, weights, n_compare=24000):
                 seen += 1
                 per_class[str(k)] = {'dice': 2.0 * float((a & b).sum()) / float(a.sum() + b.sum()), 'gpu_voxels': int(a.sum()), 'cpu_voxels': int(b.sum())}
         differ = np.flatnonzero(l_gpu != l_cpu)
+        # the same subject through test_scan on the SPLIT kernels (options fwd_split + per-voxel towers: the shared-tower evaluation
+        # stays on the f32 kernels), compared with the same CPU results and with the f32 path's labels over the whole ROI
+        split = None
+        try:
+            o2 = dict(opts, fwd_split='True', towers='patch')
+            net2 = build_model(os.path.join(PKG, 'nets'), o2)
+            t0 = time.perf_counter()
+            base.test_scan(net2, scan, o2)
+            t_scan2 = time.perf_counter() - t0
+            seg2 = nifti.load(os.path.join(sub, 'out_subcortical_rawseg.nii.gz')).get_data()
+            prob2 = nifti.load(os.path.join(sub, 'out_subcortical_prob.nii.gz')).get_data()
+            l2 = seg2[c[:, 0], c[:, 1], c[:, 2]].astype(np.int64)
+            pc2 = {}
+            for k in range(15):
+                a, b = l2 == k, l_cpu == k
+                if a.sum() + b.sum():
+                    pc2[str(k)] = 2.0 * float((a & b).sum()) / float(a.sum() + b.sum())
+            split = {'options': "fwd_split='True', towers='patch' (f16 x 2 pieces on the f16 matrix cores, f32 accumulate)",
+                     'towers': net2.last_scan_towers, 'split_fallbacks': int(net2._handle.get_option('split_fallbacks')),
+                     'min_dice': min(pc2.values()), 'classes_seen': len(pc2), 'labels_differ_vs_cpu': int((l2 != l_cpu).sum()),
+                     'labels_differ_vs_f32_whole_roi': int((seg2 != seg).sum()),
+                     'max_abs_prob_diff_vs_cpu': float(np.abs(prob2[c[:, 0], c[:, 1], c[:, 2]] - p_cpu).max()),
+                     'max_abs_prob_diff_vs_f32': float(np.abs(prob2[c[:, 0], c[:, 1], c[:, 2]] - p_gpu).max()),
+                     'test_scan_seconds': t_scan2}
+        except Exception as e:                                             # the f32 block above is the metric; say why this one is missing
+            split = {'error': repr(e)}
         return {'subject': 'synthetic 256x256x192 int16 T1, steered 15-channel prior (cnn_cort.synth.steered_atlas), %d ROI voxels' % n_roi,
                 'reference': 'float32 torch-CPU port (oracle/torch_ref.py) on %d host threads - kind "port": the Theano path cannot run here' % cores,
                 'voxels_compared': int(len(c)), 'classes_seen': seen, 'classes_in_volume': int(len(np.unique(seg))),
                 'per_class': per_class, 'min_dice': min(v['dice'] for v in per_class.values()),
                 'labels_differ': int(len(differ)),
                 'labels_differ_max_cpu_margin': float((srt[differ, -1] - srt[differ, -2]).max()) if len(differ) else 0.0,
-                'max_abs_prob_diff': float(np.abs(p_gpu - p_cpu).max()),
+                'max_abs_prob_diff': float(np.abs(p_gpu - p_cpu).max()), 'split': split,
                 'seconds': {'synthesise_and_write_subject': t_make, 'test_scan_gpu': t_scan, 'cpu_port': t_cpu}}
     finally:
         shutil.rmtree(root, ignore_errors=True)

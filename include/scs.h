@@ -94,12 +94,22 @@ int scs_set_chunk(scs_handle h, int patches_per_chunk);
  *   "wg_slices_conv2".."wg_slices_conv5"  SCS_WG_SLICES="b,c,d,e"  batch slices of the weight-gradient kernels (0 = default)
  *   "fwd_split"              SCS_FWD_SPLIT              inference: 1 = conv2..conv5 and the dense head on the f16 matrix cores with every f32 operand
  *                                                       as two f16 pieces, f32 accumulation (f32-grade results at ~2.4x the rate).  scs_forward,
- *                                                       scs_forward_host, scs_forward_volume / _rows, scs_forward_profiled; the call then waits for its
- *                                                       work, reads an overflow flag and repeats a batch whose scaled activations left the f16 range on
- *                                                       the f32 kernels ("split_fallbacks": how often, readable with scs_get_option).  Default 0
+ *                                                       scs_forward_host, scs_forward_volume / _rows, scs_forward_profiled.  The entries stay
+ *                                                       asynchronous: behind the split kernels of every internal chunk the f32 kernels of the same
+ *                                                       chunk are enqueued in a guarded form - each of their workgroups reads the overflow flag the
+ *                                                       split kernels raise when a scaled activation leaves the f16 range and exits at once while it
+ *                                                       is clear - so a flagged chunk comes out of the exact-f32 kernels (the bits the call gives
+ *                                                       without the option) with no host round trip.  "split_fallbacks": chunks repeated so far (a
+ *                                                       device counter: scs_get_option waits for the device to read it; setting it resets it).
+ *                                                       (scs_forward_volume_shared keeps the f32 kernels.)  Default 0
  *   "split_head"             SCS_SPLIT_HEAD             0: with fwd_split, the dense head stays on the f32 GEMMs.  Default 1
  *   "train_split"            SCS_TRAIN_SPLIT            training: 1 = the forward pass of the conv1 + conv2 block on the split kernels; a scaled
- *                                                       activation beyond the f16 range makes that step's loss NaN.  Default 0
+ *                                                       activation beyond the f16 range makes that step's loss NaN - and its gradients: there is
+ *                                                       no f32 repeat of a training step, an update applied from them (scs_adam_apply, or the
+ *                                                       fused update inside the step) leaves the WEIGHTS INVALID.  A caller that uses the option
+ *                                                       checks the loss before it keeps the weights (Net.fit raises at the end of the epoch);
+ *                                                       the batch norm in front bounds the conv1 output, so this takes inputs far outside a
+ *                                                       z-scored volume's range.  Default 0
  * Unknown name or value outside [-1, 2^20]: SCS_ERR_ARG. */
 int scs_set_option(scs_handle h, const char* name, int64_t value);
 int scs_get_option(scs_handle h, const char* name, int64_t* value);

@@ -28,6 +28,7 @@ import json
 import os
 import threading
 import time
+import warnings
 
 import numpy as np
 
@@ -341,6 +342,7 @@ class Net:
             time.sleep(delay)
             delay = min(1e-3, delay * 1.5)
 
+    _warned_split_shared = False      # (class-wide: the fwd_split / shared-towers note is printed once per process)
     SHARED_MIN_VOXELS = 4096          # below this the patch path is as fast
     SHARED_MAX_BOX_RATIO = 24         # bounding-box voxels per centre up to which sharing the tower work pays
     SHARED_MAX_VOXELS = 1 << 22       # 'auto' keeps 6.5 KB of block-5 features per centre on the device: 27 GB here
@@ -412,6 +414,13 @@ class Net:
         elif towers == 'shared':
             raise ValueError("towers='shared' needs the priors as atlas_rows")
         self.last_scan_towers = 'shared' if box is not None else 'patch'
+        if box is not None and self.fwd_split and not Net._warned_split_shared:
+            # the shared-tower evaluation (csrc/dense_eval.h) runs the exact-f32 kernels on its own tile sizes; the split kernels
+            # exist for the per-voxel entries only
+            Net._warned_split_shared = True
+            warnings.warn("fwd_split does not change towers='%s' on a dense ROI: the shared-tower evaluation stays on the f32 kernels "
+                          "(and is the faster form for a whole subject); options['towers'] = 'patch' runs the per-voxel towers on the "
+                          "split kernels" % towers, RuntimeWarning, stacklevel=2)
         if box is not None:
             h.forward_volume_shared(d_vol, shape, d_cen, d_atl, n, box, d_pr if want_probs else None, d_lab, stream)
         for lo in range(0, n if box is None else 0, batch):
@@ -785,6 +794,13 @@ class Net:
                 w = np.asarray(sizes, np.float64)
                 loss_sum, cnt = dist.sum_pair(float((losses * w).sum()), float(w.sum()))
                 train_loss = loss_sum / cnt if cnt else 0.0
+                if self.fit_split and not np.isfinite(train_loss):
+                    # option train_split of libscs: a conv1 activation beyond the f16 range of the split pieces turns that step's loss
+                    # into NaN - and its gradients, which the (fused) Adam update has already applied: the weights are void from that
+                    # step on (include/scs.h).  The reduced loss is the same number on every rank: all of them stop here.
+                    raise FloatingPointError('fit_split: a scaled activation left the f16 range in epoch %d (NaN training loss); the weights are '
+                                             'invalid from that step on - reload them and train with fit_split off (the exact-f32 step)'
+                                             % (first_epoch + ep + 1))
                 vloss, vcorrect = evaluate() if va_hi > va_lo else (0.0, 0)
                 vloss, vcorrect = dist.sum_pair(vloss, float(vcorrect))
                 valid_loss = vloss / nva if nva else 0.0

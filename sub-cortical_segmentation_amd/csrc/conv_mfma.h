@@ -375,6 +375,7 @@ struct ConvArgs {
                                   // instead of pooling the full-size one (SRC_BN_POOL); the backward pass still reads the full-size output.
     float* wgstats;               // EPI_RAW_STATS with G > 1 (conv5 block), or null: [tower][workgroup][COUT] (mean, M2) of the workgroup's
                                   // G * OUTB values per channel - the units the one-launch dense head finalizes (dense_chain.h)
+    const unsigned int* guard;    // GUARDED instantiations only (see the kernel): the launch does nothing while this device word is zero
 };
 
 // kernel-argument arrays indexed by the (wave-uniform) tower id: select, so the struct stays in SGPRs
@@ -579,8 +580,12 @@ struct StagedRegs {
     }
 };
 
-template <class C>
+// GUARDED (forward_chunk_split in scs_api.hip: the f32 repeat behind the split kernels of a chunk, option fwd_split): every workgroup
+// reads the device word a.guard (one scalar load) and leaves at once while it is zero - the launch does the chunk again only if a
+// split kernel raised the overflow flag, without a host round trip.  `if constexpr`: the plain instantiations are untouched.
+template <class C, bool GUARDED = false>
 __global__ __launch_bounds__(C::NTH, (C::WPS * C::NW + 3) / 4) void conv3x3_mfma_kernel(ConvArgs a) {
+    if constexpr (GUARDED) { if (*a.guard == 0u) return; }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + C::IN_FLOATS_AL;
@@ -1490,6 +1495,18 @@ inline void conv_launch(const ConvArgs& a, hipStream_t st, int ntowers = kTowers
     if (a.n <= 0) return;
     dim3 grid(((a.n + C::G - 1) / C::G) * C::NB, ntowers);
     hipLaunchKernelGGL(conv3x3_mfma_kernel<C>, grid, dim3(C::NTH), C::LDS_BYTES, st, a);
+}
+// the guarded form (a.guard set; instantiated only where a caller asks for it)
+template <class C>
+inline hipError_t conv_set_attr_guarded() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<C, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+}
+template <class C>
+inline void conv_launch_guarded(const ConvArgs& a, hipStream_t st, int ntowers = kTowers) {
+    if (a.n <= 0 || !a.guard) return;
+    dim3 grid(((a.n + C::G - 1) / C::G) * C::NB, ntowers);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<C, true>), grid, dim3(C::NTH), C::LDS_BYTES, st, a);
 }
 
 }  // namespace scs

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv12_split_train_kernel(SplitTrain12
             const int pp = 64 * Q + lane, y = pp >> 5, x = pp & 31;
             sp_split4_store(d, s_hi, s_lo, x < 30 ? (y * 30 + x) * 40 + 32 : 900 * 40 + 64, vmax);
         }
-        if (!(vmax <= kSplitOverflow)) *s_ovf = 1u;          // (also catches a NaN input)
+        if (!(vmax <= kSplitOverflow)) *s_ovf = 1u;          // (an infinite value too; NOT a NaN: vmax is built with fmaxf, which drops NaN
+                                                             // operands - a NaN input goes the way it goes in the f32 kernels, to 0 at the next ReLU)
         __syncthreads();                                     // planes complete; nobody reads the raw patch any more
         if (more) xr.store(s_x, tid);
         // ---- conv2 on the f16 matrix cores

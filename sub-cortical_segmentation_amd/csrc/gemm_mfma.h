@@ -41,6 +41,7 @@ struct GemmArgs {
     int M, K4, N;                // K4 = reduction length walked (multiple of 4)
     int K;                       // rows of W that exist (k >= K reads as zero); 0 = K4
     int relu;
+    const unsigned int* guard;   // GUARDED instantiations only (conv_mfma.h: conv3x3_mfma_kernel): the launch does nothing while this device word is zero
 };
 
 // MT = 16-row tiles per wave, NT = 16-column tiles per workgroup: workgroup tile (64*MT) x (16*NT); BK = K slab.
@@ -53,8 +54,9 @@ struct GemmTile {
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
-template <int MT, int NT, int BK = 32, int WPC = 2>
+template <int MT, int NT, int BK = 32, int WPC = 2, bool GUARDED = false>
 __global__ __launch_bounds__(256, WPC) void gemm_mfma_kernel(GemmArgs g) {
+    if constexpr (GUARDED) { if (*g.guard == 0u) return; }
     using T = GemmTile<MT, NT, BK>;
     constexpr int kGemmBK = BK, kGemmAS = T::AS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -149,8 +151,9 @@ __global__ __launch_bounds__(256, WPC) void gemm_mfma_kernel(GemmArgs g) {
 // A thread fetches MT float4 of A (row (t >> 2) + 64 i, k = 4 (t & 3) .. + 3) and up to two float4 of W per slab instead of 14
 // single floats, and parks them in LDS with 8- / 16-byte stores; the LDS images and the fragment reads are those of
 // gemm_mfma_kernel (A rows of 18 floats: bank = 2 row + k; W rows padded to 16 mod 32).  Rows >= M and k >= K read as zero.
-template <int MT, int NT, int WPC>
+template <int MT, int NT, int WPC, bool GUARDED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPC, WPC))) void gemm_mfma_v4_kernel(GemmArgs g) {
+    if constexpr (GUARDED) { if (*g.guard == 0u) return; }
     constexpr int BK = 16, BM = 64 * MT, BN = 16 * NT, BS = (BN % 32 == 16) ? BN : BN + 16, AS = BK + 2;
     constexpr int B4 = BK * BN / 4;                                    // float4 of a W slab
     static_assert(B4 <= 512 && BN % 4 == 0, "two W pieces per thread at most");
@@ -268,8 +271,9 @@ struct GemmSplitK {
     static constexpr size_t LDS = (size_t)4 * NT * 256 * 4;
 };
 
-template <int CH_ = GemmSplitK::CH>     // a template so that both translation units may instantiate it
+template <int CH_ = GemmSplitK::CH, bool GUARDED = false>     // a template so that both translation units may instantiate it
 __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
+    if constexpr (GUARDED) { if (*g.guard == 0u) return; }
     using T = GemmSplitK;
     __shared__ f32x4 s_r[4 * T::NT * 64];
     const int z = blockIdx.z;
@@ -335,8 +339,9 @@ __global__ __launch_bounds__(256, 2) void gemm_splitk_kernel(GemmArgs g) {
 // per lane, all in flight at once, instead of 136 four-byte loads.  Partial accumulators are added through LDS in wave order.
 struct GemmSplitK4 { static constexpr int BM = 16, BN = 64, NW = 8, GMAX = 5; };
 
-template <int GMAX_ = GemmSplitK4::GMAX>     // a template so that both translation units may instantiate it
+template <int GMAX_ = GemmSplitK4::GMAX, bool GUARDED = false>     // a template so that both translation units may instantiate it
 __global__ __launch_bounds__(512, 1) void gemm_splitk4_kernel(GemmArgs g) {
+    if constexpr (GUARDED) { if (*g.guard == 0u) return; }
     using T = GemmSplitK4;
     __shared__ f32x4 s_r[T::NW * 4 * 64];
     const int z = blockIdx.z;
@@ -601,6 +606,49 @@ inline void gemm_launch(const GemmArgs& g, int nproblems, hipStream_t st) {
     } else {
         dim3 grid((g.M + Lat::BM - 1) / Lat::BM, (g.N + Lat::BN - 1) / Lat::BN, nproblems);
         hipLaunchKernelGGL(gemm_splitk_kernel<>, grid, dim3(256), 0, st, g);
+    }
+}
+
+// ---- the same launches behind a device-side guard (g.guard; conv_mfma.h: conv3x3_mfma_kernel<C, true>): the same kernel choice and
+// the same grids as gemm_launch, so a guarded repeat gives gemm_launch's bits.  Templates so that only the translation unit that
+// uses them (scs_api.hip: the f32 repeat behind the split inference kernels) instantiates the guarded kernels.
+template <int DUMMY = 0>
+inline hipError_t gemm_set_attrs_guarded() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<2, 6, SCS_GEMM_BK, SCS_GEMM_WPC, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)GemmTile<2, 6, SCS_GEMM_BK>::LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<1, 3, 32, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)GemmTile<1, 3, 32>::LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_v4_kernel<SCS_GEMM_MT, 6, SCS_GEMM_V4WPC, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)GemmV4Tile<SCS_GEMM_MT, 6>::LDS);
+}
+
+template <int DUMMY = 0>
+inline void gemm_launch_guarded(const GemmArgs& g, int nproblems, hipStream_t st) {
+    if (g.M <= 0 || !g.guard) return;
+    using Big = GemmTile<2, 6, SCS_GEMM_BK>;
+    using Small = GemmTile<1, 3, 32>;
+    using Lat = GemmSplitK;
+    const long big_wgs = (long)((g.M + Big::BM - 1) / Big::BM) * ((g.N + Big::BN - 1) / Big::BN) * nproblems;
+    const long small_wgs = (long)((g.M + Small::BM - 1) / Small::BM) * ((g.N + Small::BN - 1) / Small::BN) * nproblems;
+    using V4 = GemmV4Tile<SCS_GEMM_MT, 6>;
+    const long v4_wgs = (long)((g.M + V4::BM - 1) / V4::BM) * ((g.N + V4::BN - 1) / V4::BN) * nproblems;
+    if (v4_wgs >= 192 && gemm_vec4_ok(g, nproblems)) {
+        dim3 grid((g.M + V4::BM - 1) / V4::BM, (g.N + V4::BN - 1) / V4::BN, nproblems);
+        hipLaunchKernelGGL((gemm_mfma_v4_kernel<SCS_GEMM_MT, 6, SCS_GEMM_V4WPC, true>), grid, dim3(256), V4::LDS, st, g);
+    } else if (big_wgs >= 192) {
+        dim3 grid((g.M + Big::BM - 1) / Big::BM, (g.N + Big::BN - 1) / Big::BN, nproblems);
+        hipLaunchKernelGGL((gemm_mfma_kernel<2, 6, SCS_GEMM_BK, SCS_GEMM_WPC, true>), grid, dim3(256), Big::LDS, st, g);
+    } else if (small_wgs > 256) {
+        dim3 grid((g.M + Small::BM - 1) / Small::BM, (g.N + Small::BN - 1) / Small::BN, nproblems);
+        hipLaunchKernelGGL((gemm_mfma_kernel<1, 3, 32, 2, true>), grid, dim3(256), Small::LDS, st, g);
+    } else if (gemm_vec4_ok(g, nproblems)) {
+        dim3 grid((g.M + GemmSplitK4::BM - 1) / GemmSplitK4::BM, (g.N + GemmSplitK4::BN - 1) / GemmSplitK4::BN, nproblems);
+        hipLaunchKernelGGL((gemm_splitk4_kernel<GemmSplitK4::GMAX, true>), grid, dim3(512), 0, st, g);
+    } else {
+        dim3 grid((g.M + Lat::BM - 1) / Lat::BM, (g.N + Lat::BN - 1) / Lat::BN, nproblems);
+        hipLaunchKernelGGL((gemm_splitk_kernel<GemmSplitK::CH, true>), grid, dim3(256), 0, st, g);
     }
 }
 

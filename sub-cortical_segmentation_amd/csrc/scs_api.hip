@@ -154,7 +154,10 @@ __global__ void pack_dense_kernel(const float* __restrict__ W, const float* __re
 
 // ----------------------------------------------------------------------------- small kernels of the head
 // atlas -> columns 540..554 of the FC1 output rows (ConcatLayer elem_channels2, nets.py:224); column 555 = 0
-__global__ void atlas_concat_kernel(const float* __restrict__ atlas, const int32_t* __restrict__ index, int n_rows, float* __restrict__ fc1, int n) {
+// (guard, here and in the next two kernels: null, or a device word - the kernel does nothing while it is zero; forward_chunk_split)
+__global__ void atlas_concat_kernel(const float* __restrict__ atlas, const int32_t* __restrict__ index, int n_rows, float* __restrict__ fc1, int n,
+                                    const unsigned int* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * 16) return;
     const int row = e >> 4, c = e & 15;
@@ -164,7 +167,8 @@ __global__ void atlas_concat_kernel(const float* __restrict__ atlas, const int32
 
 // same from the 4-D prior volume at the patch centres, with the zero-row -> background rule (base.py:388-394)
 __global__ void atlas_gather_kernel(const float* __restrict__ atlas4d, const int32_t* __restrict__ centers,
-                                    int dx, int dy, int dz, float* __restrict__ fc1, int n) {
+                                    int dx, int dy, int dz, float* __restrict__ fc1, int n, const unsigned int* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n) return;
     const int x = centers[row * 3], y = centers[row * 3 + 1], z = centers[row * 3 + 2];
@@ -218,7 +222,9 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
                                                       const float* __restrict__ bout /*[16]*/, int n,
                                                       float* __restrict__ logits /*[n][16] or null*/,
                                                       float* __restrict__ probs /*[n][15] or null*/,
-                                                      int32_t* __restrict__ labels /*[n] or null*/) {
+                                                      int32_t* __restrict__ labels /*[n] or null*/,
+                                                      const unsigned int* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
     __shared__ __attribute__((aligned(16))) float s_w[kFC2 * 16 + 16];
     for (int e = threadIdx.x; e < kFC2 * 16; e += blockDim.x) s_w[e] = wout[e];
     if (threadIdx.x < 16) s_w[kFC2 * 16 + threadIdx.x] = bout[threadIdx.x];
@@ -482,10 +488,10 @@ static int alloc_packed(scs_ctx* h) {
         h->sp.dw[l] = reinterpret_cast<const uint4*>(h->sp_pack + s_dw[l]);
         h->sp.db[l] = reinterpret_cast<const float*>(h->sp_pack + s_db[l]);
     }
-    SCS_HIP(hipMalloc(&h->sp_flag, sizeof(unsigned int)));
-    SCS_HIP(hipMemset(h->sp_flag, 0, sizeof(unsigned int)));
-    SCS_HIP(hipHostMalloc(&h->sp_flag_host, sizeof(unsigned int)));
-    *h->sp_flag_host = 0;
+    SCS_HIP(hipMalloc(&h->sp_flag, 4 * sizeof(unsigned int)));
+    SCS_HIP(hipMemset(h->sp_flag, 0, 4 * sizeof(unsigned int)));
+    SCS_HIP(hipHostMalloc(&h->sp_flag_host, 4 * sizeof(unsigned int)));
+    memset(h->sp_flag_host, 0, 4 * sizeof(unsigned int));
     return SCS_OK;
 }
 
@@ -551,18 +557,29 @@ int ensure_workspace(scs_ctx* h, int need) {
         h->a_pool2[t] = h->ws + o2[t]; h->a_conv5[t] = h->ws + o5[t];
     }
     h->a_feat = h->ws + of; h->a_fc1 = h->ws + o_fc1; h->a_fc2 = h->ws + o_fc2; h->a_logits = h->ws + o_lg;
-    {   // rows of the split dense head: zero once (pads and K padding are never written afterwards)
-        const size_t rb17 = (size_t)ds_row_bytes(DsK17::KP), rb18 = (size_t)ds_row_bytes(DsFC2::KP);
-        const size_t tot = c * (4 * rb17 + rb18);
-        SCS_HIP(hipMalloc(&h->r_base, tot));
-        SCS_HIP(hipMemset(h->r_base, 0, tot));
-        SCS_HIP(hipDeviceSynchronize());                   // (the kernels that fill these rows may run on a non-blocking stream)
-        for (int t = 0; t < kTowers; ++t) h->r_c5[t] = h->r_base + (size_t)t * c * rb17;
-        h->r_feat = h->r_base + 3 * c * rb17;
-        h->r_fc1 = h->r_base + 4 * c * rb17;
-    }
     h->ws_chunk = need;
+    h->r_chunk = 0;                                        // (the split head's rows, if any, were freed above: ensure_split_rows)
     h->last_n = 0;
+    return SCS_OK;
+}
+
+// rows of the split dense head (dense_split.h) for chunks of the workspace's size: allocated on the first chunk that takes the
+// split-head branch - 11 KB per patch (363 MB at the default chunk) that a handle on the f32 kernels, or with split_head = 0, never
+// pays for - and zeroed once (pads and K padding are never written afterwards)
+static int ensure_split_rows(scs_ctx* h) {
+    if (h->r_base && h->r_chunk == h->ws_chunk) return SCS_OK;
+    SCS_HIP(hipDeviceSynchronize());                       // a previous call may still be using the old rows
+    if (h->r_base) { SCS_HIP(hipFree(h->r_base)); h->r_base = nullptr; }
+    const size_t c = (size_t)h->ws_chunk;
+    const size_t rb17 = (size_t)ds_row_bytes(DsK17::KP), rb18 = (size_t)ds_row_bytes(DsFC2::KP);
+    const size_t tot = c * (4 * rb17 + rb18);
+    SCS_HIP(hipMalloc(&h->r_base, tot));
+    SCS_HIP(hipMemset(h->r_base, 0, tot));
+    SCS_HIP(hipDeviceSynchronize());                       // (the kernels that fill these rows may run on a non-blocking stream)
+    for (int t = 0; t < kTowers; ++t) h->r_c5[t] = h->r_base + (size_t)t * c * rb17;
+    h->r_feat = h->r_base + 3 * c * rb17;
+    h->r_fc1 = h->r_base + 4 * c * rb17;
+    h->r_chunk = h->ws_chunk;
     return SCS_OK;
 }
 
@@ -595,7 +612,7 @@ static int forward_head_split(scs_ctx* h, const float* atlas, const float* vol, 
     dense_split_launch<DsFC2>(d, 1, st);
     mark(7);
     hipLaunchKernelGGL(head_out_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->a_fc2, h->pk.outw, h->pk.outb, n,
-                       h->a_logits, probs, labels);
+                       h->a_logits, probs, labels, (const unsigned int*)nullptr);
     mark(8);
     SCS_HIP(hipGetLastError());
     h->last_n = n;
@@ -606,13 +623,18 @@ static int forward_head_split(scs_ctx* h, const float* atlas, const float* vol, 
 int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
                   int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev, const X0Src* x0,
-                  const int32_t* atlas_index, bool split) {
+                  const int32_t* atlas_index, int mode) {
     const PackedNet& pk = h->pk;
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
     mark(0);
-    h->last_split = false;
-    h->last_split_head = false;
+    const bool split = mode == kFwdSplit;
+    const unsigned int* guard = mode == kFwdF32Guarded ? h->sp_flag : nullptr;
+    if (!guard) {                         // (a guarded repeat leaves the record of the split pass in front of it alone)
+        h->last_split = false;
+        h->last_split_head = false;
+    }
     if (split && (ax || vol) && !x0) {
+        if (h->opt.split_head != 0) { const int rc = ensure_split_rows(h); if (rc != SCS_OK) return rc; }
         // the towers on the f16 matrix cores (conv_split.h); activations between the launches are two f16 planes [pixel][channel]
         // per patch-tower in the f32 path's buffers (same bytes per element); conv5 leaves f32 [n][540] for the head
         Split12Args a12{};
@@ -650,7 +672,7 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
         return forward_head(h, c5s, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, n, atlas_index);
     }
     ConvArgs a{};
-    a.n = n;
+    a.n = n; a.guard = guard;
     // conv1 + conv2 + pool1
     for (int t = 0; t < kTowers; ++t) {
         a.w[t] = pk.convw[t][1]; a.bias[t] = pk.convb[t][1]; a.out[t] = h->a_pool1[t];
@@ -662,13 +684,13 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     } else if (vol) {
         a.in[0] = a.in[1] = a.in[2] = vol;
         a.centers = centers; a.dimx = dx; a.dimy = dy; a.dimz = dz;
-        conv_launch<CfgConv12V>(a, st);
+        if (guard) conv_launch_guarded<CfgConv12V>(a, st); else conv_launch<CfgConv12V>(a, st);
     } else {
         a.in[0] = ax; a.in[1] = co; a.in[2] = sa;
-        conv_launch<CfgConv12>(a, st);
+        if (guard) conv_launch_guarded<CfgConv12>(a, st); else conv_launch<CfgConv12>(a, st);
     }
     mark(1);
-    if (h->opt.fwd_fused > 0) {
+    if (h->opt.fwd_fused > 0 && !guard) {        // (a guarded repeat takes the three launches below: the same bits)
         // conv3 -> conv4 + pool2 -> conv5 as ONE kernel per patch-tower (conv_fused.h): the two activations in between stay in LDS;
         // same bits as the three launches below.  An OPTION (fwd_fused = 1), not the default: it cuts the net's HBM traffic from
         // ~280 to ~113 KB per patch but streams every layer's weights through LDS once per patch-tower and runs 20 % slower than
@@ -688,50 +710,74 @@ int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa,
     }
     // conv3
     for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_pool1[t]; a.w[t] = pk.convw[t][2]; a.bias[t] = pk.convb[t][2]; a.out[t] = h->a_conv3[t]; }
-    conv_launch<CfgConv3>(a, st);
+    if (guard) conv_launch_guarded<CfgConv3>(a, st); else conv_launch<CfgConv3>(a, st);
     mark(2);
     // conv4 + pool2
     for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_conv3[t]; a.w[t] = pk.convw[t][3]; a.bias[t] = pk.convb[t][3]; a.out[t] = h->a_pool2[t]; }
-    conv_launch<CfgConv4>(a, st);
+    if (guard) conv_launch_guarded<CfgConv4>(a, st); else conv_launch<CfgConv4>(a, st);
     mark(3);
     // conv5
     for (int t = 0; t < kTowers; ++t) { a.in[t] = h->a_pool2[t]; a.w[t] = pk.convw[t][4]; a.bias[t] = pk.convb[t][4]; a.out[t] = h->a_conv5[t]; }
-    conv_launch<CfgConv5>(a, st);
+    if (guard) conv_launch_guarded<CfgConv5>(a, st); else conv_launch<CfgConv5>(a, st);
     mark(4);
     const float* c5[kTowers] = {h->a_conv5[0], h->a_conv5[1], h->a_conv5[2]};
-    return forward_head(h, c5, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, x0 ? x0->n_samples : n, atlas_index);
+    return forward_head(h, c5, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, ev, x0 ? x0->n_samples : n, atlas_index, guard);
+}
+
+// One chunk with option fwd_split, entirely on the stream (nothing here waits for the device): the split kernels; then the f32 kernels
+// of the same chunk in their guarded forms - every workgroup of them reads the overflow flag the split kernels may have raised
+// (conv_split.h: a scaled activation beyond the f16 range) and leaves at once while it is clear, so a flagged chunk is done again on
+// the exact-f32 kernels (the bits scs_forward gives without the option) and a clean one costs ten near-empty launches; then one
+// thread counts the repeat, records whether this chunk's buffers now hold the f32 layouts (scs_get_activation) and clears the flag
+// for the next chunk.
+__global__ void split_settle_kernel(unsigned int* __restrict__ words) {
+    const unsigned int f = words[0];
+    words[1] = f ? 1u : 0u;
+    if (f) { words[2] += 1u; words[0] = 0u; }
+}
+static int forward_chunk_split(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
+                               const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
+                               int n, float* probs, int32_t* labels, hipStream_t st) {
+    int rc = forward_chunk(h, ax, co, sa, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, nullptr, nullptr, nullptr, kFwdSplit);
+    if (rc != SCS_OK) return rc;
+    rc = forward_chunk(h, ax, co, sa, atlas, vol, dx, dy, dz, centers, atlas4d, n, probs, labels, st, nullptr, nullptr, nullptr, kFwdF32Guarded);
+    if (rc != SCS_OK) return rc;
+    hipLaunchKernelGGL(split_settle_kernel, dim3(1), dim3(1), 0, st, h->sp_flag);
+    SCS_HIP(hipGetLastError());
+    return SCS_OK;
 }
 
 // The fusion head of one chunk: c5[t] = the towers' flattened block-5 outputs [n][540] (nets.py:176-231: d1 x3, FC1 on their
 // concatenation, fc_2 on [FC1 | atlas prior], out + softmax); marks 5..8 of the profiled forward.
 int forward_head(scs_ctx* h, const float* const c5[kTowers], const float* atlas, const float* vol, int dx, int dy, int dz,
                  const int32_t* centers, const float* atlas4d, int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
-                 int atlas_rows, const int32_t* atlas_index) {
+                 int atlas_rows, const int32_t* atlas_index, const unsigned int* guard) {
     const PackedNet& pk = h->pk;
     auto mark = [&](int i) { if (ev) (void)hipEventRecord(ev[i], st); };
+    auto gemm = [&](const GemmArgs& g, int np) { if (guard) gemm_launch_guarded(g, np, st); else gemm_launch(g, np, st); };
     // d1 x3 -> feat[:, 180 t : 180 t + 180]
     GemmArgs g{};
-    g.M = n; g.K4 = kFlat; g.N = kD1; g.relu = 1;
+    g.M = n; g.K4 = kFlat; g.N = kD1; g.relu = 1; g.guard = guard;
     for (int t = 0; t < kTowers; ++t) g.p[t] = GemmProblem{c5[t], kFlat, pk.d1w[t], gemm_ns(kD1), pk.d1b[t], h->a_feat + t * kD1, kFlat};
-    gemm_launch(g, kTowers, st);
+    gemm(g, kTowers);
     mark(5);
     // FC1 -> fc1[:, 0:540]; atlas -> fc1[:, 540:556]
     g.K4 = kFC1; g.N = kFC1;
     g.p[0] = GemmProblem{h->a_feat, kFlat, pk.fc1w, gemm_ns(kFC1), pk.fc1b, h->a_fc1, kFC1ld};
-    gemm_launch(g, 1, st);
+    gemm(g, 1);
     if (vol && atlas4d)
-        hipLaunchKernelGGL(atlas_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->a_fc1, n);
+        hipLaunchKernelGGL(atlas_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, atlas4d, centers, dx, dy, dz, h->a_fc1, n, guard);
     else
-        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, atlas_index, atlas_rows, h->a_fc1, n);
+        hipLaunchKernelGGL(atlas_concat_kernel, dim3((n * 16 + 255) / 256), dim3(256), 0, st, atlas, atlas_index, atlas_rows, h->a_fc1, n, guard);
     mark(6);
     // fc_2
     g.K4 = kFC1ld; g.N = kFC2;
     g.p[0] = GemmProblem{h->a_fc1, kFC1ld, pk.fc2w, gemm_ns(kFC2), pk.fc2b, h->a_fc2, kFC2ld};
-    gemm_launch(g, 1, st);
+    gemm(g, 1);
     mark(7);
     // out + softmax + argmax
     hipLaunchKernelGGL(head_out_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->a_fc2, pk.outw, pk.outb, n,
-                       h->a_logits, probs, labels);
+                       h->a_logits, probs, labels, guard);
     mark(8);
     SCS_HIP(hipGetLastError());
     h->last_n = n;
@@ -818,6 +864,13 @@ static int set_kernel_attrs() {
     SCS_HIP(dense_split_set_attr<DsK17>());
     SCS_HIP(dense_split_set_attr<DsFC2>());
     SCS_HIP(gemm_set_attrs());
+    // the guarded forms of the f32 inference kernels (forward_chunk_split)
+    SCS_HIP(conv_set_attr_guarded<CfgConv12>());
+    SCS_HIP(conv_set_attr_guarded<CfgConv12V>());
+    SCS_HIP(conv_set_attr_guarded<CfgConv3>());
+    SCS_HIP(conv_set_attr_guarded<CfgConv4>());
+    SCS_HIP(conv_set_attr_guarded<CfgConv5>());
+    SCS_HIP(gemm_set_attrs_guarded());
     return SCS_OK;
 }
 
@@ -956,6 +1009,12 @@ int scs_set_option(scs_handle h, const char* name, int64_t value) {
     SCS_ARG(slot != nullptr, "unknown option name");
     SCS_ARG(value >= -1 && value <= (1 << 20), "option value out of range");
     *slot = (int)value;
+    if (slot == &h->opt.split_fallbacks) {                 // the counter lives on the device (sp_flag[2]): set it behind everything enqueued
+        SCS_HIP(hipSetDevice(h->device));
+        SCS_HIP(hipDeviceSynchronize());
+        const unsigned int v = value > 0 ? (unsigned int)value : 0u;
+        SCS_HIP(hipMemcpy(h->sp_flag + 2, &v, sizeof(v), hipMemcpyHostToDevice));
+    }
     return SCS_OK;
 }
 
@@ -963,6 +1022,13 @@ int scs_get_option(scs_handle h, const char* name, int64_t* value) {
     SCS_ARG(h && name && value, "null handle, option name or output");
     int* slot = option_slot(h, name);
     SCS_ARG(slot != nullptr, "unknown option name");
+    if (slot == &h->opt.split_fallbacks) {                 // counted on the device by the chunks' settle launches: read behind everything enqueued
+        SCS_HIP(hipSetDevice(h->device));
+        SCS_HIP(hipDeviceSynchronize());
+        unsigned int v = 0;
+        SCS_HIP(hipMemcpy(&v, h->sp_flag + 2, sizeof(v), hipMemcpyDeviceToHost));
+        *slot = (int)v;
+    }
     *value = *slot;
     return SCS_OK;
 }
@@ -1024,13 +1090,13 @@ static int balanced_chunk(int64_t n, int max_chunk) {
     return (int)(c > max_chunk ? max_chunk : c);
 }
 
-// behind the split kernels of a call: wait for the stream and read (and clear) the overflow flag: 1 = set, 0 = clean, < 0 = error
+// (scs_forward_profiled only: the timed split pass has no f32 repeat behind it) wait for the stream and read (and clear) the overflow
+// flag: 1 = set, 0 = clean, < 0 = error
 static int split_overflowed(scs_ctx* h, hipStream_t st) {
     SCS_HIP(hipMemcpyAsync(h->sp_flag_host, h->sp_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
     SCS_HIP(hipStreamSynchronize(st));
     if (*h->sp_flag_host == 0) return 0;
     SCS_HIP(hipMemsetAsync(h->sp_flag, 0, sizeof(unsigned int), st));
-    ++h->opt.split_fallbacks;
     return 1;
 }
 
@@ -1047,21 +1113,21 @@ static int forward_common(scs_handle h, const float* ax, const float* co, const 
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
-    // fwd_split: patch inputs run on the split kernels; the call then waits for the stream, reads the overflow flag and repeats
-    // the batch on the f32 kernels if a scaled activation left the f16 range (conv_split.h)
+    // fwd_split: every chunk on the split kernels with its guarded f32 repeat behind it (forward_chunk_split) - the call enqueues
+    // and returns like the f32 form.  The flag word is cleared in front of the first chunk on THIS stream (a call that failed half
+    // way, or the profiled entry, may have left it set).
     const bool split = h->opt.fwd_split > 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool sp = split && pass == 0;
-        for (int64_t s = 0; s < n; s += step) {
-            const int m = (int)((n - s < step) ? (n - s) : step);
-            rc = forward_chunk(h, ax ? ax + s * 1024 : nullptr, co ? co + s * 1024 : nullptr, sa ? sa + s * 1024 : nullptr,
-                               atlas ? atlas + s * 15 : nullptr, vol, dx, dy, dz, centers ? centers + s * 3 : nullptr, atlas4d,
-                               m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, nullptr, nullptr, nullptr, sp);
-            if (rc != SCS_OK) return rc;
-        }
-        if (!sp) break;
-        rc = split_overflowed(h, st);
-        if (rc <= 0) return rc;                              // 0: clean; < 0: error; 1: repeat on the f32 kernels
+    if (split) SCS_HIP(hipMemsetAsync(h->sp_flag, 0, sizeof(unsigned int), st));
+    for (int64_t s = 0; s < n; s += step) {
+        const int m = (int)((n - s < step) ? (n - s) : step);
+        const float *cax = ax ? ax + s * 1024 : nullptr, *cco = co ? co + s * 1024 : nullptr, *csa = sa ? sa + s * 1024 : nullptr;
+        const float* cat = atlas ? atlas + s * 15 : nullptr;
+        const int32_t* cc = centers ? centers + s * 3 : nullptr;
+        float* cp = probs ? probs + s * 15 : nullptr;
+        int32_t* cl = labels ? labels + s : nullptr;
+        rc = split ? forward_chunk_split(h, cax, cco, csa, cat, vol, dx, dy, dz, cc, atlas4d, m, cp, cl, st)
+                   : forward_chunk(h, cax, cco, csa, cat, vol, dx, dy, dz, cc, atlas4d, m, cp, cl, st, nullptr, nullptr, nullptr, kFwdF32);
+        if (rc != SCS_OK) return rc;
     }
     return SCS_OK;
 }
@@ -1213,20 +1279,14 @@ int scs_forward_host(scs_handle h, const float* ax, const float* co, const float
         }
         const Buf& d = buf[which];
         hipError_t e = hipSuccess;
-        for (int pass = 0; pass < 2; ++pass) {
-            // fwd_split: the chunk on the split kernels first; its overflow flag comes back with the results, and a flagged chunk
-            // is repeated on the f32 kernels (conv_split.h)
-            const bool sp = h->opt.fwd_split > 0 && pass == 0;
-            rc = forward_chunk(h, d.ax, d.co, d.sa, d.at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d.pr, d.lb, sc, nullptr, nullptr, nullptr, sp);
-            if (rc == SCS_OK && sp) e = hipMemcpyAsync(h->sp_flag_host, h->sp_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, sc);
-            if (rc == SCS_OK && e == hipSuccess && probs) e = hipMemcpyAsync(probs + s * 15, d.pr, m * 60, hipMemcpyDeviceToHost, sc);
-            if (rc == SCS_OK && e == hipSuccess && labels) e = hipMemcpyAsync(labels + s, d.lb, m * 4, hipMemcpyDeviceToHost, sc);
-            if (e == hipSuccess) e = hipStreamSynchronize(sc);
-            if (rc != SCS_OK || e != hipSuccess || !sp || *h->sp_flag_host == 0) break;
-            e = hipMemsetAsync(h->sp_flag, 0, sizeof(unsigned int), sc);
-            ++h->opt.split_fallbacks;
-            if (e != hipSuccess) break;
-        }
+        // fwd_split: the chunk on the split kernels with its guarded f32 repeat behind it (forward_chunk_split)
+        if (h->opt.fwd_split > 0) {
+            if (s == 0) e = hipMemsetAsync(h->sp_flag, 0, sizeof(unsigned int), sc);
+            rc = e == hipSuccess ? forward_chunk_split(h, d.ax, d.co, d.sa, d.at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d.pr, d.lb, sc) : SCS_OK;
+        } else rc = forward_chunk(h, d.ax, d.co, d.sa, d.at, nullptr, 0, 0, 0, nullptr, nullptr, (int)m, d.pr, d.lb, sc, nullptr, nullptr, nullptr, kFwdF32);
+        if (rc == SCS_OK && e == hipSuccess && probs) e = hipMemcpyAsync(probs + s * 15, d.pr, m * 60, hipMemcpyDeviceToHost, sc);
+        if (rc == SCS_OK && e == hipSuccess && labels) e = hipMemcpyAsync(labels + s, d.lb, m * 4, hipMemcpyDeviceToHost, sc);
+        if (e == hipSuccess) e = hipStreamSynchronize(sc);
         if (next.joinable()) next.join();
         if (inline_upload) upload(s + hstep, which ^ 1, &nerr);
         if (rc != SCS_OK) return rc;
@@ -1247,6 +1307,7 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
     if (rc != SCS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (h->packed_dirty) { rc = repack_inference(h, st); if (rc != SCS_OK) return rc; h->packed_dirty = false; }
+    if (h->opt.fwd_split > 0) SCS_HIP(hipMemsetAsync(h->sp_flag, 0, 2 * sizeof(unsigned int), st));      // (words 0, 1; the profiled pass has no f32 repeat)
     const int nchunks = (int)((n + step - 1) / step);
     std::vector<hipEvent_t> ev;
     try { ev.resize((size_t)nchunks * 9); } catch (...) { set_error("out of host memory"); return SCS_ERR_HIP; }
@@ -1256,7 +1317,7 @@ int scs_forward_profiled(scs_handle h, const float* ax, const float* co, const f
         const int m = (int)((n - s < step) ? (n - s) : step);
         rc = forward_chunk(h, ax + s * 1024, co + s * 1024, sa + s * 1024, atlas + s * 15, nullptr, 0, 0, 0, nullptr, nullptr,
                            m, probs ? probs + s * 15 : nullptr, labels ? labels + s : nullptr, st, &ev[(size_t)c * 9], nullptr, nullptr,
-                           h->opt.fwd_split > 0);
+                           h->opt.fwd_split > 0 ? kFwdSplit : kFwdF32);
         if (rc != SCS_OK) break;
     }
     if (rc == SCS_OK) {
@@ -1284,6 +1345,12 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
     if (!h->ws || h->last_n <= 0) { set_error("no forward has run"); return SCS_ERR_STATE; }
     SCS_HIP(hipSetDevice(h->device));
     SCS_HIP(hipDeviceSynchronize());
+    bool last_split = h->last_split, last_split_head = h->last_split_head;
+    if (last_split) {                                      // a chunk the guarded f32 kernels repeated holds THEIR layouts (sp_flag[1])
+        unsigned int repeated = 0;
+        SCS_HIP(hipMemcpy(&repeated, h->sp_flag + 1, sizeof(repeated), hipMemcpyDeviceToHost));
+        if (repeated) last_split = last_split_head = false;
+    }
     const size_t n = (size_t)h->last_n;
     size_t per = 0;
     float* const* tow = nullptr;
@@ -1307,7 +1374,7 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
         SCS_ARG(count == 3 * n * per, "count does not match 3*n*per-patch size");
         for (int t = 0; t < kTowers; ++t)
             SCS_HIP(hipMemcpy(host_out + t * n * per, tow[t], n * per * sizeof(float), hipMemcpyDeviceToHost));
-        if (h->last_split && which <= 2) {
+        if (last_split && which <= 2) {
             // the split forward left two f16 planes [pixel][channel] (hi, lo; times the activation scale) per patch-tower in the same
             // bytes: back to f32 [channel][pixel]
             const int ch = which == 0 ? 20 : 40, px = (int)per / ch;
@@ -1324,7 +1391,7 @@ int scs_get_activation(scs_handle h, int which, float* host_out, size_t count) {
         SCS_ARG(count == n * per, "count does not match n*row size");
         SCS_HIP(hipMemcpy(host_out, single, n * per * sizeof(float), hipMemcpyDeviceToHost));
     }
-    if (h->last_split_head && which >= 3 && which <= 5) {
+    if (last_split_head && which >= 3 && which <= 5) {
         // the split head keeps these as rows of halves (dense_split.h): back to the f32 layouts of the ids
         const int kp = which == 5 ? DsFC2::KP : DsK17::KP, cols = which == 5 ? kFC1 + kAtlas : kFlat, rb = ds_row_bytes(kp);
         std::vector<unsigned char> rows(n * rb);

@@ -27,7 +27,7 @@ struct scs_options {
                                      // (conv_split.h: f32-grade results, ~2x the f32-MFMA rate); scs_forward / scs_forward_profiled on patch inputs;
                                      // the call then returns after the work has finished (it reads the overflow flag and, if a scaled activation
                                      // left the f16 range, repeats the batch on the f32 kernels).  Default (-1, 0): the exact-f32 MFMA kernels
-    int split_fallbacks = 0;         // (counter, read with scs_get_option) batches repeated on the f32 kernels after such an overflow
+    int split_fallbacks = 0;         // (counter, read with scs_get_option: the device word sp_flag[2]) chunks repeated on the f32 kernels after such an overflow
     int split_head = -1;             // SCS_SPLIT_HEAD: with fwd_split, 0 = the dense head on the f32-MFMA GEMMs (round-5's first form); default
                                      // (-1, 1): d1 x3, FC1, fc_2 on the split kernels of dense_split.h as well
     int train_split = -1;            // SCS_TRAIN_SPLIT: 1 = the training forward's conv1 + conv2 block on the f16 matrix cores with split operands
@@ -72,9 +72,12 @@ struct scs_ctx {
     unsigned char* r_c5[scs::kTowers]{};      // [chunk] rows of 544 halves per piece: the towers' flattened block-5 outputs
     unsigned char* r_feat = nullptr;          // [chunk] rows of 544: d1 x3 side by side (FC1's input)
     unsigned char* r_fc1 = nullptr;           // [chunk] rows of 576: FC1 output + atlas prior (fc_2's input)
-    unsigned char* r_base = nullptr;
-    unsigned int* sp_flag = nullptr;           // overflow flag of the split kernels (device) ...
-    unsigned int* sp_flag_host = nullptr;      // ... and its pinned host copy
+    unsigned char* r_base = nullptr;          // (allocated by the first chunk that takes the split-head branch: scs_api.hip, ensure_split_rows)
+    int r_chunk = 0;                          // chunk size those rows were allocated for
+    unsigned int* sp_flag = nullptr;           // device words: [0] overflow flag of the split kernels of the chunk in flight (the guard of
+                                               // the f32 repeat behind them), [1] whether the LAST chunk was repeated (its buffers then hold the f32
+                                               // kernels' layouts), [2] chunks repeated so far (option split_fallbacks)
+    unsigned int* sp_flag_host = nullptr;      // pinned host copy of those words (read behind a synchronisation only)
     bool last_split = false;                   // the last forward left split planes in a_pool1 / a_conv3 / a_pool2
     bool last_split_head = false;              // ... and rows of halves in r_c5 / r_feat / r_fc1 (the split dense head)
 
@@ -115,9 +118,12 @@ int repack_inference(scs_ctx* h, hipStream_t st);
 int forward_chunk(scs_ctx* h, const float* ax, const float* co, const float* sa, const float* atlas,
                   const float* vol, int dx, int dy, int dz, const int32_t* centers, const float* atlas4d,
                   int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
-                  const X0Src* x0 = nullptr, const int32_t* atlas_index = nullptr, bool split = false);
+                  const X0Src* x0 = nullptr, const int32_t* atlas_index = nullptr, int mode = 0);
 int forward_head(scs_ctx* h, const float* const c5[kTowers], const float* atlas, const float* vol, int dx, int dy, int dz,
                  const int32_t* centers, const float* atlas4d, int n, float* probs, int32_t* labels, hipStream_t st, hipEvent_t* ev,
-                 int atlas_rows, const int32_t* atlas_index);
+                 int atlas_rows, const int32_t* atlas_index, const unsigned int* guard = nullptr);
+// forward_chunk modes: the f32 kernels; the split kernels (option fwd_split); the f32 kernels behind the device-side guard
+// h->sp_flag (they run only if a split kernel of the same chunk raised the overflow flag: scs_api.hip, forward_chunk_split)
+enum { kFwdF32 = 0, kFwdSplit = 1, kFwdF32Guarded = 2 };
 void train_free(scs_ctx* h);
 }

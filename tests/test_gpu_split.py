@@ -124,6 +124,66 @@ def test_out_of_range_activations_fall_back_to_the_f32_kernels(split):
     assert np.array_equal(probs, p32) and np.array_equal(labels, l32)
 
 
+def test_a_flagged_chunk_is_repeated_on_the_device_and_the_others_are_not(split):
+    """The repeat is per internal chunk and happens on the device (guarded f32 launches behind the split kernels of the chunk, no host
+    round trip): with 64-row chunks and out-of-range inputs in rows 64..127 only, that chunk carries the f32 path's bits, the
+    other three the split kernels', and the device counter reads 1."""
+    g = gold('g1_random.npz')
+    n = 256
+    rep = lambda a: np.concatenate([a] * (n // a.shape[0] + 1))[:n].copy()
+    ax, co, sa, at = (rep(g[k]) for k in ('ax', 'co', 'sa', 'atlas'))
+    assert split.set_chunk(64) == 64
+    try:
+        p_split, l_split = run_forward(split, ax, co, sa, at)                  # clean: all four chunks on the split kernels
+        assert split.get_option('split_fallbacks') == 0
+        ax[64:128] *= 3.0e4
+        probs, labels = run_forward(split, ax, co, sa, at)
+        assert split.get_option('split_fallbacks') == 1
+        split.set_option('fwd_split', -1)
+        p32, l32 = run_forward(split, ax, co, sa, at)
+    finally:
+        split.set_chunk(32768)
+    hot = np.zeros(n, bool)
+    hot[64:128] = True
+    assert np.array_equal(probs[hot], p32[hot]) and np.array_equal(labels[hot], l32[hot])
+    assert np.array_equal(probs[~hot], p_split[~hot]) and np.array_equal(labels[~hot], l_split[~hot])
+    assert not np.array_equal(p_split[~hot], p32[~hot])                      # (the two forms do differ in the last bits)
+
+
+def test_the_split_entries_enqueue_and_return(split):
+    """work is ENQUEUED on the caller's stream.  With fwd_split the call used to wait for the stream to read the overflow
+    flag; now nothing in it synchronises - shown by capturing it into a HIP graph (any synchronisation or blocking copy inside a
+    capture is an error) and replaying the graph on new inputs, clean and overflowing."""
+    from test_gpu_forward import dev
+    g = gold('g1_random.npz')
+    n = g['ax'].shape[0]
+    d = [dev(g[k]) for k in ('ax', 'co', 'sa', 'atlas')]
+    pr = torch.empty((n, 15), device='cuda:0')
+    lb = torch.empty((n,), dtype=torch.int32, device='cuda:0')
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        split.forward(*d, n, pr, lb, s.cuda_stream)                            # warm-up: the workspace exists before the capture
+    s.synchronize()
+    want = pr.clone()
+    graph = torch.cuda.CUDAGraph()
+    pr.zero_()
+    with torch.cuda.graph(graph, stream=s):
+        split.forward(*d, n, pr, lb, torch.cuda.current_stream().cuda_stream)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(pr, want) and split.get_option('split_fallbacks') == 0
+    for t in d[:3]:
+        t.mul_(3.0e4)                                                          # same buffers, out-of-range values: the replay repeats on f32
+    graph.replay()
+    torch.cuda.synchronize()
+    assert split.get_option('split_fallbacks') == 1
+    split.set_option('fwd_split', -1)
+    p32 = torch.empty_like(pr)
+    split.forward(*d, n, p32, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(pr, p32)
+
+
 def test_gather_fused_volume_path_on_the_split_kernels_equals_their_patch_path(split):
     """scs_forward_volume with fwd_split: the conv1 + conv2 + pool1 split kernel cuts the patches itself (tri-planar gather of
     base.py:293-306, zero padded): the same bits as the split patch entry on the patches the literal restatement cut."""
@@ -163,7 +223,14 @@ def test_full_size_properties_on_the_split_path(split):
     torch.cuda.synchronize()
     assert torch.equal(p2, p1[perm]) and torch.equal(l2, l1[perm]) and torch.equal(p3, p1)
     assert (p1.sum(1) - 1).abs().max().item() < 1e-5
+    assert torch.equal(l1.long(), p1.argmax(1))
     assert split.get_option('split_fallbacks') == 0
+    # spot-check a slice against the float64 oracle (as the f32 twin does: tests/test_gpu_forward.py::test_full_size_properties)
+    from cnn_cort import params as P
+    from conftest import WEIGHTS
+    idx = np.arange(0, n, n // 16)[:16]
+    ref = O.forward(P.load_params(WEIGHTS), ax[idx], co[idx], sa[idx], at[idx])
+    assert np.abs(p1.cpu().numpy()[idx] - ref).max() < PROB_TOL
 
 
 def test_net_predict_with_fwd_split_option(weights):
@@ -188,3 +255,57 @@ def test_net_predict_with_fwd_split_option(weights):
         assert np.abs(psp - g['probs']).max() < PROB_TOL
         Xd = {k: torch.from_numpy(np.ascontiguousarray(v)).to('cuda:0') for k, v in X.items()}
         assert np.array_equal(nsp.predict(Xd), l32)
+
+
+@pytest.mark.timeout(900)
+def test_whole_subject_through_test_scan_on_the_split_kernels(tmp_path, weights):
+    """test_scan (base.py:401-458) with options['fwd_split'] = 'True' and the per-voxel towers (options['towers'] = 'patch') on the
+    256x256x192 15-class subject of BASELINE configs[4]: the raw labels equal the f32 path's on every ROI voxel, per-class Dice 1.0 over
+    all 15 classes, probabilities within 2e-5 of the f32 path's, and NO chunk fell back to the f32 kernels (split_fallbacks == 0: what
+    is compared is the split kernels' output).  The default towers ('auto': shared-tower evaluation on a dense ROI) stay on the f32
+    kernels and say so once."""
+    import os
+    import sys
+    import warnings
+    from conftest import ROOT, PKG
+    sys.path.insert(0, ROOT)
+    import bench
+    from cnn_cort import base, nifti, nets
+    from cnn_cort.nets import build_model
+    scan = bench.make_cohort(str(tmp_path), 1, seed=3, steered=True)[0]
+    sub = os.path.dirname(scan)
+    opts = {'experiment': 'miccai2012_v1', 'net_verbose': 0, 'train_split': 0.25, 'max_epochs': 1, 'patience': 20, 'patch_size': [32, 32],
+            'load_weights': 'True', 'batch_size': 128, 'device': 0, 'crop': 'True', 'test_batch_size': 100000, 'out_probabilities': 'True',
+            'post_process': 'False', 'debug': 'False', 'towers': 'patch'}
+    out = {}
+    for form in ('f32', 'split'):
+        o = dict(opts, fwd_split='True') if form == 'split' else dict(opts)
+        net = build_model(os.path.join(PKG, 'nets'), o)
+        base.test_scan(net, scan, o)
+        assert net.last_scan_towers == 'patch'
+        seg = nifti.load(os.path.join(sub, 'out_subcortical_rawseg.nii.gz')).get_data().copy()
+        prob = nifti.load(os.path.join(sub, 'out_subcortical_prob.nii.gz')).get_data()
+        roi = prob.sum(-1) != 0
+        out[form] = (seg, prob[roi].astype(np.float32), roi, net._handle.get_option('split_fallbacks'), net.last_scan_voxels)
+        if form == 'split':
+            assert net._handle.get_option('fwd_split') == 1
+            nets.Net._warned_split_shared = False
+            with pytest.warns(RuntimeWarning, match='shared-tower evaluation stays on the f32 kernels'):
+                base.test_scan(net, scan, dict(o, towers='auto', out_probabilities='False'))
+            assert net.last_scan_towers == 'shared'
+            assert np.array_equal(nifti.load(os.path.join(sub, 'out_subcortical_rawseg.nii.gz')).get_data(), out['f32'][0])
+            with warnings.catch_warnings():
+                warnings.simplefilter('error')                                  # ... once per process
+                base.test_scan(net, scan, dict(o, towers='auto', out_probabilities='False'))
+    (s32, p32, r32, _, n32), (ssp, psp, rsp, fallbacks, nsp) = out['f32'], out['split']
+    assert fallbacks == 0, '%d chunk(s) of the subject fell back to the f32 kernels' % fallbacks
+    assert n32 == nsp > 250000 and np.array_equal(r32, rsp)
+    assert np.array_equal(ssp, s32), '%d labels differ' % int((ssp != s32).sum())
+    live = np.unique(s32)
+    assert len(live) == 15, live
+    for k in live:                                                               # per-class Dice (trivially 1.0 with equal labels: stated for the record)
+        a, b = ssp == k, s32 == k
+        assert 2.0 * (a & b).sum() / (a.sum() + b.sum()) == 1.0
+    err = float(np.abs(psp - p32).max())
+    print('whole subject on the split kernels: %d ROI voxels, 15 classes, labels equal, max |p_split - p_f32| = %.3g, fallbacks %d' % (nsp, err, fallbacks))
+    assert err < 5e-5

@@ -12,9 +12,9 @@ import sys
 
 
 def short(name):
-    m = re.search(r'ConvCfg<([^>]*)>', name)
-    if m:
-        return 'conv<' + m.group(1).replace(' ', '') + '>'
+    m = re.search(r'ConvCfg<([^>]*)>(, true)?', name)
+    if m:               # (", true": the guarded instantiation behind the split kernels, scs_api.hip forward_chunk_split - its own row)
+        return ('guarded ' if m.group(2) else '') + 'conv<' + m.group(1).replace(' ', '') + '>'
     return name.split('(')[0].replace('scs::', '')
 
 

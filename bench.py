@@ -67,6 +67,26 @@ def synth_on_device(torch, n, seed, dev):
     return views[0], views[1], views[2], atlas
 
 
+def collective_config(world):
+    """What a SCALE reader needs beside the numbers: the bucket form of the gradient exchange (SCS_DP_BUCKETS: 1 = one all-reduce of
+    the arena behind the step, 2 = the dense head's bucket on a communication stream under the conv backward pass), the collective
+    library's version and the transport switches that were set."""
+    from cnn_cort import dist
+    out = {'dp_buckets': dist.dp_buckets(), 'world': world}
+    try:
+        import torch
+        v = torch.cuda.nccl.version()                                  # RCCL's version on ROCm builds
+        out['rccl_version'] = '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        out['torch'] = torch.__version__
+    except Exception as e:
+        out['rccl_version'] = 'unavailable (%s)' % type(e).__name__
+    env = {k: os.environ[k] for k in ('SCS_DP_BUCKETS', 'NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'RCCL_MSCCL_ENABLE',
+                                      'HSA_ENABLE_IPC_MODE_LEGACY', 'NCCL_P2P_DISABLE', 'NCCL_DEBUG') if k in os.environ}
+    if env:
+        out['env'] = env
+    return out
+
+
 def usable_cpus():
     """Host threads this process may actually run on: affinity mask capped by the cgroup CPU quota (the GPU boxes
     expose 256 logical CPUs but grant a 16-CPU share; 256 torch threads on that share run 100x slower)."""
@@ -685,7 +705,8 @@ def main():
         'dtype': 'f32' if args.dtype == 'f32' or args.mode == 'volume' else (SPLIT_DTYPE if args.mode == 'forward' else TRAIN_SPLIT_DTYPE), 'data': 'synthetic',
         'config': {'workload': workload, 'weights': 'miccai2012_v1 (shipped)', 'per_gpu_batch': B, 'chunk': chunk,
                    'parallelism': 'independent patch shards, no data-path collective' if args.mode != 'train'
-                   else 'dp%d, one RCCL all-reduce of the 3.5 MB gradient arena per step' % world},
+                   else 'dp%d, one RCCL all-reduce of the 3.5 MB gradient arena per step' % world,
+                   **collective_config(world)},
         'net_tflops': value * flop_per_patch / 1e12,
         'net_frac_of_f32_peak': value * flop_per_patch / 1e12 / (PEAK_F32_TFLOPS * world),
     }
@@ -814,7 +835,7 @@ def main():
                 h.set_option('train_split', -1)
             if rank == 0:
                 out['train_step'] = dict(blk, metric='tri-view 32x32 patches/s (train step: scs_train_step + all-reduce + scs_adam_apply)',
-                                         flop_per_patch=TRAIN_FLOP, dtype='f32', data='synthetic')
+                                         flop_per_patch=TRAIN_FLOP, dtype='f32', data='synthetic', collective=collective_config(world))
                 if sblk:
                     out['train_step']['split'] = sblk
         if not args.no_sustained:

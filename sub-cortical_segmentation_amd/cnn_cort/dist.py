@@ -161,12 +161,18 @@ def allreduce_grads(handle, active, stream=0, n_active=None, buckets=None):
     if not is_dist():                         # a process group of ONE rank still runs the collective (RCCL rehearsal on one GPU)
         return 1.0
     import torch
-    ptr, n = handle.grad_arena()
-    g = wrap_device_floats(ptr, n, handle.device)
+    g = _grad_arena_tensor(handle)
+    n = g.numel()
     td = _td()
     if buckets is None:
         buckets = dp_buckets()
-    if buckets == 2 and active:
+    if buckets == 2 and active and not g.is_cuda:
+        # host arena (the gloo rehearsal of tests/test_dist_cpu.py): no streams to overlap on, the SAME collectives in the same order
+        first, count = handle.wait_head_grads(0)
+        assert first + count == n
+        td.all_reduce(g[first:], op=td.ReduceOp.SUM)
+        td.all_reduce(g[:first], op=td.ReduceOp.SUM)
+    elif buckets == 2 and active:
         dev = g.device
         comm = _comm_streams.get(dev)
         if comm is None:
@@ -195,6 +201,16 @@ def allreduce_grads(handle, active, stream=0, n_active=None, buckets=None):
     return 1.0 / max(1, n_active)
 
 
+def _grad_arena_tensor(handle):
+    """The gradient arena of a handle as a flat torch tensor: a zero-copy view of libscs's device arena, or - for a stand-in handle
+    in the CPU rehearsals - whatever its grad_arena_tensor() returns."""
+    t = getattr(handle, 'grad_arena_tensor', None)
+    if t is not None:
+        return t()
+    ptr, n = handle.grad_arena()
+    return wrap_device_floats(ptr, n, handle.device)
+
+
 def handle_head_bucket(n):
     """(first float, count) of the dense head's bucket in an arena of n floats - the layout constant a rank WITHOUT a step of
     its own needs (an active rank gets it from scs_wait_head_grads)."""
@@ -208,8 +224,12 @@ def sync_params(handle):
     entries are already identical)."""
     if not is_dist():
         return
-    ptr, n = handle.param_arena()
-    p = wrap_device_floats(ptr, n, handle.device)
+    t = getattr(handle, 'param_arena_tensor', None)            # (stand-in handles of the CPU rehearsals, as _grad_arena_tensor)
+    if t is not None:
+        p = t()
+    else:
+        ptr, n = handle.param_arena()
+        p = wrap_device_floats(ptr, n, handle.device)
     td = _td()
     td.all_reduce(p, op=td.ReduceOp.SUM)
     p.mul_(1.0 / world_size())

@@ -94,6 +94,95 @@ def test_two_rank_gloo_data_parallel_plumbing():
     assert a['two_buckets_equal'] and b['two_buckets_equal'] and a['head_first'] == 436320 and (a['min'], b['min']) == (1.0, 1.0)
 
 
+class _HostHandle:
+    """Stand-in for a libscs handle in the gloo rehearsal: host gradient / parameter arenas with the real layout constants."""
+
+    def __init__(self, n, first):
+        self.g = torch.zeros(n, dtype=torch.float32)
+        self.p = torch.zeros(n, dtype=torch.float32)
+        self.first = first
+        self.waited = 0
+
+    def grad_arena_tensor(self):
+        return self.g
+
+    def param_arena_tensor(self):
+        return self.p
+
+    def wait_head_grads(self, stream):          # (_hip.Handle.wait_head_grads: first float and count of the dense head's bucket)
+        self.waited += 1
+        return self.first, self.g.numel() - self.first
+
+
+def _tail_worker(rank, world, port, q, buckets):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      SCS_DP_BUCKETS=str(buckets))
+    from cnn_cort import dist, params as P
+    dist.init_from_env(backend='gloo')
+    n, first = P.N_STORED, P.head_first_float()
+    h = _HostHandle(n, first)
+    ramp = torch.arange(n, dtype=torch.float32) * 1e-6
+    starts = [0, 8, 16]                              # three mini-batches over two ranks: step 1 has ONE active rank (rank 0)
+    got = []
+    for step, (start, active) in enumerate(dist.shard_steps(starts)):
+        def fill():
+            if active:                               # "this step's gradients": a ramp that identifies rank and step in every element
+                h.g.copy_(ramp + (10.0 * (step + 1) + rank))
+            else:
+                h.g.fill_(123.0)                     # stale gradients of the previous step: must not reach the sum
+        # once with the schedule known (what Net.fit passes), once asking the ranks (the extra flag exchange)
+        fill()
+        scale_known = dist.allreduce_grads(h, active, 0, n_active=dist.active_ranks(len(starts), step, world))
+        summed = h.g.clone().numpy()
+        fill()
+        scale_asked = dist.allreduce_grads(h, active, 0)
+        got.append((bool(active), scale_known, scale_asked, summed, h.g.clone().numpy()))
+    h.p.fill_(float(rank + 1))                       # the epoch's last collective, behind the ragged tail: the arena average
+    dist.sync_params(h)
+    dist.barrier()
+    q.put({'rank': rank, 'steps': got, 'waited': h.waited, 'buckets': dist.dp_buckets(), 'p': (float(h.p.min()), float(h.p.max()))})
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('buckets', [2, 1])
+def test_ragged_epoch_tail_in_the_bucketed_exchange(buckets):
+    """SURVEY 8(e) at the tail of an epoch, both bucket forms, REAL collectives in their real order (cnn_cort/dist.py,
+    allreduce_grads): three mini-batches over two ranks leave the second step with one active rank.  The inactive rank must zero its
+    stale arena and issue the same collectives in the same order as the active one - dense head's bucket, towers' bucket, (flag) -
+    or gloo pairs a 447 135-float all-reduce with a 436 320-float one and the exchange fails; the sums must be the active ranks'
+    gradients element for element and the scale 1 / active ranks, whether the schedule is passed in or asked for; the parameter
+    average of the epoch's end follows on the same group."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tail_worker, args=(r, world, port, q, buckets)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs], key=lambda d: d['rank'])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = res
+    assert a['buckets'] == b['buckets'] == buckets
+    from cnn_cort import params as P
+    ramp = (torch.arange(P.N_STORED, dtype=torch.float32) * 1e-6)
+    # step 0: both active -> sum of the two ramps, scale 1/2; step 1: rank 0 alone -> its ramp, scale 1
+    want0 = ((ramp + 10.0) + (ramp + 11.0)).numpy()
+    want1 = (ramp + 20.0).numpy()
+    for r in (a, b):
+        (act0, k0, s0, sum0, again0), (act1, k1, s1, sum1, again1) = r['steps']
+        assert act0 and act1 == (r['rank'] == 0)
+        assert (k0, s0, k1, s1) == (0.5, 0.5, 1.0, 1.0)
+        assert np.array_equal(sum0, want0) and np.array_equal(again0, want0)
+        assert np.array_equal(sum1, want1) and np.array_equal(again1, want1)          # the stale 123s of the idle rank are gone
+        assert r['p'] == (1.5, 1.5)
+    # an active rank asks libscs where the dense head's bucket starts (scs_wait_head_grads) exactly when it had a step of its own
+    assert (a['waited'], b['waited']) == ((4, 2) if buckets == 2 else (0, 0))
+
+
 def test_single_process_degrades_to_noops():
     from cnn_cort import dist
     assert dist.world_size() == 1 and dist.rank() == 0

@@ -736,11 +736,17 @@ def main():
                            'launch_ms': dur * 1e3, 'patches_per_launch': per_launch_patches}
         # beside the nominal peak: what this device issues when it does nothing but the MFMA the kernels are built on (live probe)
         try:
-            issue = h.probe_f32_mfma()
+            issue, ghz = h.probe_f32_mfma_clock()
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
             out['roofline']['device_mfma_issue_rate'] = {
-                'tflops': issue, 'achieved_frac_of_it': achieved / issue,
+                'tflops': issue, 'shader_clock_ghz': ghz,
+                # 4 SIMDs per CU x 2048 FLOP per instruction / 32 cycles at the measured clock: what the pipe gives at THAT clock
+                'pipe_rate_at_that_clock_tflops': cus * 4 * 2048 / 32 * ghz * 1e9 / 1e12 if ghz else None,
                 'what': 'back-to-back v_mfma_f32_16x16x4_f32, independent accumulators, operands in registers, four waves per SIMD on '
-                        'every CU (scs_probe_f32_mfma, three launches of ~4 ms, the last one timed, this process): the nominal peak prices the instruction at 32 cycles of 2.4 GHz'}
+                        'every CU (scs_probe_f32_mfma_clock, three launches of ~4 ms, the last one timed, this process), and the shader clock the '
+                        'device held meanwhile (s_memtime / s_memrealtime x 100 MHz, median over the workgroups).  The nominal peak prices the '
+                        'instruction at 32 cycles of 2.4 GHz; the probe runs at ~97 % of the pipe rate in cycles, so its spread over devices and '
+                        'runs is the clock.  Informational: `frac` above is against the nominal peak'}
         except Exception as e:                                            # informational: never fails the bench line
             out['roofline']['device_mfma_issue_rate'] = {'error': str(e)}
         out['stages'] = {names[i]: {'ms_per_step': float(ms[i]),

@@ -32,6 +32,7 @@ SIGNATURES = {
     'scs_set_option': (_c.c_int, [_vp, _c.c_char_p, _c.c_int64]),
     'scs_get_option': (_c.c_int, [_vp, _c.c_char_p, _c.POINTER(_c.c_int64)]),
     'scs_probe_f32_mfma': (_c.c_int, [_vp, _c.POINTER(_c.c_double)]),
+    'scs_probe_f32_mfma_clock': (_c.c_int, [_vp, _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     'scs_forward': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
     'scs_forward_host': (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int64, _vp, _vp]),
     'scs_forward_volume': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _c.c_int64, _vp, _vp, _vp]),
@@ -278,6 +279,12 @@ class Handle:
         v = ctypes.c_double(0.0)
         _check(self.lib.scs_probe_f32_mfma(self.h, ctypes.byref(v)), 'scs_probe_f32_mfma')
         return float(v.value)
+
+    def probe_f32_mfma_clock(self):
+        """(TFLOP/s of the same probe, shader clock in GHz held while it ran) - include/scs.h: scs_probe_f32_mfma_clock."""
+        v, g = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _check(self.lib.scs_probe_f32_mfma_clock(self.h, ctypes.byref(v), ctypes.byref(g)), 'scs_probe_f32_mfma_clock')
+        return float(v.value), float(g.value)
 
     # ---- inference
     def _check_inputs(self, ax, co, sa, atlas, n, y=None, probs=None, labels=None):

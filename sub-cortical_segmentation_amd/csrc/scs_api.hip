@@ -1033,12 +1033,15 @@ int scs_get_option(scs_handle h, const char* name, int64_t* value) {
     return SCS_OK;
 }
 
-// ---- scs_probe_f32_mfma: issue rate of v_mfma_f32_16x16x4_f32 (independent accumulators, operands in registers)
-__global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters) {
+// ---- scs_probe_f32_mfma[_clock]: issue rate of v_mfma_f32_16x16x4_f32 (independent accumulators, operands in registers), and the
+// shader clock the device holds while it runs them: one lane per workgroup stamps s_memtime (tick = shader cycle) and s_memrealtime
+// (the constant 100 MHz counter) around the loop - clock = d memtime / d memrealtime x 100 MHz (MI355X_MICROARCH.md, "DVFS give-back" (6))
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, unsigned long long* stamps /*[workgroup][2]: d memtime, d memrealtime*/, int iters) {
     f32x4 acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float x = threadIdx.x * 0.001f, y = 1.0f + threadIdx.x * 0.002f;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[i], 0, 0, 0);
@@ -1046,35 +1049,53 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters) 
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
     if (s == 12345.678f) out[blockIdx.x] = s;                    // keeps the accumulators alive; never true for these operands
 }
 
-int scs_probe_f32_mfma(scs_handle h, double* tflops) {
+int scs_probe_f32_mfma_clock(scs_handle h, double* tflops, double* shader_ghz) {
     SCS_ARG(h && tflops, "null handle or output");
     SCS_HIP(hipSetDevice(h->device));
     hipDeviceProp_t prop;
     SCS_HIP(hipGetDeviceProperties(&prop, h->device));
     const int cus = prop.multiProcessorCount, wgs = cus * 4, iters = 8000;     // 4 workgroups of 4 waves per CU: four waves per SIMD; ~4 ms per launch
     float* out = nullptr;
+    unsigned long long* stamps = nullptr;
     SCS_HIP(hipMalloc(&out, wgs * sizeof(float)));
+    hipError_t err = hipMalloc(&stamps, (size_t)wgs * 2 * sizeof(unsigned long long));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
-    hipError_t err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
     if (err == hipSuccess) err = hipEventCreate(&e1);
     for (int rep = 0; rep < 3 && err == hipSuccess; ++rep) {                     // the last of three launches is the one timed
         err = hipEventRecord(e0, nullptr);
-        hipLaunchKernelGGL(mfma_probe_kernel, dim3(wgs), dim3(256), 0, nullptr, out, iters);
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(wgs), dim3(256), 0, nullptr, out, stamps, iters);
         if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
         if (err == hipSuccess) err = hipEventSynchronize(e1);
         if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
     }
+    std::vector<unsigned long long> st;
+    if (err == hipSuccess && shader_ghz) {
+        try { st.resize((size_t)wgs * 2); } catch (...) { err = hipErrorOutOfMemory; }
+        if (err == hipSuccess) err = hipMemcpy(st.data(), stamps, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(out);
+    if (stamps) (void)hipFree(stamps);
     if (err != hipSuccess || !(ms > 0.f)) { set_error("scs_probe_f32_mfma: %s", hipGetErrorString(err)); return SCS_ERR_HIP; }
     *tflops = (double)wgs * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;         // 16x16x4 = 1024 MACs per wave-instruction
+    if (shader_ghz) {
+        std::vector<double> ghz;
+        for (int i = 0; i < wgs; ++i) if (st[2 * i + 1] > 0) ghz.push_back((double)st[2 * i] / (double)st[2 * i + 1] * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        *shader_ghz = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];                   // median over the workgroups
+    }
     return SCS_OK;
 }
+
+int scs_probe_f32_mfma(scs_handle h, double* tflops) { return scs_probe_f32_mfma_clock(h, tflops, nullptr); }
 
 int scs_set_chunk(scs_handle h, int patches_per_chunk) {
     if (!h) return SCS_ERR_ARG;

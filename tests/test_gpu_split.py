@@ -306,6 +306,21 @@ def test_whole_subject_through_test_scan_on_the_split_kernels(tmp_path, weights)
     for k in live:                                                               # per-class Dice (trivially 1.0 with equal labels: stated for the record)
         a, b = ssp == k, s32 == k
         assert 2.0 * (a & b).sum() / (a.sum() + b.sum()) == 1.0
-    err = float(np.abs(psp - p32).max())
-    print('whole subject on the split kernels: %d ROI voxels, 15 classes, labels equal, max |p_split - p_f32| = %.3g, fallbacks %d' % (nsp, err, fallbacks))
-    assert err < 5e-5
+    diff = np.abs(psp - p32).max(1)
+    err = float(diff.max())
+    # the logits of this steered subject reach +-80, so 1e-7 relative is 1e-5 of a probability near a tie (the f32 path itself is
+    # 4.5e-5 from the float32 CPU port on it, bench.py `dice`): the two device paths are compared at 2.5e-4, and BOTH are held to the
+    # 1e-4 bar against the float64 oracle on the 16 voxels where they differ most (patches cut by the literal per-voxel procedure)
+    from oracle import patches_ref as R
+    worst = np.argsort(diff)[-16:]
+    cs = [tuple(int(v) for v in c) for c in np.argwhere(r32)[worst]]
+    raw = nifti.load(scan).get_data()
+    vn = R.zscore_inference(raw)
+    views = [np.stack([np.array(R.get_patches(vn, cs, (32, 32), mode=m)).astype(np.float32)], axis=1) for m in ('axial', 'coronal', 'saggital')]
+    atlas = nifti.load(os.path.join(sub, 'tmp', 'MNI_sub_probabilities.nii.gz')).get_data()
+    p_ref = O.forward(weights, views[0], views[1], views[2], R.atlas_vectors(atlas, cs))
+    e32, esp = float(np.abs(p32[worst] - p_ref).max()), float(np.abs(psp[worst] - p_ref).max())
+    print('whole subject on the split kernels: %d ROI voxels, 15 classes, labels equal, fallbacks %d; max |p_split - p_f32| = %.3g; on the 16 voxels '
+          'where the two paths differ most, against the float64 oracle: f32 path %.3g, split path %.3g' % (nsp, fallbacks, err, e32, esp))
+    assert err < 2.5e-4
+    assert e32 < 1e-4 and esp < 1e-4

@@ -60,7 +60,8 @@ def _workers():
     except AttributeError:
         n = os.cpu_count() or 1
     try:                                               # container CPU quota (cgroup v2), when one is set
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        with open("/sys/fs/cgroup/cpu.max") as _f:
+            quota, period = _f.read().split()
         if quota != 'max':
             n = min(n, max(1, int(quota) // int(period)))
     except (OSError, ValueError):

@@ -50,6 +50,23 @@ constexpr int kSp12XFloats = 1024 + 64;        // raw patch + pad (tiles of the 
 constexpr size_t kSp12LdsBytes = 2 * (size_t)kSp12PlaneBytes + kSp12XFloats * 4;
 constexpr int kSp12W1Floats = 12 * 20 + 20;    // conv1 operands: [slot 4 dy + dx (dx = 3: zero)][20 couts] + bias[20], both times kSplitActScale
 constexpr int kSp12W2Vec = 6 * 2 * 2 * 64;     // conv2 operands: [k-step][M tile][piece][lane] x 16 bytes
+// ... followed (inference pack only) by the STACKED remainder tiles [pixel row R = 0..3][k half][piece][lane]: conv2's 20 output channels
+// are one full M tile and 4 rows of a second one; in the row-reuse walk below a fragment (pixel row R of a pooling group's 4 x 2
+// pixels) serves tap row R of the windows' upper output row and tap row R - 1 of their lower one, so the remainder channels' weights
+// for both uses share ONE A operand - rows 0..3: channels 16..19 at tap row R, rows 4..7: the same channels at tap row R - 1 (rows
+// that do not exist: zero) - and one MFMA triple per fragment does the work of two: 16 x 3 instead of 24 x 3 MFMAs per pooling group
+// on the remainder tile, -17 % of the conv2 MFMAs.  The upper row's sums come out in accumulator rows 0..3 (lane group 0), the lower
+// row's in rows 4..7 (lane group 1).
+constexpr int kSp12W2StackVec = 4 * 2 * 2 * 64;
+#ifndef SP_STACK
+#define SP_STACK 1           // conv1+conv2+pool1: the stacked remainder tiles (0: the plain second M tile, 37.5 % of whose rows are zero)
+#endif
+// element of a stacked tile: row r of the A operand of (pixel row R) -> (output channel, tap row) or nothing
+__host__ __device__ constexpr bool sp12_stack_row(int R, int r, int& o, int& dy) {
+    if (r < 4) { o = 16 + r; dy = R; return R <= 2; }
+    if (r < 8) { o = 16 + (r - 4); dy = R - 1; return R >= 1; }
+    o = 0; dy = 0; return false;
+}
 
 struct Split12Args {
     const float* in[kTowers];     // [n][32][32]; VOL: in[0] = the z-scored volume [dimx][dimy][dimz], patches are cut around `centers`
@@ -189,14 +206,25 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
     for (int t = 0; t < 9; ++t) a4[t] = w1[(4 * (t / 3) + t % 3) * 20 + 16 + (lane & 3)];   // couts 16..19 on the 4x4x1 blocks
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b1m[i] = w1[240 + 4 * j + i]; b1r[i] = w1[240 + 16 + i]; }
-    f16x8 wh[6][2], wl[6][2];
+    constexpr int MREG = (SP_STACK && SP_ROWREUSE) ? 1 : 2;      // M tiles held in the plain form (stacked: the full tile only)
+    f16x8 wh[6][MREG], wl[6][MREG];
 #pragma unroll
     for (int s = 0; s < 6; ++s)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MREG; ++m) {
             wh[s][m] = __builtin_bit_cast(f16x8, a.w2[tower][((s * 2 + m) * 2 + 0) * 64 + lane]);
             wl[s][m] = __builtin_bit_cast(f16x8, a.w2[tower][((s * 2 + m) * 2 + 1) * 64 + lane]);
         }
+#if SP_STACK && SP_ROWREUSE
+    f16x8 wsh[4][2], wsl[4][2];                                  // the stacked remainder tiles [pixel row R][k half]
+#pragma unroll
+    for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            wsh[R][hh] = __builtin_bit_cast(f16x8, a.w2[tower][kSp12W2Vec + ((R * 2 + hh) * 2 + 0) * 64 + lane]);
+            wsl[R][hh] = __builtin_bit_cast(f16x8, a.w2[tower][kSp12W2Vec + ((R * 2 + hh) * 2 + 1) * 64 + lane]);
+        }
+#endif
     f32x4 bias0, bias1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { bias0[i] = a.b2[tower][4 * j + i]; bias1[i] = a.b2[tower][16 + i]; }
@@ -217,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
         rs0 = x + 8 * (j & 1);
         rs1 = x + 8 - 8 * (j & 1);
     }
+    const int rs_up = ((n & 3) >> 1) * 1200;      // (stacked remainder of the odd tile: every column starts at its window's TOP pixel row)
     float vmax = 0.f;
     const float* inp = VOL ? a.in[0] : a.in[tower];
     unsigned char* outp = reinterpret_cast<unsigned char*>(a.out[tower]);
@@ -279,9 +308,14 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
             const unsigned char* h1 = s_hi + rd1[k];
             const unsigned char* l0 = s_lo + rd0[k];
             const unsigned char* l1 = s_lo + rd1[k];
-            f32x4 acc[4][2];
+            f32x4 acc[4][MREG];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { acc[q][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[q][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int m = 0; m < MREG; ++m) acc[q][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if SP_STACK && SP_ROWREUSE
+            f32x4 accs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // remainder channels: [column parity]; rows 0..3 upper, 4..7 lower output row
+#endif
 #if SP_ROWREUSE
             // fragment f = 4 R + 2 half + column parity: pixel row R (0..3) of the windows' 4 x 2 pixels, read ONCE and used by the window
             // row it serves as tap row R (output row 0) and as tap row R - 1 (output row 1): 16 fragment pairs per group instead of 24;
@@ -305,12 +339,17 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
                         if (dy < 0 || dy > 2) continue;
                         const int s = 2 * dy + hh, q = 2 * use + qc;
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) {
+                        for (int m = 0; m < MREG; ++m) {
                             if (piece == 0) acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][m], bh, acc[q][m], 0, 0, 0);
                             else if (piece == 1) acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bl, acc[q][m], 0, 0, 0);
                             else acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bh, acc[q][m], 0, 0, 0);
                         }
                     }
+#if SP_STACK
+                    if (piece == 0) accs[qc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsl[R][hh], bh, accs[qc], 0, 0, 0);
+                    else if (piece == 1) accs[qc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsh[R][hh], bl, accs[qc], 0, 0, 0);
+                    else accs[qc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsh[R][hh], bh, accs[qc], 0, 0, 0);
+#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -346,7 +385,14 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v0[i] = fmaxf(fmaxf(fmaxf(acc[0][0][i], acc[1][0][i]), fmaxf(acc[2][0][i], acc[3][0][i])) * inv + bias0[i], 0.f);
+#if SP_STACK && SP_ROWREUSE
+                // the window's four positions: two column parities in this lane, the lower output row in lane + 16 (accumulator rows 4..7)
+                const float up = fmaxf(accs[0][i], accs[1][i]);
+                const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __builtin_bit_cast(int, up)));
+                v1[i] = fmaxf(fmaxf(up, lo) * inv + bias1[i], 0.f);          // (read by lane group 0 only)
+#else
                 v1[i] = fmaxf(fmaxf(fmaxf(acc[0][1][i], acc[1][1][i]), fmaxf(acc[2][1][i], acc[3][1][i])) * inv + bias1[i], 0.f);
+#endif
             }
             sp12_store<OUT_SPLIT>(op, w, j, v0, v1, vmax);
         }
@@ -361,18 +407,36 @@ __global__ __launch_bounds__(256, 2) void conv12_split_kernel(Split12Args a) {
                 const int off = (s >> 1) * 1200 + (s & 1) * 64;
                 const f16x8 bh = sp_frag(h0 + off, h1 + off), bl = sp_frag(l0 + off, l1 + off);
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MREG; ++m) {
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s][m], bh, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bl, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s][m], bh, acc[m], 0, 0, 0);
                 }
             }
+#if SP_STACK && SP_ROWREUSE
+            // the remainder channels in the stacked form: every column walks the four pixel rows of ITS window from the top (columns of the
+            // lower output row repeat those of the upper one: their sums are the same numbers), rows 0..3 / 4..7 = upper / lower output row
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const int off = (f >> 1) * 1200 + (f & 1) * 64 - rs_up;
+                const f16x8 bh = sp_frag(h0 + off, h1 + off), bl = sp_frag(l0 + off, l1 + off);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsl[f >> 1][f & 1], bh, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsh[f >> 1][f & 1], bl, acc[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wsh[f >> 1][f & 1], bh, acc[1], 0, 0, 0);
+            }
+#endif
             const int w = 192 + (n >> 2);
             f32x4 v0, v1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v0[i] = fmaxf(sp_quad_max(acc[0][i]) * inv + bias0[i], 0.f);
+#if SP_STACK && SP_ROWREUSE
+                const float up = sp_quad_max(acc[1][i]);          // both column parities (and the repeated rows) of the window
+                const float lo = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane + 16) & 63) << 2, __builtin_bit_cast(int, up)));
+                v1[i] = fmaxf(fmaxf(up, lo) * inv + bias1[i], 0.f);
+#else
                 v1[i] = fmaxf(sp_quad_max(acc[1][i]) * inv + bias1[i], 0.f);
+#endif
             }
             if ((n & 3) == 0) sp12_store<OUT_SPLIT>(op, w, j, v0, v1, vmax);
         }

@@ -91,8 +91,9 @@ __global__ void pack_conv1_kernel(const float* __restrict__ W, const float* __re
 
 // ---- split operands (conv_split.h).  One workgroup per layer: weight scale = the power of two that puts max |folded weight| into
 // [2^12, 2^13), then every lane's 8 halves per (k-step, channel tile), high and low piece; bias [tiles * 16] + 1 / (act scale * weight scale)
+// stack: conv2 only - behind the plain tiles, the stacked remainder tiles of conv_split.h (kSp12W2StackVec; sp12_stack_row)
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ W, const float* __restrict__ bn, int cin, int cout,
-                                                         uint4* __restrict__ wp, float* __restrict__ bias) {
+                                                         uint4* __restrict__ wp, float* __restrict__ bias, int stack) {
     __shared__ float s_red[256];
     const int tid = threadIdx.x;
     float mx = 0.f;
@@ -122,6 +123,29 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
         }
         wp[((st * MT + m) * 2 + 0) * 64 + lane] = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
         wp[((st * MT + m) * 2 + 1) * 64 + lane] = make_uint4(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16));
+    }
+    if (stack) {
+        uint4* ws = wp + KS * MT * 2 * 64;
+        for (int idx = tid; idx < 4 * 2 * 64; idx += 256) {
+            const int lane = idx & 63, hh = (idx >> 6) & 1, R = idx >> 7, r = lane & 15, j = lane >> 4;
+            int o = 0, dy = 0;
+            const bool row = sp12_stack_row(R, r, o, dy);
+            unsigned short hb[8], lb[8];
+            for (int pos = 0; pos < 8; ++pos) {
+                const int e = 32 * hh + 8 * j + sp_chunk_elem(j, pos);
+                float v = 0.f;
+                if (row && e < 3 * cin && o < cout) {
+                    const int c = e % cin, dx = e / cin;
+                    v = W[((o * cin + c) * 3 + (2 - dy)) * 3 + (2 - dx)];
+                    v *= bn[cout + o] * bn[3 * cout + o];
+                    v *= sw;                                                              // (the roundings of the plain tiles above)
+                }
+                const _Float16 hv = (_Float16)v, lv = (_Float16)(v - (float)hv);
+                hb[pos] = __builtin_bit_cast(unsigned short, hv); lb[pos] = __builtin_bit_cast(unsigned short, lv);
+            }
+            ws[((R * 2 + hh) * 2 + 0) * 64 + lane] = make_uint4(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16), hb[4] | (hb[5] << 16), hb[6] | (hb[7] << 16));
+            ws[((R * 2 + hh) * 2 + 1) * 64 + lane] = make_uint4(lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16), lb[4] | (lb[5] << 16), lb[6] | (lb[7] << 16));
+        }
     }
     for (int n = tid; n < MT * 16; n += 256) bias[n] = n < cout ? bn[n] - bn[2 * cout + n] * bn[cout + n] * bn[3 * cout + n] : 0.f;
     if (tid == 0) bias[MT * 16] = 1.f / (kSplitActScale * sw);
@@ -469,7 +493,7 @@ static int alloc_packed(scs_ctx* h) {
         s_w1[t] = stake(kSp12W1Floats * 4);
         for (int i = 1; i < kConvs; ++i) {
             const int KS = 3 * ((3 * kCin[i] + 31) / 32), MT = (kCout[i] + 15) / 16;
-            s_w[t][i] = stake((size_t)KS * MT * 2 * 64 * 16); s_b[t][i] = stake((MT * 16 + 1) * 4);
+            s_w[t][i] = stake((size_t)KS * MT * 2 * 64 * 16 + (i == 1 ? (size_t)kSp12W2StackVec * 16 : 0)); s_b[t][i] = stake((MT * 16 + 1) * 4);
         }
     }
     for (int l = 0; l < 5; ++l) {
@@ -510,7 +534,7 @@ int repack_inference(scs_ctx* h, hipStream_t st) {
         hipLaunchKernelGGL(pack_split1_kernel, dim3(1), dim3(320), 0, st, P + T.convW[0], P + T.bn[0], const_cast<float*>(h->sp.w1[t]));
         for (int i = 1; i < kConvs; ++i)
             hipLaunchKernelGGL(pack_split_kernel, dim3(1), dim3(256), 0, st, P + T.convW[i], P + T.bn[i], kCin[i], kCout[i],
-                               const_cast<uint4*>(h->sp.w[t][i]), const_cast<float*>(h->sp.bias[t][i]));
+                               const_cast<uint4*>(h->sp.w[t][i]), const_cast<float*>(h->sp.bias[t][i]), i == 1 ? 1 : 0);
     }
     hipLaunchKernelGGL(pack_dense_kernel, dim3(128), dim3(256), 0, st, P + H.fc1W, P + H.fc1b, kFC1, kFC1, kFC1,
                        gemm_ns(kFC1), h->pk.fc1w, h->pk.fc1b);

@@ -14,13 +14,20 @@ dev = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to('
 ax, co, sa, at = [dev(a) for a in synth.patch_batch(B, seed=0)]
 y = dev(np.random.RandomState(0).randint(0, 15, B).astype(np.uint8), torch.uint8)
 st = torch.cuda.current_stream().cuda_stream
+FUSED = os.environ.get('SCS_ISSUE_FUSED', '1') != '0'          # the update inside the step (what bench.py times on one rank)
+if FUSED:
+    h.set_fused_adam(True)
+def one(i):
+    h.train_step(ax, co, sa, at, y, B, seed=i, want_loss=False, stream=st)
+    if not FUSED:
+        h.adam_apply(stream=st)
 for _ in range(20):
-    h.train_step(ax, co, sa, at, y, B, seed=1, want_loss=False, stream=st); h.adam_apply(stream=st)
+    one(1)
 torch.cuda.synchronize()
 for steps in (50, 200):
     t0 = time.perf_counter()
     for i in range(steps):
-        h.train_step(ax, co, sa, at, y, B, seed=i, want_loss=False, stream=st); h.adam_apply(stream=st)
+        one(i)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()

@@ -41,6 +41,19 @@ static std::vector<unsigned short> pack_split(const std::vector<float>& wc, int 
         pk[((((size_t)s * MT + m) * 2 + 0) * 64 + lane) * 8 + pos] = h_bits(h);
         pk[((((size_t)s * MT + m) * 2 + 1) * 64 + lane) * 8 + pos] = h_bits(l);
     }
+    if (cin == 20 && cout == 20) {              // conv2: the stacked remainder tiles behind the plain ones (conv_split.h: kSp12W2StackVec)
+        const size_t base = pk.size();
+        pk.resize(base + (size_t)kSp12W2StackVec * 8, 0);
+        for (int R = 0; R < 4; ++R) for (int hh = 0; hh < 2; ++hh) for (int lane = 0; lane < 64; ++lane) for (int pos = 0; pos < 8; ++pos) {
+            const int r = lane & 15, j = lane >> 4, e = 32 * hh + 8 * j + sp_chunk_elem(j, pos);
+            int o = 0, dy = 0;
+            float v = 0.f;
+            if (sp12_stack_row(R, r, o, dy) && e < 3 * cin) v = wc[(o * cin + e % cin) * 9 + dy * 3 + e / cin] * sw;
+            const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+            pk[base + ((((size_t)(R * 2 + hh)) * 2 + 0) * 64 + lane) * 8 + pos] = h_bits(h);
+            pk[base + ((((size_t)(R * 2 + hh)) * 2 + 1) * 64 + lane) * 8 + pos] = h_bits(l);
+        }
+    }
     return pk;
 }
 

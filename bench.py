@@ -92,7 +92,8 @@ def usable_cpus():
     expose 256 logical CPUs but grant a 16-CPU share; 256 torch threads on that share run 100x slower)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
         if quota != 'max':
             n = min(n, max(1, int(int(quota) / int(period))))
     except Exception:

@@ -6,7 +6,7 @@
 #   separate runs, no trace domains beside them).  Results land in gpurun_out/; tools/pmc_traffic.py then writes
 #   profiles/traffic.json against gpurun_out/csrc_sha16.txt.
 set -o pipefail
-R=${1:-r05}
+R=${1:-r06}
 PART=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out

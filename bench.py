@@ -745,9 +745,9 @@ def main():
                 'pipe_rate_at_that_clock_tflops': cus * 4 * 2048 / 32 * ghz * 1e9 / 1e12 if ghz else None,
                 'what': 'back-to-back v_mfma_f32_16x16x4_f32, independent accumulators, operands in registers, four waves per SIMD on '
                         'every CU (scs_probe_f32_mfma_clock, three launches of ~4 ms, the last one timed, this process), and the shader clock the '
-                        'device held meanwhile (s_memtime / s_memrealtime x 100 MHz, median over the workgroups).  The nominal peak prices the '
-                        'instruction at 32 cycles of 2.4 GHz; the probe runs at ~97 % of the pipe rate in cycles, so its spread over devices and '
-                        'runs is the clock.  Informational: `frac` above is against the nominal peak'}
+                        'device held meanwhile (s_memtime / s_memrealtime x 100 MHz, median over the workgroups; constant operands: the least power '
+                        'an MFMA loop can draw).  The nominal peak prices the instruction at 32 cycles of 2.4 GHz; tflops / pipe_rate_at_that_clock '
+                        'is the share of the pipe the loop reaches in cycles.  Informational: `frac` above is against the nominal peak'}
         except Exception as e:                                            # informational: never fails the bench line
             out['roofline']['device_mfma_issue_rate'] = {'error': str(e)}
         out['stages'] = {names[i]: {'ms_per_step': float(ms[i]),

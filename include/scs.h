@@ -120,8 +120,8 @@ int scs_get_option(scs_handle h, const char* name, int64_t* value);
  * same process as the kernels it is set beside.  No reference counterpart.  Synchronises the device. */
 int scs_probe_f32_mfma(scs_handle h, double* tflops);
 /* The same probe, and the SHADER CLOCK the device held while it ran (GHz; median over the workgroups of d s_memtime / d s_memrealtime
- * x 100 MHz around the loop): the probe's rate differs between devices and runs (126-139 TFLOP/s seen on this pool) because that clock
- * does - in cycles the loop runs at 97 % of the pipe rate (32 cycles per instruction and SIMD) on all of them. */
+ * x 100 MHz around the loop), so that a reader can tell a clock difference between devices or runs (126-139 TFLOP/s seen on this pool)
+ * from an issue-rate difference: rate / (CUs x 4 SIMDs x 2048 FLOP / 32 cycles x clock) is the share of the pipe the loop reaches. */
 int scs_probe_f32_mfma_clock(scs_handle h, double* tflops, double* shader_ghz);
 
 /* Deterministic forward on n patches (device pointers).  probs and/or labels may be NULL.

@@ -22,6 +22,16 @@ def gold(name):
     return np.load(os.path.join(GOLD, name), allow_pickle=False)
 
 
+def exact_f32_form(obj):
+    """Pin a libscs handle (or a Net's) to the exact-f32 kernels whatever SCS_FWD_SPLIT / SCS_TRAIN_SPLIT say in the environment: for the
+    tests that compare two FORMS of the f32 path bit for bit (the split forms give the oracle's numbers to the same bars, not the f32
+    path's bits: tests/test_gpu_split.py, test_gpu_train_split.py).  Returns the object."""
+    h = obj._ensure_handle() if hasattr(obj, '_ensure_handle') else obj
+    h.set_option('fwd_split', 0)
+    h.set_option('train_split', 0)
+    return obj
+
+
 @pytest.fixture(scope='session')
 def weights():
     from cnn_cort import params as P

@@ -15,7 +15,8 @@ KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', '
 
 
 def run_bench(args):
-    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    # (the line under test is the DEFAULT one: whatever forces an option form on the suite from outside stays outside)
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'SCS_FWD_SPLIT', 'SCS_TRAIN_SPLIT', 'SCS_SPLIT_HEAD')}
     env['SCS_BENCH_CPU_BUDGET'] = '2'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -85,7 +85,11 @@ def test_per_layer_activations(handle, weights):
     close(feat, np.concatenate([tr['%s_d1' % t] for t in towers], axis=1), 'd1 concat')
     fc1 = handle.get_activation(5, n * 556).reshape(n, 556)
     close(fc1[:, :540], tr['FC1'], 'FC1')
-    assert np.array_equal(fc1[:, 540:555], args[3]) and np.all(fc1[:, 555] == 0)
+    if handle.get_option('fwd_split') > 0:     # (forced on from the environment: the prior columns travel as two f16 pieces, 22 bits)
+        close(fc1[:, 540:555], args[3], 'prior columns')
+    else:
+        assert np.array_equal(fc1[:, 540:555], args[3])
+    assert np.all(fc1[:, 555] == 0)
     fc2 = handle.get_activation(6, n * 272).reshape(n, 272)
     close(fc2[:, :270], tr['fc_2'], 'fc_2')
     logits = handle.get_activation(7, n * 16).reshape(n, 16)

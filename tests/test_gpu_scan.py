@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import PKG
+from conftest import PKG, exact_f32_form
 from cnn_cort import base, nifti
 from cnn_cort.nets import build_model
 from oracle import np_oracle as O, patches_ref as R
@@ -183,7 +183,7 @@ def test_shared_tower_evaluation_gives_the_bits_of_the_patch_path(weights, case)
     border, for degenerate boxes and for a sparse centre list - with host and with device-resident inputs."""
     import torch
     vol, centers, atlas = _roi_case(case)
-    net = build_model(os.path.join(PKG, 'nets'), options('/nonexistent'))
+    net = exact_f32_form(build_model(os.path.join(PKG, 'nets'), options('/nonexistent')))
     lp, pp = net.predict_volume(vol, centers, atlas_rows=atlas, want_probs=True, batch=10 ** 9, towers='patch')
     assert net.last_scan_towers == 'patch'
     ls, ps = net.predict_volume(vol, centers, atlas_rows=atlas, want_probs=True, towers='shared')
@@ -322,7 +322,7 @@ def test_full_size_subject_of_baseline_config_4(tmp_path, weights):
     scan = bench.make_cohort(str(tmp_path), 1, seed=3, steered=True)[0]
     sub = os.path.dirname(scan)
     opts = options(str(tmp_path), test_batch_size=100000)
-    net = build_model(os.path.join(PKG, 'nets'), opts)
+    net = exact_f32_form(build_model(os.path.join(PKG, 'nets'), opts))      # shared-tower maps against per-voxel towers, bit for bit
     minutes = base.test_scan(net, scan, opts)
     assert 0 <= minutes < 1.0
     raw = nifti.load(scan).get_data()

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import gold
+from conftest import exact_f32_form, gold
 from cnn_cort import dist, params as P
 from oracle import np_oracle as O
 
@@ -510,7 +510,7 @@ def test_conv5_backward_as_one_launch_against_the_generic_kernels(weights, monke
     from cnn_cort import synth, _hip
     out = {}
     for form, bound in (("generic", "0"), ("fused", "1024"), ("fused again", "1024")):
-        h = _hip.Handle(0)
+        h = exact_f32_form(_hip.Handle(0))      # (the 2e-6 bar below is for two forms of ONE step: the f32 one, whatever the environment says)
         h.set_option('c5_fused_max_batch', int(bound))
         h.set_option('tail_fused', 0)           # (the conv5 backward kernels alone: with tail_fused the forward differs in the order of two sums)
         h.set_params(P.params_to_flat(weights))

@@ -20,6 +20,9 @@ def main():
     for B in (256, 128):
         h = _hip.Handle(0)
         h.set_params(P.params_to_flat(weights))
+        fused = os.environ.get('SCS_ISSUE_FUSED', '1') != '0'       # the update inside the step, as bench.py runs one rank (a probe: a
+        if fused:                                                    # replayed graph repeats the captured step's Adam coefficients)
+            h.set_fused_adam(True)
         ax, co, sa, at, y = bench.train_inputs(torch, B, 0, 'cuda:0')
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
@@ -27,7 +30,8 @@ def main():
 
             def step(seed):
                 h.train_step(ax, co, sa, at, y, B, seed=seed, want_loss=False, stream=st)
-                h.adam_apply(stream=st)
+                if not fused:
+                    h.adam_apply(stream=st)
             for i in range(20):
                 step(5 + i)
             torch.cuda.synchronize()

@@ -758,7 +758,7 @@ def test_banded_tilings_of_the_middle_layers_against_the_whole_patch_tilings(wei
     from cnn_cort import synth, _hip
     out = {}
     for form in ('whole', 'bands', 'bands again'):
-        h = _hip.Handle(0)
+        h = exact_f32_form(_hip.Handle(0))      # (two tilings of ONE step: the f32 one)
         h.set_params(P.params_to_flat(weights))
         h.set_option('split_max_batch', 0 if form == 'whole' else 128)
         st = torch.cuda.current_stream().cuda_stream

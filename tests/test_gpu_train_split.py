@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from cnn_cort import params as P
+from conftest import exact_f32_form
 from test_gpu_train import _step_against_gate_aware_oracle, dev, arena, fresh   # noqa: F401  (fresh: fixture)
 
 pytestmark = pytest.mark.gpu
@@ -152,8 +153,10 @@ def test_fit_with_the_fit_split_option(weights, tmp_path):
         d.mkdir()
         net = nets.build_model(str(d), dict(opt, fit_split='True') if key == 'split' else dict(opt))
         net.load_params_from({k: [a.copy() for a in v] for k, v in weights.items()})
+        if key == 'f32':
+            exact_f32_form(net)                   # (the comparison's other side, whatever SCS_TRAIN_SPLIT says in the environment)
         net.fit(X, y)
-        assert net._handle.get_option('train_split') == (1 if key == 'split' else -1)
+        assert net._handle.get_option('train_split') == (1 if key == 'split' else 0)
         hist[key] = [(r['train_loss'], r['valid_loss']) for r in net.train_history_]
     assert len(hist['split']) == 2 and all(np.isfinite(v) for r in hist['split'] for v in r)
     for a, b in zip(hist['split'], hist['f32']):
